@@ -1,0 +1,107 @@
+/* lotus_hip.h - C ABI of the MI355X-native LOTUS embedding-retrieval hot path (liblotus_hip.so).
+ *
+ * The reference (lotus-data/lotus, pure Python) has no FFI of its own: its arithmetic is the third-party
+ * faiss-cpu wheel reached through SWIG.  Every entry point below names the reference call it replaces
+ * (paths relative to the reference checkout).  Host code (Python/ctypes today - see INTEGRATION.md) binds
+ * exactly these symbols.
+ *
+ * Conventions
+ *   - every function returns int32 status: LVS_OK (0) or a negative LVS_E*; lvs_last_error() gives the
+ *     thread-local message of the last failure.
+ *   - all data pointers are DEVICE pointers (HBM) unless the name ends in _host; the caller owns every buffer;
+ *     the library allocates nothing and keeps no pointer after a call returns (work is enqueued on `stream`,
+ *     a hipStream_t passed as void*, NULL = default stream).
+ *   - "rows" matrices are the library's device layout produced by lvs_pack_rows(): fp16, row-major, leading
+ *     dimension lvs_packed_ld(d, mode) halfs.
+ *   - result keys: one uint64 per (query, rank): ord32(score where larger = better) << 32 | (0xFFFFFFFF - id);
+ *     descending key order == (score best-first, id ascending); key 0 == empty slot (fewer than k rows).
+ */
+#ifndef LOTUS_HIP_H
+#define LOTUS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LVS_ABI_VERSION 1
+
+#define LVS_OK 0
+#define LVS_EINVAL (-1)   /* bad argument */
+#define LVS_ENOMEM (-2)   /* workspace too small */
+#define LVS_EDEVICE (-3)  /* HIP runtime error */
+#define LVS_EUNSUPPORTED (-4)
+
+/* element types of caller-side embeddings */
+#define LVS_DTYPE_F32 0
+#define LVS_DTYPE_F16 1
+
+/* metrics; values follow faiss.METRIC_INNER_PRODUCT / METRIC_L2 (lotus/vector_store/faiss_vs.py:14) */
+#define LVS_METRIC_IP 0
+#define LVS_METRIC_L2 1
+
+/* packed-row modes */
+#define LVS_PACK_F16 0   /* fp16 values, one MFMA pass (embeddings stored as fp16) */
+#define LVS_PACK_SPLIT 1 /* fp32 values carried as fp16 hi|lo pair, three MFMA passes, ~2^-21 relative error */
+
+/* largest k lvs_flat_search_keys accepts (it runs ceil(k/24) passes over the corpus) */
+#define LVS_MAX_K 2048
+
+int32_t lvs_abi_version(void);
+const char* lvs_last_error(void);
+
+/* Device discovery (no reference counterpart; the reference is CPU-only). */
+int32_t lvs_device_count(int32_t* out_count);
+int32_t lvs_device_info(int32_t device, char* name, int32_t name_cap, int32_t* out_cus, int64_t* out_hbm_bytes);
+
+/* ---- packing: replaces faiss `index.add(embeddings)` (faiss_vs.py:24,64) and the python-wrapper cast of
+ * `query_vectors` (faiss_vs.py:67,75): C-contiguous float32 -> device fp16 rows. ---- */
+int32_t lvs_packed_ld(int32_t d, int32_t pack_mode);        /* leading dimension in halfs, or <0 */
+/* src: [n][d] of src_dtype (device). dst: [n][ld] fp16 (device). If normalize != 0 rows are L2-normalised in
+ * fp32 before rounding (cosine = inner product of normalised rows; sentence_transformers_rm.py:30,71).
+ * out_norms_sq (nullable): [n] float32 |x_i|^2 of the stored (rounded) values, used by the L2 metric. */
+int32_t lvs_pack_rows(const void* src, int32_t src_dtype, int64_t n, int32_t d, int32_t pack_mode,
+                      int32_t normalize, void* dst, float* out_norms_sq, void* stream);
+/* dst[i] = src[ids[i]] for packed rows (the `ids` branch gather, faiss_vs.py:59-64). */
+int32_t lvs_gather_rows(const void* src, int32_t ld, const int64_t* ids, int64_t n_ids, void* dst, void* stream);
+/* dst[i] = src[ids[i]] for a float32 vector (row norms of a gathered subset). */
+int32_t lvs_gather_f32(const float* src, const int64_t* ids, int64_t n_ids, float* dst, void* stream);
+
+/* ---- exact top-k search: replaces faiss `IndexFlat::search` behind `index.search(query_vectors, K)`
+ * (faiss_vs.py:67,75) - tiled MFMA distance + fused per-query top-k. ---- */
+/* bytes of scratch lvs_flat_search_keys needs for this problem */
+int64_t lvs_flat_search_workspace_bytes(int64_t nq, int64_t nb, int32_t d, int32_t pack_mode, int32_t k);
+/* xb: [nb][ld] packed corpus shard, xq: [nq][ld] packed queries.
+ * xb_norms_sq / xq_norms_sq: |.|^2 per row, required for LVS_METRIC_L2, ignored for IP.
+ * id_offset: global id of shard row 0 (keys carry global ids < 2^32).
+ * row_ids (nullable): [nb] uint32 - id to report for each shard row instead of id_offset + row (subset search).
+ * out_keys: [nq][k] uint64, best first. */
+int32_t lvs_flat_search_keys(const void* xb, int64_t nb, const void* xq, int64_t nq, int32_t d, int32_t pack_mode,
+                             int32_t metric, int32_t k, const float* xb_norms_sq, const float* xq_norms_sq,
+                             int64_t id_offset, const uint32_t* row_ids, uint64_t* out_keys, void* workspace,
+                             int64_t workspace_bytes, void* stream);
+/* Merge `nparts` candidate lists (e.g. the all-gathered per-shard lists): parts [nparts][nq][k] -> out [nq][k]. */
+int32_t lvs_merge_keys(const uint64_t* parts, int32_t nparts, int64_t nq, int32_t k, uint64_t* out_keys,
+                       void* stream);
+/* keys -> faiss-shaped result (faiss_vs.py:67,75 return values): D float32 [nq][k], I int64 [nq][k];
+ * empty slots become I = -1, D = -FLT_MAX (IP) / +FLT_MAX (L2).  id_map (nullable): I = id_map[id]
+ * (the sub-index -> global id remap of faiss_vs.py:71-72). */
+int32_t lvs_keys_to_result(const uint64_t* keys, int64_t nq, int32_t k, int32_t metric, const int64_t* id_map,
+                           float* out_D, int64_t* out_I, void* stream);
+
+/* ---- full score rows (callers that ask for K = N: sem_dedup.py:45, sem_filter.py:491-497, sem_join.py:367):
+ * out [nq][ld_out] float32 "better" scores (IP: the product; L2: minus the squared distance). ---- */
+int32_t lvs_scores(const void* xb, int64_t nb, const void* xq, int64_t nq, int32_t d, int32_t pack_mode,
+                   int32_t metric, const float* xb_norms_sq, const float* xq_norms_sq, float* out, int64_t ld_out,
+                   void* stream);
+/* ---- measurement hook: average duration in ms of the dominant search kernel's launches since the last reset,
+ * measured with HIP events on the launch stream (enabled with lvs_timing_enable(1)). ---- */
+int32_t lvs_timing_enable(int32_t on);
+int32_t lvs_timing_read(double* out_total_ms, int64_t* out_launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LOTUS_HIP_H */

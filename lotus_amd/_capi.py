@@ -1,0 +1,88 @@
+"""ctypes binding of ``liblotus_hip.so`` (C ABI in ``include/lotus_hip.h``).
+
+The binding is deliberately thin: every function takes raw device addresses (ints) and sizes.  Loading fails
+loudly when the library has not been built; there is no fallback implementation."""
+from __future__ import annotations
+
+import ctypes
+import os
+import re
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liblotus_hip.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "lotus_hip.h")
+
+OK, EINVAL, ENOMEM, EDEVICE, EUNSUPPORTED = 0, -1, -2, -3, -4
+DTYPE_F32, DTYPE_F16 = 0, 1
+METRIC_IP, METRIC_L2 = 0, 1
+PACK_F16, PACK_SPLIT = 0, 1
+MAX_K = 2048
+
+_i32, _i64, _vp, _dbl = ctypes.c_int32, ctypes.c_int64, ctypes.c_void_p, ctypes.c_double
+
+# name -> (restype, argtypes); must list every symbol declared in include/lotus_hip.h
+SIGNATURES = {
+    "lvs_abi_version": (_i32, []),
+    "lvs_last_error": (ctypes.c_char_p, []),
+    "lvs_device_count": (_i32, [ctypes.POINTER(_i32)]),
+    "lvs_device_info": (_i32, [_i32, ctypes.c_char_p, _i32, ctypes.POINTER(_i32), ctypes.POINTER(_i64)]),
+    "lvs_packed_ld": (_i32, [_i32, _i32]),
+    "lvs_pack_rows": (_i32, [_vp, _i32, _i64, _i32, _i32, _i32, _vp, _vp, _vp]),
+    "lvs_gather_rows": (_i32, [_vp, _i32, _vp, _i64, _vp, _vp]),
+    "lvs_gather_f32": (_i32, [_vp, _vp, _i64, _vp, _vp]),
+    "lvs_flat_search_workspace_bytes": (_i64, [_i64, _i64, _i32, _i32, _i32]),
+    "lvs_flat_search_keys": (_i32, [_vp, _i64, _vp, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _i64, _vp, _vp, _vp,
+                                    _i64, _vp]),
+    "lvs_merge_keys": (_i32, [_vp, _i32, _i64, _i32, _vp, _vp]),
+    "lvs_keys_to_result": (_i32, [_vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp]),
+    "lvs_scores": (_i32, [_vp, _i64, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _i64, _vp]),
+    "lvs_timing_enable": (_i32, [_i32]),
+    "lvs_timing_read": (_i32, [ctypes.POINTER(_dbl), ctypes.POINTER(_i64)]),
+}
+
+
+class LotusHipError(RuntimeError):
+    """A C-ABI call returned a non-zero status."""
+
+
+_lib = None
+
+
+def declared_symbols() -> list[str]:
+    """Function names declared in include/lotus_hip.h."""
+    with open(HEADER_PATH) as f:
+        text = f.read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(lvs_[a-z0-9_]+)\s*\(", text)))
+
+
+def load():
+    """dlopen the library and bind every declared symbol.  Raises if the library is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise LotusHipError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). lotus_amd has no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    if lib.lvs_abi_version() != 1:
+        raise LotusHipError(f"ABI version mismatch: library reports {lib.lvs_abi_version()}")
+    _lib = lib
+    return lib
+
+
+def check(status: int, what: str = "") -> None:
+    if status != OK:
+        msg = load().lvs_last_error().decode("utf-8", "replace")
+        raise LotusHipError(f"{what or 'lotus_hip call'} failed with status {status}: {msg}")
+
+
+def device_count() -> int:
+    n = _i32(0)
+    st = load().lvs_device_count(ctypes.byref(n))
+    return int(n.value) if st == OK else 0

@@ -1,0 +1,150 @@
+"""Device backend: torch provides HBM buffers, streams and (for multi-GPU) RCCL; every compute step is a C-ABI call
+into liblotus_hip.so.  No CPU fallback - constructing the backend without a GPU raises."""
+from __future__ import annotations
+
+import ctypes
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import _capi
+from ._capi import LotusHipError
+
+
+@dataclass
+class PackedRows:
+    """Device image of an embedding matrix: fp16 rows [n, ld] (+ |x|^2 per row)."""
+
+    rows: "object"  # torch.Tensor float16 [n, ld]
+    norms: "object"  # torch.Tensor float32 [n]
+    n: int
+    d: int
+    mode: int  # _capi.PACK_F16 | _capi.PACK_SPLIT
+
+
+def _ptr(t) -> int:
+    return 0 if t is None else int(t.data_ptr())
+
+
+class HipBackend:
+    PACK_CHUNK_ROWS = 262144
+
+    def __init__(self, device=None):
+        import torch
+
+        self.torch = torch
+        self.lib = _capi.load()
+        if not torch.cuda.is_available():
+            raise LotusHipError("lotus_amd needs a ROCm GPU (torch.cuda.is_available() is False); no CPU fallback")
+        self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+        self._ws = None
+
+    # ---- plumbing ----
+    def _stream(self) -> int:
+        return int(self.torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _workspace(self, nbytes: int):
+        if self._ws is None or self._ws.numel() < nbytes:
+            self._ws = self.torch.empty(max(nbytes, 1 << 20), dtype=self.torch.uint8, device=self.device)
+        return self._ws
+
+    def synchronize(self) -> None:
+        self.torch.cuda.synchronize(self.device)
+
+    def to_device(self, arr: np.ndarray):
+        return self.torch.from_numpy(np.ascontiguousarray(arr)).to(self.device)
+
+    # ---- packing ----
+    def pack(self, x, mode: int, normalize: bool = False) -> PackedRows:
+        """x: numpy [n,d] (float16/32/64) or a torch CUDA tensor (float16/float32)."""
+        torch = self.torch
+        is_tensor = torch.is_tensor(x)
+        n, d = int(x.shape[0]), int(x.shape[1])
+        ld = int(self.lib.lvs_packed_ld(d, mode))
+        if ld <= 0:
+            raise LotusHipError(f"bad dimension d={d}")
+        rows = torch.empty((n, ld), dtype=torch.float16, device=self.device)
+        norms = torch.empty((n,), dtype=torch.float32, device=self.device)
+        step = self.PACK_CHUNK_ROWS
+        for r0 in range(0, n, step):
+            r1 = min(n, r0 + step)
+            if is_tensor:
+                chunk = x[r0:r1].contiguous()
+                if chunk.dtype not in (torch.float16, torch.float32):
+                    chunk = chunk.to(torch.float32)
+                if chunk.device != self.device:
+                    chunk = chunk.to(self.device)
+            else:
+                c = x[r0:r1]
+                c = np.ascontiguousarray(c, dtype=np.float16 if c.dtype == np.float16 else np.float32)
+                chunk = torch.from_numpy(c).to(self.device)
+            src_dtype = _capi.DTYPE_F16 if chunk.dtype == torch.float16 else _capi.DTYPE_F32
+            _capi.check(self.lib.lvs_pack_rows(_ptr(chunk), src_dtype, r1 - r0, d, mode, int(bool(normalize)),
+                                               _ptr(rows[r0:r1]), _ptr(norms[r0:r1]), self._stream()), "lvs_pack_rows")
+            del chunk
+        return PackedRows(rows=rows, norms=norms, n=n, d=d, mode=mode)
+
+    def gather(self, src: PackedRows, ids_dev) -> PackedRows:
+        torch = self.torch
+        m = int(ids_dev.numel())
+        ld = int(src.rows.shape[1])
+        rows = torch.empty((m, ld), dtype=torch.float16, device=self.device)
+        norms = torch.empty((m,), dtype=torch.float32, device=self.device)
+        _capi.check(self.lib.lvs_gather_rows(_ptr(src.rows), ld, _ptr(ids_dev), m, _ptr(rows), self._stream()),
+                    "lvs_gather_rows")
+        _capi.check(self.lib.lvs_gather_f32(_ptr(src.norms), _ptr(ids_dev), m, _ptr(norms), self._stream()),
+                    "lvs_gather_f32")
+        return PackedRows(rows=rows, norms=norms, n=m, d=src.d, mode=src.mode)
+
+    # ---- search ----
+    def search_keys(self, corpus: PackedRows, queries: PackedRows, k: int, metric: int, id_offset: int = 0,
+                    row_ids=None):
+        """-> int64 tensor [nq, k] holding the uint64 result keys (bit pattern)."""
+        torch = self.torch
+        if corpus.d != queries.d or corpus.mode != queries.mode:
+            raise ValueError("corpus / query layout mismatch")
+        keys = torch.empty((queries.n, k), dtype=torch.int64, device=self.device)
+        need = int(self.lib.lvs_flat_search_workspace_bytes(queries.n, corpus.n, corpus.d, corpus.mode, k))
+        if need < 0:
+            raise LotusHipError("lvs_flat_search_workspace_bytes rejected the shape")
+        ws = self._workspace(need)
+        _capi.check(self.lib.lvs_flat_search_keys(
+            _ptr(corpus.rows), corpus.n, _ptr(queries.rows), queries.n, corpus.d, corpus.mode, metric, k,
+            _ptr(corpus.norms), _ptr(queries.norms), int(id_offset), _ptr(row_ids), _ptr(keys), _ptr(ws),
+            int(ws.numel()), self._stream()), "lvs_flat_search_keys")
+        return keys
+
+    def merge_keys(self, parts):
+        """parts int64 [P, nq, k] -> [nq, k]."""
+        torch = self.torch
+        P, nq, k = (int(s) for s in parts.shape)
+        out = torch.empty((nq, k), dtype=torch.int64, device=self.device)
+        _capi.check(self.lib.lvs_merge_keys(_ptr(parts.contiguous()), P, nq, k, _ptr(out), self._stream()),
+                    "lvs_merge_keys")
+        return out
+
+    def keys_to_result(self, keys, metric: int, id_map=None):
+        torch = self.torch
+        nq, k = int(keys.shape[0]), int(keys.shape[1])
+        D = torch.empty((nq, k), dtype=torch.float32, device=self.device)
+        I = torch.empty((nq, k), dtype=torch.int64, device=self.device)
+        _capi.check(self.lib.lvs_keys_to_result(_ptr(keys), nq, k, metric, _ptr(id_map), _ptr(D), _ptr(I),
+                                                self._stream()), "lvs_keys_to_result")
+        return D, I
+
+    def scores(self, corpus: PackedRows, queries: PackedRows, metric: int):
+        torch = self.torch
+        out = torch.empty((queries.n, corpus.n), dtype=torch.float32, device=self.device)
+        _capi.check(self.lib.lvs_scores(_ptr(corpus.rows), corpus.n, _ptr(queries.rows), queries.n, corpus.d,
+                                        corpus.mode, metric, _ptr(corpus.norms), _ptr(queries.norms), _ptr(out),
+                                        corpus.n, self._stream()), "lvs_scores")
+        return out
+
+    # ---- measurement ----
+    def timing_enable(self, on: bool) -> None:
+        _capi.check(self.lib.lvs_timing_enable(int(on)))
+
+    def timing_read(self):
+        tot, cnt = ctypes.c_double(0), ctypes.c_int64(0)
+        _capi.check(self.lib.lvs_timing_read(ctypes.byref(tot), ctypes.byref(cnt)))
+        return float(tot.value), int(cnt.value)

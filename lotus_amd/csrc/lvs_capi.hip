@@ -1,0 +1,469 @@
+// C-ABI of liblotus_hip (see include/lotus_hip.h) + the small streaming kernels around the tile kernel:
+// row packing (fp32/fp16 -> fp16 or fp16 hi|lo), row gather, candidate-list merge, key decoding.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <mutex>
+#include <vector>
+
+#include "lvs_common.h"
+#include "lvs_tile.h"
+
+// ---------------------------------------------------------------------------------------------------------------
+// error plumbing
+// ---------------------------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+void lvs_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char* lvs_last_error(void) { return g_err; }
+extern "C" int32_t lvs_abi_version(void) { return LVS_ABI_VERSION; }
+
+extern "C" int32_t lvs_device_count(int32_t* out_count) {
+    LVS_REQUIRE(out_count, "out_count is NULL");
+    int n = 0;
+    LVS_HIP_CHECK(hipGetDeviceCount(&n));
+    *out_count = n;
+    return LVS_OK;
+}
+
+extern "C" int32_t lvs_device_info(int32_t device, char* name, int32_t name_cap, int32_t* out_cus,
+                                   int64_t* out_hbm_bytes) {
+    hipDeviceProp_t p;
+    LVS_HIP_CHECK(hipGetDeviceProperties(&p, device));
+    if (name && name_cap > 0) {
+        snprintf(name, (size_t)name_cap, "%s (%s)", p.name, p.gcnArchName);
+    }
+    if (out_cus) *out_cus = p.multiProcessorCount;
+    if (out_hbm_bytes) *out_hbm_bytes = (int64_t)p.totalGlobalMem;
+    return LVS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// timing hook (HIP events on the launch stream around the dominant kernel)
+// ---------------------------------------------------------------------------------------------------------------
+namespace {
+struct TimingState {
+    std::mutex mu;
+    bool on = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+    double total_ms = 0;
+    int64_t launches = 0;
+} g_timing;
+
+struct ScopedKernelTimer {
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipStream_t s;
+    bool on;
+    explicit ScopedKernelTimer(hipStream_t st) : s(st) {
+        std::lock_guard<std::mutex> lk(g_timing.mu);
+        on = g_timing.on;
+        if (on) {
+            if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) {
+                on = false;
+                return;
+            }
+            (void)hipEventRecord(e0, s);
+        }
+    }
+    ~ScopedKernelTimer() {
+        if (!on) return;
+        (void)hipEventRecord(e1, s);
+        std::lock_guard<std::mutex> lk(g_timing.mu);
+        g_timing.pending.emplace_back(e0, e1);
+    }
+};
+}  // namespace
+
+extern "C" int32_t lvs_timing_enable(int32_t on) {
+    std::lock_guard<std::mutex> lk(g_timing.mu);
+    g_timing.on = on != 0;
+    for (auto& pr : g_timing.pending) {
+        (void)hipEventDestroy(pr.first);
+        (void)hipEventDestroy(pr.second);
+    }
+    g_timing.pending.clear();
+    g_timing.total_ms = 0;
+    g_timing.launches = 0;
+    return LVS_OK;
+}
+
+extern "C" int32_t lvs_timing_read(double* out_total_ms, int64_t* out_launches) {
+    std::lock_guard<std::mutex> lk(g_timing.mu);
+    for (auto& pr : g_timing.pending) {
+        LVS_HIP_CHECK(hipEventSynchronize(pr.second));
+        float ms = 0;
+        LVS_HIP_CHECK(hipEventElapsedTime(&ms, pr.first, pr.second));
+        g_timing.total_ms += ms;
+        g_timing.launches += 1;
+        (void)hipEventDestroy(pr.first);
+        (void)hipEventDestroy(pr.second);
+    }
+    g_timing.pending.clear();
+    if (out_total_ms) *out_total_ms = g_timing.total_ms;
+    if (out_launches) *out_launches = g_timing.launches;
+    return LVS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// packing
+// ---------------------------------------------------------------------------------------------------------------
+extern "C" int32_t lvs_packed_ld(int32_t d, int32_t pack_mode) {
+    if (d <= 0) return LVS_EINVAL;
+    int64_t dpad = lvs_round_up(d, LVS_BK);
+    if (pack_mode == LVS_PACK_F16) return (int32_t)dpad;
+    if (pack_mode == LVS_PACK_SPLIT) return (int32_t)(2 * dpad);
+    return LVS_EINVAL;
+}
+
+namespace {
+
+__device__ inline float wave_sum(float v) {
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+
+// one wave per row
+template <typename SrcT>
+__global__ __launch_bounds__(256) void pack_rows_kernel(const SrcT* __restrict__ src, long long n, int d, int dpad,
+                                                        int split, int normalize, _Float16* __restrict__ dst,
+                                                        float* __restrict__ norms) {
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= n) return;
+    const SrcT* s = src + row * (long long)d;
+    const int ld = split ? 2 * dpad : dpad;
+    _Float16* o = dst + row * (long long)ld;
+    float scale = 1.0f;
+    if (normalize) {
+        float ss = 0.f;
+        for (int j = lane; j < d; j += 64) {
+            float x = (float)s[j];
+            ss += x * x;
+        }
+        ss = wave_sum(ss);
+        scale = ss > 0.f ? 1.0f / sqrtf(ss) : 0.f;
+    }
+    float nn = 0.f;
+    for (int j = lane; j < dpad; j += 64) {
+        float x = j < d ? (float)s[j] * scale : 0.f;
+        _Float16 hi = (_Float16)x;
+        float stored = (float)hi;
+        o[j] = hi;
+        if (split) {
+            _Float16 lo = (_Float16)(x - (float)hi);
+            o[dpad + j] = lo;
+            stored += (float)lo;
+        }
+        nn += stored * stored;
+    }
+    if (norms) {
+        nn = wave_sum(nn);
+        if (lane == 0) norms[row] = nn;
+    }
+}
+
+__global__ __launch_bounds__(256) void gather_rows_kernel(const uint4* __restrict__ src, long long ld16,
+                                                          const long long* __restrict__ ids, long long n_ids,
+                                                          uint4* __restrict__ dst) {
+    const long long total = n_ids * ld16;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        long long r = i / ld16, c = i - r * ld16;
+        dst[i] = src[ids[r] * ld16 + c];
+    }
+}
+
+__global__ __launch_bounds__(256) void gather_f32_kernel(const float* __restrict__ src, const long long* __restrict__ ids,
+                                                         long long n_ids, float* __restrict__ dst) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_ids) dst[i] = src[ids[i]];
+}
+
+// one wave per query: merge nparts sorted-or-not candidate lists of k keys into the best k (k <= 64)
+__global__ __launch_bounds__(256) void merge_keys_kernel(const u64* __restrict__ parts, int nparts, long long nq, int k,
+                                                         u64* __restrict__ out, long long out_ld) {
+    const int lane = threadIdx.x & 63;
+    const long long q = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (q >= nq) return;
+    const long long total = (long long)nparts * k;
+    u64 best = 0;
+    for (long long c0 = 0; c0 < total; c0 += 64) {
+        long long c = c0 + lane;
+        u64 v = 0;
+        if (c < total) {
+            long long p = c / k, j = c - p * k;
+            v = parts[(p * nq + q) * k + j];
+        }
+        v = lvs_wave_sort_desc(v, lane);
+        if (c0 == 0) {
+            best = v;
+        } else {
+            u64 w = lvs_shfl_u64(v, 63 - lane);  // ascending copy
+            best = best > w ? best : w;          // top-64 of the union, bitonic
+            best = lvs_wave_bitonic_merge_desc(best, lane);
+        }
+    }
+    if (lane < k) out[q * out_ld + lane] = best;
+}
+
+__global__ __launch_bounds__(256) void keys_to_result_kernel(const u64* __restrict__ keys, long long n, int metric,
+                                                             const long long* __restrict__ id_map,
+                                                             float* __restrict__ D, long long* __restrict__ I) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    u64 key = keys[i];
+    const float FLT_MAX_ = 3.4028234663852886e38f;
+    if (key == 0) {
+        D[i] = metric == LVS_METRIC_IP ? -FLT_MAX_ : FLT_MAX_;
+        I[i] = -1;
+        return;
+    }
+    float better = lvs_unord32((uint32_t)(key >> 32));
+    long long id = (long long)(0xFFFFFFFFu - (uint32_t)(key & 0xFFFFFFFFull));
+    D[i] = metric == LVS_METRIC_IP ? better : (0.0f - better);
+    I[i] = id_map ? id_map[id] : id;
+}
+
+}  // namespace
+
+extern "C" int32_t lvs_pack_rows(const void* src, int32_t src_dtype, int64_t n, int32_t d, int32_t pack_mode,
+                                 int32_t normalize, void* dst, float* out_norms_sq, void* stream) {
+    LVS_REQUIRE(n >= 0 && d > 0, "bad shape n=%lld d=%d", (long long)n, d);
+    LVS_REQUIRE(pack_mode == LVS_PACK_F16 || pack_mode == LVS_PACK_SPLIT, "bad pack_mode %d", pack_mode);
+    LVS_REQUIRE(src_dtype == LVS_DTYPE_F32 || src_dtype == LVS_DTYPE_F16, "bad src_dtype %d", src_dtype);
+    if (n == 0) return LVS_OK;
+    LVS_REQUIRE(src && dst, "NULL buffer");
+    const int dpad = (int)lvs_round_up(d, LVS_BK);
+    dim3 block(256), grid((unsigned)lvs_ceil_div(n, 4));
+    hipStream_t st = (hipStream_t)stream;
+    if (src_dtype == LVS_DTYPE_F32)
+        hipLaunchKernelGGL(pack_rows_kernel<float>, grid, block, 0, st, (const float*)src, (long long)n, d, dpad,
+                           pack_mode == LVS_PACK_SPLIT, normalize, (_Float16*)dst, out_norms_sq);
+    else
+        hipLaunchKernelGGL(pack_rows_kernel<_Float16>, grid, block, 0, st, (const _Float16*)src, (long long)n, d,
+                           dpad, pack_mode == LVS_PACK_SPLIT, normalize, (_Float16*)dst, out_norms_sq);
+    LVS_HIP_CHECK(hipGetLastError());
+    return LVS_OK;
+}
+
+extern "C" int32_t lvs_gather_rows(const void* src, int32_t ld, const int64_t* ids, int64_t n_ids, void* dst,
+                                   void* stream) {
+    LVS_REQUIRE(ld > 0 && ld % 8 == 0, "ld must be a positive multiple of 8 halfs");
+    if (n_ids == 0) return LVS_OK;
+    LVS_REQUIRE(src && ids && dst && n_ids > 0, "bad arguments");
+    long long ld16 = ld / 8;
+    long long total = n_ids * ld16;
+    unsigned grid = (unsigned)(lvs_ceil_div(total, 256) < 16384 ? lvs_ceil_div(total, 256) : 16384);
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const uint4*)src, ld16,
+                       (const long long*)ids, (long long)n_ids, (uint4*)dst);
+    LVS_HIP_CHECK(hipGetLastError());
+    return LVS_OK;
+}
+
+extern "C" int32_t lvs_gather_f32(const float* src, const int64_t* ids, int64_t n_ids, float* dst, void* stream) {
+    if (n_ids == 0) return LVS_OK;
+    LVS_REQUIRE(src && ids && dst && n_ids > 0, "bad arguments");
+    hipLaunchKernelGGL(gather_f32_kernel, dim3((unsigned)lvs_ceil_div(n_ids, 256)), dim3(256), 0,
+                       (hipStream_t)stream, src, (const long long*)ids, (long long)n_ids, dst);
+    LVS_HIP_CHECK(hipGetLastError());
+    return LVS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// search
+// ---------------------------------------------------------------------------------------------------------------
+namespace {
+struct Plan {
+    int dpad, nkd, nk, ld;
+    int ntiles, nqt, nslab, tiles_per_slab;
+    int kpass, npass;
+    int64_t off_gtau, off_partial, off_pass, total;
+};
+
+int make_plan(int64_t nq, int64_t nb, int32_t d, int32_t pack_mode, int32_t k, Plan& p) {
+    if (nq < 0 || nb < 0 || d <= 0 || k < 0) return LVS_EINVAL;
+    if (pack_mode != LVS_PACK_F16 && pack_mode != LVS_PACK_SPLIT) return LVS_EINVAL;
+    p.dpad = (int)lvs_round_up(d, LVS_BK);
+    p.nkd = p.dpad / LVS_BK;
+    p.nk = pack_mode == LVS_PACK_SPLIT ? 3 * p.nkd : p.nkd;
+    p.ld = pack_mode == LVS_PACK_SPLIT ? 2 * p.dpad : p.dpad;
+    p.ntiles = (int)lvs_ceil_div(nb > 0 ? nb : 1, LVS_BC);
+    p.nqt = (int)lvs_ceil_div(nq > 0 ? nq : 1, LVS_BQ);
+    // enough (query tile, slab) items to load-balance 256 CUs (~8 items per CU), slabs kept >= 8 tiles
+    int64_t want = lvs_ceil_div(2048, p.nqt);
+    int64_t max_slabs = lvs_ceil_div(p.ntiles, 8);
+    int64_t s = want < 1 ? 1 : want;
+    if (s > max_slabs) s = max_slabs;
+    if (s < 1) s = 1;
+    p.tiles_per_slab = (int)lvs_ceil_div(p.ntiles, s);
+    p.nslab = (int)lvs_ceil_div(p.ntiles, p.tiles_per_slab);
+    p.kpass = k < LVS_KPASS ? (k > 0 ? k : 1) : LVS_KPASS;
+    p.npass = k > 0 ? (int)lvs_ceil_div(k, p.kpass) : 0;
+    int64_t off = 0;
+    p.off_gtau = off;
+    off += lvs_round_up(nq * 4, 256);
+    p.off_partial = off;
+    off += lvs_round_up((int64_t)p.nslab * nq * p.kpass * 8, 256);
+    p.off_pass = off;  // [nq][kpass] merged keys of one pass (multi-pass only)
+    off += p.npass > 1 ? lvs_round_up(nq * p.kpass * 8, 256) : 0;
+    p.total = off;
+    return LVS_OK;
+}
+
+__global__ void copy_pass_kernel(const u64* __restrict__ src, long long nq, int kp, u64* __restrict__ dst, int k,
+                                 int col0) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nq * kp) return;
+    long long q = i / kp;
+    int j = (int)(i - q * kp);
+    if (col0 + j < k) dst[q * k + col0 + j] = src[i];
+}
+}  // namespace
+
+extern "C" int64_t lvs_flat_search_workspace_bytes(int64_t nq, int64_t nb, int32_t d, int32_t pack_mode, int32_t k) {
+    Plan p;
+    if (make_plan(nq, nb, d, pack_mode, k, p) != LVS_OK) return LVS_EINVAL;
+    return p.total;
+}
+
+extern "C" int32_t lvs_flat_search_keys(const void* xb, int64_t nb, const void* xq, int64_t nq, int32_t d,
+                                        int32_t pack_mode, int32_t metric, int32_t k, const float* xb_norms_sq,
+                                        const float* xq_norms_sq, int64_t id_offset, const uint32_t* row_ids,
+                                        uint64_t* out_keys, void* workspace, int64_t workspace_bytes, void* stream) {
+    Plan p;
+    LVS_REQUIRE(make_plan(nq, nb, d, pack_mode, k, p) == LVS_OK, "bad shape nq=%lld nb=%lld d=%d k=%d pack=%d",
+                (long long)nq, (long long)nb, d, k, pack_mode);
+    LVS_REQUIRE(metric == LVS_METRIC_IP || metric == LVS_METRIC_L2, "bad metric %d", metric);
+    LVS_REQUIRE(k <= LVS_MAX_K, "k=%d exceeds LVS_MAX_K", k);
+    LVS_REQUIRE(id_offset >= 0 && id_offset + nb < 0xFFFFFFFFll, "ids must stay below 2^32-1");
+    if (nq == 0 || k == 0) return LVS_OK;
+    LVS_REQUIRE(out_keys, "out_keys is NULL");
+    hipStream_t st = (hipStream_t)stream;
+    if (nb == 0) {
+        LVS_HIP_CHECK(hipMemsetAsync(out_keys, 0, (size_t)nq * k * 8, st));
+        return LVS_OK;
+    }
+    LVS_REQUIRE(xb && xq, "NULL rows");
+    LVS_REQUIRE(metric != LVS_METRIC_L2 || (xb_norms_sq && xq_norms_sq), "L2 needs both norm vectors");
+    if (workspace_bytes < p.total || !workspace) {
+        lvs_set_error("workspace too small: need %lld bytes, got %lld", (long long)p.total, (long long)workspace_bytes);
+        return LVS_ENOMEM;
+    }
+    char* ws = (char*)workspace;
+    uint32_t* gtau = (uint32_t*)(ws + p.off_gtau);
+    u64* partial = (u64*)(ws + p.off_partial);
+    u64* passbuf = (u64*)(ws + p.off_pass);
+
+    LvsTileArgs a;
+    memset(&a, 0, sizeof(a));
+    a.xb = xb;
+    a.xq = xq;
+    a.bn = xb_norms_sq;
+    a.qn = xq_norms_sq;
+    a.row_ids = row_ids;
+    a.gtau = gtau;
+    a.out = partial;
+    a.nb = nb;
+    a.nq = nq;
+    a.ld = p.ld;
+    a.id_offset = id_offset;
+    a.nkd = p.nkd;
+    a.nk = p.nk;
+    a.metric = metric;
+    a.ntiles = p.ntiles;
+    a.tiles_per_slab = p.tiles_per_slab;
+    a.nslab = p.nslab;
+    a.nqt = p.nqt;
+
+    for (int pass = 0; pass < p.npass; ++pass) {
+        const int col0 = pass * p.kpass;
+        const int kp = (k - col0) < p.kpass ? (k - col0) : p.kpass;
+        a.k = kp;
+        // pass > 0: only keys strictly below the last key of the previous pass take part
+        a.ub = pass == 0 ? nullptr : (const u64*)out_keys + (col0 - 1);
+        a.ub_stride = k;
+        LVS_HIP_CHECK(hipMemsetAsync(gtau, 0, (size_t)nq * 4, st));
+        {
+            ScopedKernelTimer timer(st);
+            LVS_HIP_CHECK(lvs_tile_launch(LVS_MODE_TOPK, a, st));
+        }
+        dim3 mgrid((unsigned)lvs_ceil_div(nq, 4)), mblock(256);
+        if (p.npass == 1) {
+            hipLaunchKernelGGL(merge_keys_kernel, mgrid, mblock, 0, st, partial, p.nslab, (long long)nq, kp,
+                               (u64*)out_keys, (long long)k);
+        } else {
+            // the upper bounds of this pass live in out_keys, so merge into a side buffer first
+            hipLaunchKernelGGL(merge_keys_kernel, mgrid, mblock, 0, st, partial, p.nslab, (long long)nq, kp, passbuf,
+                               (long long)kp);
+            hipLaunchKernelGGL(copy_pass_kernel, dim3((unsigned)lvs_ceil_div(nq * kp, 256)), dim3(256), 0, st, passbuf,
+                               (long long)nq, kp, (u64*)out_keys, k, col0);
+        }
+        LVS_HIP_CHECK(hipGetLastError());
+    }
+    return LVS_OK;
+}
+
+extern "C" int32_t lvs_merge_keys(const uint64_t* parts, int32_t nparts, int64_t nq, int32_t k, uint64_t* out_keys,
+                                  void* stream) {
+    LVS_REQUIRE(nparts >= 1 && nq >= 0 && k >= 0, "bad arguments");
+    LVS_REQUIRE(k <= 64, "lvs_merge_keys handles k <= 64 per call (got %d)", k);
+    if (nq == 0 || k == 0) return LVS_OK;
+    LVS_REQUIRE(parts && out_keys, "NULL buffer");
+    hipLaunchKernelGGL(merge_keys_kernel, dim3((unsigned)lvs_ceil_div(nq, 4)), dim3(256), 0, (hipStream_t)stream,
+                       (const u64*)parts, nparts, (long long)nq, k, (u64*)out_keys, (long long)k);
+    LVS_HIP_CHECK(hipGetLastError());
+    return LVS_OK;
+}
+
+extern "C" int32_t lvs_keys_to_result(const uint64_t* keys, int64_t nq, int32_t k, int32_t metric,
+                                      const int64_t* id_map, float* out_D, int64_t* out_I, void* stream) {
+    LVS_REQUIRE(nq >= 0 && k >= 0, "bad shape");
+    LVS_REQUIRE(metric == LVS_METRIC_IP || metric == LVS_METRIC_L2, "bad metric %d", metric);
+    long long n = (long long)nq * k;
+    if (n == 0) return LVS_OK;
+    LVS_REQUIRE(keys && out_D && out_I, "NULL buffer");
+    hipLaunchKernelGGL(keys_to_result_kernel, dim3((unsigned)lvs_ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const u64*)keys, n, metric, (const long long*)id_map, out_D, (long long*)out_I);
+    LVS_HIP_CHECK(hipGetLastError());
+    return LVS_OK;
+}
+
+extern "C" int32_t lvs_scores(const void* xb, int64_t nb, const void* xq, int64_t nq, int32_t d, int32_t pack_mode,
+                              int32_t metric, const float* xb_norms_sq, const float* xq_norms_sq, float* out,
+                              int64_t ld_out, void* stream) {
+    Plan p;
+    LVS_REQUIRE(make_plan(nq, nb, d, pack_mode, 1, p) == LVS_OK, "bad shape");
+    LVS_REQUIRE(metric == LVS_METRIC_IP || metric == LVS_METRIC_L2, "bad metric %d", metric);
+    if (nq == 0 || nb == 0) return LVS_OK;
+    LVS_REQUIRE(xb && xq && out && ld_out >= nb, "bad buffers");
+    LVS_REQUIRE(metric != LVS_METRIC_L2 || (xb_norms_sq && xq_norms_sq), "L2 needs both norm vectors");
+    LvsTileArgs a;
+    memset(&a, 0, sizeof(a));
+    a.xb = xb;
+    a.xq = xq;
+    a.bn = xb_norms_sq;
+    a.qn = xq_norms_sq;
+    a.scores = out;
+    a.ld_scores = ld_out;
+    a.nb = nb;
+    a.nq = nq;
+    a.ld = p.ld;
+    a.nkd = p.nkd;
+    a.nk = p.nk;
+    a.metric = metric;
+    a.k = 1;
+    a.ntiles = p.ntiles;
+    a.tiles_per_slab = p.tiles_per_slab;
+    a.nslab = p.nslab;
+    a.nqt = p.nqt;
+    LVS_HIP_CHECK(lvs_tile_launch(LVS_MODE_SCORES, a, (hipStream_t)stream));
+    return LVS_OK;
+}

@@ -1,0 +1,38 @@
+// Launch interface of the tiled distance / top-k kernel (lvs_tile.hip).
+#pragma once
+#include "lvs_common.h"
+
+#define LVS_BC 256          // corpus rows per score tile (MFMA M)
+#define LVS_BQ 128          // queries per score tile (MFMA N)
+#define LVS_BK 64           // halfs per K-step
+#define LVS_LCAP 32         // candidate slots per query in LDS
+#define LVS_KPASS 24        // largest k one pass selects (LCAP minus head-room)
+#define LVS_TILE_THREADS 512
+#define LVS_TILE_LDS_BYTES (2 * (LVS_BC + LVS_BQ) * LVS_BK * 2 + LVS_BQ * LVS_LCAP * 8 + LVS_BQ * 8 + LVS_BQ * 4 + 16)
+
+#define LVS_MODE_TOPK 0
+#define LVS_MODE_SCORES 1
+
+struct LvsTileArgs {
+    const void* xb;           // [nb][ld] fp16 packed corpus shard
+    const void* xq;           // [nq][ld] fp16 packed queries
+    const float* bn;          // [nb] |y|^2 (L2 only)
+    const float* qn;          // [nq] |q|^2 (L2 only)
+    const uint32_t* row_ids;  // nullable [nb]: id reported for a shard row
+    const u64* ub;            // nullable: per-query exclusive upper bound key (multi-pass k > LVS_KPASS)
+    long long ub_stride;      // stride of ub in u64 elements
+    uint32_t* gtau;           // [nq] shared running thresholds (ord32 of the k-th best score), zero-initialised
+    u64* out;                 // [nslab][nq][k] per-slab candidate keys
+    float* scores;            // LVS_MODE_SCORES: [nq][ld_scores]
+    long long ld_scores;
+    long long nb, nq, ld;     // ld in halfs
+    long long id_offset;
+    int nkd;                  // padded d / 64
+    int nk;                   // K-steps per tile: nkd (fp16) or 3 * nkd (split fp32)
+    int metric;
+    int k;                    // <= LVS_KPASS
+    int ntiles, tiles_per_slab, nslab, nqt;
+};
+
+int lvs_tile_grid_blocks(int nqt, int nslab);
+hipError_t lvs_tile_launch(int mode, const LvsTileArgs& a, hipStream_t stream);

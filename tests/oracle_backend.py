@@ -1,0 +1,86 @@
+"""Test double for ``lotus_amd.backend.HipBackend`` that answers every device call with the CPU oracle.
+
+Lives under tests/ on purpose: it lets the host-side logic of ``HipVS`` (argument handling, padding, subset/ids
+mapping, caching, sharding + all-gather + merge over gloo) run in a GPU-less container.  It is never importable
+from the product package."""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+import oracle
+from lotus_amd import _capi
+from lotus_amd.backend import PackedRows
+from oracle.flat import _finish
+
+
+def _emulate_storage(x: np.ndarray, mode: int) -> np.ndarray:
+    """Values the device would hold: fp16-rounded (PACK_F16) or hi+lo of an fp16 pair (PACK_SPLIT)."""
+    x = np.asarray(x, dtype=np.float32)
+    hi = x.astype(np.float16)
+    if mode == _capi.PACK_F16:
+        return hi.astype(np.float32)
+    lo = (x - hi.astype(np.float32)).astype(np.float16)
+    return hi.astype(np.float32) + lo.astype(np.float32)
+
+
+class OracleBackend:
+    device = torch.device("cpu")
+
+    def __init__(self):
+        self.calls = []
+
+    def synchronize(self):
+        pass
+
+    def to_device(self, arr):
+        return torch.from_numpy(np.ascontiguousarray(arr))
+
+    def pack(self, x, mode, normalize=False):
+        x = x.numpy() if torch.is_tensor(x) else np.asarray(x)
+        x = x.astype(np.float32)
+        if normalize:
+            x = x / np.linalg.norm(x, axis=1, keepdims=True)
+        vals = _emulate_storage(x, mode)
+        self.calls.append(("pack", vals.shape, mode))
+        norms = np.einsum("ij,ij->i", vals, vals, dtype=np.float32)
+        return PackedRows(rows=torch.from_numpy(vals), norms=torch.from_numpy(norms), n=vals.shape[0],
+                          d=vals.shape[1] if vals.ndim == 2 else 0, mode=mode)
+
+    def gather(self, src, ids_dev):
+        idx = ids_dev.numpy().astype(np.int64)
+        self.calls.append(("gather", len(idx)))
+        return PackedRows(rows=src.rows[idx], norms=src.norms[idx], n=len(idx), d=src.d, mode=src.mode)
+
+    def search_keys(self, corpus, queries, k, metric, id_offset=0, row_ids=None):
+        self.calls.append(("search", queries.n, corpus.n, k, metric))
+        xb, xq = corpus.rows.numpy(), queries.rows.numpy()
+        if corpus.n == 0:
+            return torch.zeros((queries.n, k), dtype=torch.int64)
+        D, I = oracle.flat_search(xb, xq, min(k, corpus.n), metric)
+        better = D if metric == 0 else -D
+        valid = I >= 0
+        if row_ids is not None:
+            rid = row_ids.numpy().view(np.uint32).astype(np.int64)
+            ids = np.where(valid, rid[np.where(valid, I, 0)], 0)
+        else:
+            ids = np.where(valid, I + id_offset, 0)
+        keys = np.where(valid, oracle.pack_keys(better, ids), np.uint64(0))
+        # a mapped id order may differ from the scan order inside exact ties: re-sort by key
+        keys = np.sort(keys, axis=1)[:, ::-1]
+        if keys.shape[1] < k:
+            keys = np.concatenate([keys, np.zeros((keys.shape[0], k - keys.shape[1]), np.uint64)], axis=1)
+        return torch.from_numpy(np.ascontiguousarray(keys).view(np.int64))
+
+    def merge_keys(self, parts):
+        p = parts.numpy().view(np.uint64)
+        P, nq, k = p.shape
+        allk = np.transpose(p, (1, 0, 2)).reshape(nq, P * k)
+        out = np.sort(allk, axis=1)[:, ::-1][:, :k]
+        self.calls.append(("merge", P, nq, k))
+        return torch.from_numpy(np.ascontiguousarray(out).view(np.int64))
+
+    def keys_to_result(self, keys, metric, id_map=None):
+        k = keys.numpy().view(np.uint64)
+        D, I = _finish(k, metric, None if id_map is None else id_map.numpy())
+        return torch.from_numpy(D), torch.from_numpy(I)
