@@ -1,0 +1,60 @@
+"""Summarise rocprofv3 CSV output (kernel stats + separate --pmc passes) of `bench.py` into profiles/.
+
+usage: python tools/pmc_summary.py <gpurun_out dir> <tag>    ->  profiles/<tag>_kernel_stats.csv, profiles/<tag>_pmc.json
+HBM traffic follows /opt/skills/guides/MI355X_MICROARCH.md (section HBM): FETCH_SIZE / WRITE_SIZE are reported in KiB by
+rocprofv3; on gfx950 FETCH_SIZE counts 64 B per 128-B request for wide (16 B/lane) streaming reads, so read bytes =
+2 * FETCH_SIZE * 1024.  WRITE_SIZE is uncalibrated (taken as is); it is 5 orders of magnitude below the reads here."""
+import collections, csv, glob, json, os, sys
+
+src, tag = sys.argv[1], sys.argv[2]
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+out_dir = os.path.join(root, "profiles")
+os.makedirs(out_dir, exist_ok=True)
+KERNEL = "lvs_tile_kernel"
+
+stats = glob.glob(os.path.join(src, "prof_*", "*kernel_stats.csv"))
+summary = {}
+if stats:
+    rows = list(csv.DictReader(open(stats[0])))
+    keep = [r for r in rows if float(r["Percentage"]) >= 0.01 or KERNEL in r["Name"]]
+    with open(os.path.join(out_dir, f"{tag}_kernel_stats.csv"), "w", newline="") as f:
+        w = csv.DictWriter(f, fieldnames=rows[0].keys())
+        w.writeheader()
+        for r in keep:
+            r = dict(r)
+            if len(r["Name"]) > 160:
+                r["Name"] = r["Name"][:157] + "..."
+            w.writerow(r)
+    for r in rows:
+        if KERNEL in r["Name"] and "<0>" in r["Name"]:
+            summary["rocprof_kernel_avg_ms"] = float(r["AverageNs"]) / 1e6
+            summary["rocprof_kernel_calls"] = int(r["Calls"])
+
+counters = collections.defaultdict(list)
+for p in glob.glob(os.path.join(src, "pmc_*", "*counter_collection.csv")):
+    for r in csv.DictReader(open(p)):
+        if KERNEL in r["Kernel_Name"]:
+            counters[r["Counter_Name"]].append(float(r["Counter_Value"]))
+            summary.setdefault("vgpr", int(r["VGPR_Count"]))
+            summary.setdefault("sgpr", int(r["SGPR_Count"]))
+            summary.setdefault("lds_bytes", int(r["LDS_Block_Size"]))
+            summary.setdefault("grid", int(r["Grid_Size"]))
+avg = {k: sum(v) / len(v) for k, v in counters.items()}
+summary["counters_per_launch"] = avg
+if "FETCH_SIZE" in avg:
+    rd = 2.0 * avg["FETCH_SIZE"] * 1024
+    wr = avg.get("WRITE_SIZE", 0.0) * 1024
+    summary["hbm_read_bytes_per_launch"] = rd
+    summary["hbm_write_bytes_per_launch"] = wr
+    summary["traffic_bytes_per_launch"] = rd + wr
+if "TCC_HIT_sum" in avg:
+    summary["l2_hit_rate"] = avg["TCC_HIT_sum"] / (avg["TCC_HIT_sum"] + avg["TCC_MISS_sum"])
+if "SQ_VALU_MFMA_BUSY_CYCLES" in avg and "GRBM_GUI_ACTIVE" in avg:
+    # GRBM_GUI_ACTIVE is summed over the 8 XCDs; MFMA busy cycles over the 1024 SIMDs
+    summary["mfma_busy_frac"] = (avg["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024) / (avg["GRBM_GUI_ACTIVE"] / 8)
+if "SQ_WAVE_CYCLES" in avg:
+    for c in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY"):
+        if c in avg:
+            summary[c.lower() + "_frac"] = avg[c] / avg["SQ_WAVE_CYCLES"]
+json.dump(summary, open(os.path.join(out_dir, f"{tag}_pmc.json"), "w"), indent=1)
+print(json.dumps(summary, indent=1))
