@@ -2,6 +2,7 @@
 // row packing (fp32/fp16 -> fp16 or fp16 hi|lo), row gather, candidate-list merge, key decoding.
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <mutex>
@@ -285,10 +286,12 @@ struct Plan {
     int dpad, nkd, nk, ld;
     int ntiles, nqt, nslab, tiles_per_slab;
     int kpass, npass;
+    int gq;
+    int v2;  // 1: 256x256 kernel (lvs_tile2.hip), top-k with k <= LVS2_KCAP
     int64_t off_gtau, off_partial, off_pass, total;
 };
 
-int make_plan(int64_t nq, int64_t nb, int32_t d, int32_t pack_mode, int32_t k, Plan& p) {
+int make_plan(int64_t nq, int64_t nb, int32_t d, int32_t pack_mode, int32_t k, Plan& p, bool allow_v2 = true) {
     if (nq < 0 || nb < 0 || d <= 0 || k < 0) return LVS_EINVAL;
     if (pack_mode != LVS_PACK_F16 && pack_mode != LVS_PACK_SPLIT) return LVS_EINVAL;
     p.dpad = (int)lvs_round_up(d, LVS_BK);
@@ -296,13 +299,26 @@ int make_plan(int64_t nq, int64_t nb, int32_t d, int32_t pack_mode, int32_t k, P
     p.nk = pack_mode == LVS_PACK_SPLIT ? 3 * p.nkd : p.nkd;
     p.ld = pack_mode == LVS_PACK_SPLIT ? 2 * p.dpad : p.dpad;
     p.ntiles = (int)lvs_ceil_div(nb > 0 ? nb : 1, LVS_BC);
-    p.nqt = (int)lvs_ceil_div(nq > 0 ? nq : 1, LVS_BQ);
-    // enough (query tile, slab) items to load-balance 256 CUs (~8 items per CU), slabs kept >= 8 tiles
-    int64_t want = lvs_ceil_div(2048, p.nqt);
+    p.v2 = allow_v2 && k >= 1 && k <= LVS2_KCAP;
+    if (const char* e = getenv("LVS_KERNEL")) {  // tuning override: 1 = 256x128 kernel, 2 = 256x256 kernel
+        if (atoi(e) == 1) p.v2 = 0;
+    }
+    p.nqt = (int)lvs_ceil_div(nq > 0 ? nq : 1, p.v2 ? LVS2_BQ : LVS_BQ);
+    // enough (query tile, slab) items to load-balance 256 CUs (~32 items per CU), slabs kept >= 8 tiles
+    int64_t want = lvs_ceil_div(8192, p.nqt);
     int64_t max_slabs = lvs_ceil_div(p.ntiles, 8);
     int64_t s = want < 1 ? 1 : want;
     if (s > max_slabs) s = max_slabs;
     if (s < 1) s = 1;
+    if (const char* e = getenv("LVS_NSLAB")) {  // tuning override
+        int64_t v = atoll(e);
+        if (v >= 1 && v <= p.ntiles) s = v;
+    }
+    p.gq = p.v2 ? 32 : 8;  // measured on MI355X at 100k x 1M (profiles/r01_tuning.md)
+    if (const char* e = getenv("LVS_GQ")) {
+        int v = atoi(e);
+        if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16 || v == 32) p.gq = v;
+    }
     p.tiles_per_slab = (int)lvs_ceil_div(p.ntiles, s);
     p.nslab = (int)lvs_ceil_div(p.ntiles, p.tiles_per_slab);
     p.kpass = k < LVS_KPASS ? (k > 0 ? k : 1) : LVS_KPASS;
@@ -382,6 +398,8 @@ extern "C" int32_t lvs_flat_search_keys(const void* xb, int64_t nb, const void* 
     a.tiles_per_slab = p.tiles_per_slab;
     a.nslab = p.nslab;
     a.nqt = p.nqt;
+    a.gq = p.gq;
+    a.debug_hot = getenv("LVS_DEBUG_HOT") ? atoi(getenv("LVS_DEBUG_HOT")) : 0;
 
     for (int pass = 0; pass < p.npass; ++pass) {
         const int col0 = pass * p.kpass;
@@ -393,7 +411,10 @@ extern "C" int32_t lvs_flat_search_keys(const void* xb, int64_t nb, const void* 
         LVS_HIP_CHECK(hipMemsetAsync(gtau, 0, (size_t)nq * 4, st));
         {
             ScopedKernelTimer timer(st);
-            LVS_HIP_CHECK(lvs_tile_launch(LVS_MODE_TOPK, a, st));
+            if (p.v2)
+                LVS_HIP_CHECK(lvs_tile2_launch(a, st));
+            else
+                LVS_HIP_CHECK(lvs_tile_launch(LVS_MODE_TOPK, a, st));
         }
         dim3 mgrid((unsigned)lvs_ceil_div(nq, 4)), mblock(256);
         if (p.npass == 1) {
@@ -440,7 +461,7 @@ extern "C" int32_t lvs_scores(const void* xb, int64_t nb, const void* xq, int64_
                               int32_t metric, const float* xb_norms_sq, const float* xq_norms_sq, float* out,
                               int64_t ld_out, void* stream) {
     Plan p;
-    LVS_REQUIRE(make_plan(nq, nb, d, pack_mode, 1, p) == LVS_OK, "bad shape");
+    LVS_REQUIRE(make_plan(nq, nb, d, pack_mode, 1, p, false) == LVS_OK, "bad shape");
     LVS_REQUIRE(metric == LVS_METRIC_IP || metric == LVS_METRIC_L2, "bad metric %d", metric);
     if (nq == 0 || nb == 0) return LVS_OK;
     LVS_REQUIRE(xb && xq && out && ld_out >= nb, "bad buffers");
@@ -464,6 +485,7 @@ extern "C" int32_t lvs_scores(const void* xb, int64_t nb, const void* xq, int64_
     a.tiles_per_slab = p.tiles_per_slab;
     a.nslab = p.nslab;
     a.nqt = p.nqt;
+    a.gq = p.gq;
     LVS_HIP_CHECK(lvs_tile_launch(LVS_MODE_SCORES, a, (hipStream_t)stream));
     return LVS_OK;
 }

@@ -10,6 +10,9 @@
 #define LVS_TILE_THREADS 512
 #define LVS_TILE_LDS_BYTES (2 * (LVS_BC + LVS_BQ) * LVS_BK * 2 + LVS_BQ * LVS_LCAP * 8 + LVS_BQ * 8 + LVS_BQ * 4 + 16)
 
+#define LVS2_KCAP 12        // largest k of the 256x256 kernel (lvs_tile2.hip)
+#define LVS2_BQ 256
+
 #define LVS_MODE_TOPK 0
 #define LVS_MODE_SCORES 1
 
@@ -32,7 +35,10 @@ struct LvsTileArgs {
     int metric;
     int k;                    // <= LVS_KPASS
     int ntiles, tiles_per_slab, nslab, nqt;
+    int debug_hot;            // tuning aid: every workgroup re-reads tile 0 / query tile 0 (all loads L2-hot)
+    int gq;                   // query tiles per XCD group (1,2,4,8,16,32); slabs per group = 32 / gq
 };
 
-int lvs_tile_grid_blocks(int nqt, int nslab);
+int lvs_tile_grid_blocks(int nqt, int nslab, int gq);
 hipError_t lvs_tile_launch(int mode, const LvsTileArgs& a, hipStream_t stream);
+hipError_t lvs_tile2_launch(const LvsTileArgs& a, hipStream_t stream);

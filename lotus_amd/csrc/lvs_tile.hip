@@ -56,10 +56,11 @@ __device__ inline bool item_of_block(const LvsTileArgs& a, int b, int& qt, int& 
     int x = b & 7, j = b >> 3;
     int gseq = j >> 5, r = j & 31;
     int g = gseq * 8 + x;
-    int nqg = (a.nqt + 7) >> 3;
+    int gq = a.gq, gs = 32 / a.gq;  // group = gq query tiles x gs slabs = 32 blocks
+    int nqg = (a.nqt + gq - 1) / gq;
     int qgroup = g % nqg, sgroup = g / nqg;
-    qt = qgroup * 8 + (r & 7);
-    slab = sgroup * 4 + (r >> 3);
+    qt = qgroup * gq + (r % gq);
+    slab = sgroup * gs + (r / gq);
     return qt < a.nqt && slab < a.nslab;
 }
 
@@ -105,7 +106,7 @@ __global__ __launch_bounds__(LVS_TILE_THREADS, 2) void lvs_tile_kernel(const Lvs
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         int row = wave * 16 + i * 8 + srow;
-        long long grow = q0 + row;
+        long long grow = a.debug_hot ? row : q0 + row;
         if (grow > a.nq - 1) grow = a.nq - 1;
         q_src[i] = xq + grow * ld + (sp ^ ((row >> 1) & 7)) * 8;
     }
@@ -115,7 +116,7 @@ __global__ __launch_bounds__(LVS_TILE_THREADS, 2) void lvs_tile_kernel(const Lvs
         int seg = ks / nkd, r = ks - seg * nkd;
         int qcol = (seg == 2 ? dpad : 0) + r * LVS_BK;
         int ccol = (seg == 1 ? dpad : 0) + r * LVS_BK;
-        long long trow0 = (long long)(tile0 + ti) * LVS_BC;
+        long long trow0 = a.debug_hot ? 0 : (long long)(tile0 + ti) * LVS_BC;
         char* base = smem + buf * STAGE_BYTES;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -348,8 +349,9 @@ template __global__ void lvs_tile_kernel<LVS_MODE_TOPK>(const LvsTileArgs);
 template __global__ void lvs_tile_kernel<LVS_MODE_SCORES>(const LvsTileArgs);
 
 // ---- launch helpers (called from lvs_capi.hip) -------------------------------------------------------------
-int lvs_tile_grid_blocks(int nqt, int nslab) {
-    long long nqg = (nqt + 7) / 8, nsg = (nslab + 3) / 4;
+int lvs_tile_grid_blocks(int nqt, int nslab, int gq) {
+    int gs = 32 / gq;
+    long long nqg = (nqt + gq - 1) / gq, nsg = (nslab + gs - 1) / gs;
     long long groups = lvs_round_up(nqg * nsg, 8);
     return (int)(groups * 32);
 }
@@ -365,7 +367,7 @@ hipError_t lvs_tile_launch(int mode, const LvsTileArgs& a, hipStream_t stream) {
         if (e != hipSuccess) return e;
         attr_done = true;
     }
-    dim3 grid(lvs_tile_grid_blocks(a.nqt, a.nslab)), block(LVS_TILE_THREADS);
+    dim3 grid(lvs_tile_grid_blocks(a.nqt, a.nslab, a.gq)), block(LVS_TILE_THREADS);
     if (mode == LVS_MODE_TOPK)
         hipLaunchKernelGGL(lvs_tile_kernel<LVS_MODE_TOPK>, grid, block, LDS_TOTAL, stream, a);
     else

@@ -1,0 +1,368 @@
+// Second-generation tile kernel: 256 corpus rows x 256 queries per workgroup, top-k only, k <= LVS2_KCAP.
+//
+// Same role as lvs_tile.hip (faiss IndexFlat::search behind lotus/vector_store/faiss_vs.py:67,75) and the same
+// result keys / thresholds; what changes is the geometry, chosen for L2 traffic and MFMA occupancy:
+//   score tile   256 corpus rows (MFMA M) x 256 queries (MFMA N): 128 flop per byte staged from L2 (v1: 85)
+//   wave layout  2 (corpus) x 4 (queries); each wave 128 x 64 = 4 x 2 accumulators of v_mfma_f32_32x32x16_f16
+//                (128 accumulator VGPRs), 32 MFMAs per wave between barriers
+//   LDS          2 x 512 rows x 128 B staging = 128 KB, which leaves 32 KB for candidates; so instead of fixed
+//                slots per query the workgroup keeps one sorted k-list per query (256 x KCAP x 8 B) and a shared
+//                append pool (768 keys + owners).  A full pool is drained into the lists (each wave owns 32
+//                queries and scans the pool), which is also when thresholds tighten.
+#include "lvs_common.h"
+#include "lvs_tile.h"
+
+namespace {
+
+constexpr int BC = 256, BQ = 256, BK = 64;
+constexpr int ROWB = BK * 2;
+constexpr int STAGE_BYTES = (BC + BQ) * ROWB;  // 65536
+constexpr int KCAP = LVS2_KCAP;                // 12
+constexpr int PCAP = 768;                      // pool entries
+constexpr int OFF_LIST = 2 * STAGE_BYTES;      // u64 [BQ][KCAP] sorted descending, first k used
+constexpr int OFF_PKEY = OFF_LIST + BQ * KCAP * 8;
+constexpr int OFF_POWN = OFF_PKEY + PCAP * 8;  // u16 [PCAP] local query of each pool entry
+constexpr int OFF_CTRL = OFF_POWN + PCAP * 2;  // u32 pool_cnt[2], flags[2]
+constexpr int LDS_TOTAL = OFF_CTRL + 16;
+static_assert(LDS_TOTAL <= 160 * 1024, "LDS budget");
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef const __attribute__((address_space(1))) void gbl_void_t;
+
+__device__ inline void glds16(const void* gsrc, void* ldst) {
+    __builtin_amdgcn_global_load_lds((gbl_void_t*)gsrc, (lds_void_t*)ldst, 16, 0, 0);
+}
+
+__device__ inline float max16(const f32x16& v) {
+    float a = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
+    float b = fmaxf(fmaxf(v[4], v[5]), fmaxf(v[6], v[7]));
+    float c = fmaxf(fmaxf(v[8], v[9]), fmaxf(v[10], v[11]));
+    float d = fmaxf(fmaxf(v[12], v[13]), fmaxf(v[14], v[15]));
+    return fmaxf(fmaxf(a, b), fmaxf(c, d));
+}
+
+__device__ inline float tau_float(uint32_t ord) { return ord == 0 ? -INFINITY : lvs_unord32(ord); }
+
+__device__ inline bool item_of_block(const LvsTileArgs& a, int b, int& qt, int& slab) {
+    int x = b & 7, j = b >> 3;
+    int gseq = j >> 5, r = j & 31;
+    int g = gseq * 8 + x;
+    int gq = a.gq, gs = 32 / a.gq;
+    int nqg = (a.nqt + gq - 1) / gq;
+    int qgroup = g % nqg, sgroup = g / nqg;
+    qt = qgroup * gq + (r % gq);
+    slab = sgroup * gs + (r / gq);
+    return qt < a.nqt && slab < a.nslab;
+}
+
+}  // namespace
+
+__global__ __launch_bounds__(512, 2) void lvs_tile2_kernel(const LvsTileArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+
+    int qt, slab;
+    if (!item_of_block(a, blockIdx.x, qt, slab)) return;
+    const long long q0 = (long long)qt * BQ;
+    const int tile0 = slab * a.tiles_per_slab;
+    const int tile1 = min(a.ntiles, tile0 + a.tiles_per_slab);
+    if (tile0 >= tile1) return;
+
+    u64* lists = (u64*)(smem + OFF_LIST);
+    u64* pkey = (u64*)(smem + OFF_PKEY);
+    unsigned short* pown = (unsigned short*)(smem + OFF_POWN);
+    uint32_t* pcnt = (uint32_t*)(smem + OFF_CTRL);  // [2]
+    uint32_t* flags = pcnt + 2;                       // [2]
+
+    const _Float16* __restrict__ xb = (const _Float16*)a.xb;
+    const _Float16* __restrict__ xq = (const _Float16*)a.xq;
+    const long long ld = a.ld;
+    const int nk = a.nk, nkd = a.nkd, dpad = a.nkd * BK;
+    const int k = a.k;
+
+    // ---- staging addresses: wave stages corpus rows [wave*32, +32) and query rows [wave*32, +32) --------------
+    const int srow = lane >> 3, sp = lane & 7;
+    int s_row[4], s_col[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int row = wave * 32 + i * 8 + srow;
+        s_row[i] = row;
+        s_col[i] = (sp ^ ((row >> 1) & 7)) * 8;
+    }
+    const _Float16* q_src[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        long long grow = a.debug_hot ? s_row[i] : q0 + s_row[i];
+        if (grow > a.nq - 1) grow = a.nq - 1;
+        q_src[i] = xq + grow * ld + s_col[i];
+    }
+
+    auto stage = [&](int t, int buf) {
+        int ti = t / nk, ks = t - ti * nk;
+        int seg = ks / nkd, r = ks - seg * nkd;
+        int qcol = (seg == 2 ? dpad : 0) + r * BK;
+        int ccol = (seg == 1 ? dpad : 0) + r * BK;
+        long long trow0 = a.debug_hot ? 0 : (long long)(tile0 + ti) * BC;
+        char* base = smem + buf * STAGE_BYTES;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            long long grow = trow0 + s_row[i];
+            if (grow > a.nb - 1) grow = a.nb - 1;
+            glds16(xb + grow * ld + ccol + s_col[i], base + (wave * 32 + i * 8) * ROWB);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) glds16(q_src[i] + qcol, base + BC * ROWB + (wave * 32 + i * 8) * ROWB);
+    };
+
+    int foff[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk)
+        foff[kk] = (lane & 31) * ROWB + ((((kk * 2) + (lane >> 5)) ^ (((lane & 31) >> 1) & 7)) << 4);
+    const int a_base = (wm * 128) * ROWB;
+    const int b_base = BC * ROWB + (wn * 64) * ROWB;
+
+    int qloc[2];
+    bool qvalid[2];
+    float tauf[2];
+    uint32_t gord[2];
+    u64 ubk[2];
+    float qnv[2];
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+        qloc[ni] = wn * 64 + ni * 32 + (lane & 31);
+        qvalid[ni] = (q0 + qloc[ni]) < a.nq;
+        tauf[ni] = -INFINITY;
+        gord[ni] = 0;
+        ubk[ni] = ~0ull;
+        qnv[ni] = 0.f;
+        if (qvalid[ni]) {
+            if (a.ub) ubk[ni] = a.ub[(q0 + qloc[ni]) * a.ub_stride];
+            if (a.metric == LVS_METRIC_L2) qnv[ni] = a.qn[q0 + qloc[ni]];
+        }
+    }
+
+    for (int i = tid; i < BQ * KCAP; i += 512) lists[i] = 0;
+    if (tid < 4) pcnt[tid] = 0;
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+    // Drain the pool into the per-query sorted lists.  Called by all waves between two barriers; wave w owns
+    // queries [32w, 32w+32), one per lane of its lower half.  n = number of valid pool entries.
+    auto drain = [&](uint32_t n) {
+        if (lane < 32) {
+            const int q = wave * 32 + lane;
+            u64* L = lists + q * KCAP;
+            bool changed = false;
+            for (uint32_t e = 0; e < n; ++e) {
+                if (pown[e] != (unsigned short)q) continue;
+                const u64 key = pkey[e];
+                if (key <= L[k - 1]) continue;
+                int j = k - 1;
+                while (j > 0 && L[j - 1] < key) {
+                    L[j] = L[j - 1];
+                    --j;
+                }
+                L[j] = key;
+                changed = true;
+            }
+            const u64 tk = L[k - 1];
+            if (changed && tk != 0 && (q0 + q) < a.nq) atomicMax(&a.gtau[q0 + q], (uint32_t)(tk >> 32));
+        }
+    };
+
+    int round = 0;
+    const int T = (tile1 - tile0) * nk;
+    stage(0, 0);
+    int ks_in_tile = 0, ti = 0;
+    for (int t = 0; t < T; ++t) {
+        const int buf = t & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        // ---- one K-step, software-pipelined by hand: 16 steps f = kk*4 + mi of {A-fragment read two steps ahead,
+        // one staging load of the NEXT K-step (first 8 steps), 2 MFMAs}; B fragments double-buffered per kk ----
+        const char* sb = smem + buf * STAGE_BYTES;
+        // the step after the last one re-loads the last K-step into the idle buffer (never read): no branches
+        char* n_base = smem + (buf ^ 1) * STAGE_BYTES;
+        const int tn = t + 1 < T ? t + 1 : T - 1;
+        const int n_ti = tn / nk;
+        const int n_ks = tn - n_ti * nk;
+        const int n_seg = n_ks / nkd, n_r = n_ks - n_seg * nkd;
+        const int n_qcol = (n_seg == 2 ? dpad : 0) + n_r * BK;
+        const int n_ccol = (n_seg == 1 ? dpad : 0) + n_r * BK;
+        const long long n_trow0 = a.debug_hot ? 0 : (long long)(tile0 + n_ti) * BC;
+        half8 Bf[2][2], Af[3];
+        Bf[0][0] = *(const half8*)(sb + b_base + foff[0]);
+        Bf[0][1] = *(const half8*)(sb + b_base + 32 * ROWB + foff[0]);
+        Af[0] = *(const half8*)(sb + a_base + foff[0]);
+        Af[1] = *(const half8*)(sb + a_base + 32 * ROWB + foff[0]);
+#pragma unroll
+        for (int f = 0; f < 16; ++f) {
+            const int kk = f >> 2, mi = f & 3;
+            if (f + 2 < 16) {
+                const int f2 = f + 2;
+                Af[f2 % 3] = *(const half8*)(sb + a_base + (f2 & 3) * 32 * ROWB + foff[f2 >> 2]);
+            }
+            if (mi == 1 && kk + 1 < 4) {
+                Bf[(kk + 1) & 1][0] = *(const half8*)(sb + b_base + foff[kk + 1]);
+                Bf[(kk + 1) & 1][1] = *(const half8*)(sb + b_base + 32 * ROWB + foff[kk + 1]);
+            }
+            if (f < 8) {
+                if (f < 4) {
+                    long long grow = n_trow0 + s_row[f];
+                    if (grow > a.nb - 1) grow = a.nb - 1;
+                    glds16(xb + grow * ld + n_ccol + s_col[f], n_base + (wave * 32 + f * 8) * ROWB);
+                } else {
+                    glds16(q_src[f - 4] + n_qcol, n_base + BC * ROWB + (wave * 32 + (f - 4) * 8) * ROWB);
+                }
+            }
+            acc[mi][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Af[f % 3], Bf[kk & 1][0], acc[mi][0], 0, 0, 0);
+            acc[mi][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Af[f % 3], Bf[kk & 1][1], acc[mi][1], 0, 0, 0);
+        }
+
+        if (++ks_in_tile < nk) continue;
+        ks_in_tile = 0;
+        // =============================== tile epilogue ===================================================
+        const long long trow0 = (long long)(tile0 + ti) * BC;
+        ++ti;
+        const int lrow_base = wm * 128 + 4 * (lane >> 5);  // + mi*32 + (r&3) + 8*(r>>2)
+
+        if (a.metric == LVS_METRIC_L2) {
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    long long row = trow0 + lrow_base + mi * 32 + (r & 3) + 8 * (r >> 2);
+                    float bnv = row < a.nb ? a.bn[row] : 0.f;
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni) {
+                        float dis = (qnv[ni] + bnv) - 2.0f * acc[mi][ni][r];
+                        acc[mi][ni][r] = -fmaxf(dis, 0.f);
+                    }
+                }
+        }
+
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+            if (qvalid[ni]) {
+                uint32_t g = a.gtau[q0 + qloc[ni]];
+                gord[ni] = g > gord[ni] ? g : gord[ni];
+                tauf[ni] = fmaxf(tauf[ni], tau_float(gord[ni]));
+            }
+        u64 done0 = 0, done1 = 0;
+        const bool last_tile = (t + 1 == T);
+        for (;;) {
+            bool anyhit = false;
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) anyhit |= qvalid[ni] && (max16(acc[mi][ni]) >= tauf[ni]);
+            if (__any(anyhit)) {
+#pragma unroll 1
+                for (int tsel = 0; tsel < 8; ++tsel) {
+                    const int mi = tsel >> 1, ni = tsel & 1;
+                    f32x16 tv;
+                    switch (tsel) {
+                        case 0: tv = acc[0][0]; break;
+                        case 1: tv = acc[0][1]; break;
+                        case 2: tv = acc[1][0]; break;
+                        case 3: tv = acc[1][1]; break;
+                        case 4: tv = acc[2][0]; break;
+                        case 5: tv = acc[2][1]; break;
+                        case 6: tv = acc[3][0]; break;
+                        default: tv = acc[3][1]; break;
+                    }
+                    const float tf = ni ? tauf[1] : tauf[0];
+                    const bool qv = ni ? qvalid[1] : qvalid[0];
+                    const bool th = qv && (max16(tv) >= tf);
+                    if (!__any(th)) continue;
+                    if (th) {
+                        const int q = ni ? qloc[1] : qloc[0];
+                        const u64 ubq = ni ? ubk[1] : ubk[0];
+                        const uint32_t go = ni ? gord[1] : gord[0];
+                        const u64 tk = lists[q * KCAP + k - 1];
+                        const long long rbase = trow0 + lrow_base + mi * 32;
+                        u64 done = tsel < 4 ? done0 : done1;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const float s = tv[r];
+                            const u64 bit = 1ull << ((tsel & 3) * 16 + r);
+                            if (s >= tf && !(done & bit)) {
+                                const long long row = rbase + (r & 3) + 8 * (r >> 2);
+                                done |= bit;
+                                if (row < a.nb) {
+                                    const uint32_t id = a.row_ids ? a.row_ids[row] : (uint32_t)(row + a.id_offset);
+                                    const u64 key = lvs_pack_key(s, id);
+                                    if (key > tk && key < ubq && (uint32_t)(key >> 32) >= go) {
+                                        const uint32_t pos = atomicAdd(&pcnt[round & 1], 1u);
+                                        if (pos < PCAP) {
+                                            pkey[pos] = key;
+                                            pown[pos] = (unsigned short)q;
+                                        } else {
+                                            flags[round & 1] = 1u;  // pool full: retried after the drain
+                                            done &= ~bit;
+                                        }
+                                    }
+                                }
+                            }
+                        }
+                        if (tsel < 4) done0 = done; else done1 = done;
+                    }
+                }
+            }
+            __syncthreads();
+            const uint32_t ovf = flags[round & 1];
+            if (!ovf && !last_tile) break;
+            // ---- drain (pool full, or the item's last tile) ----
+            uint32_t n = pcnt[round & 1];
+            n = n < PCAP ? n : PCAP;
+            if (tid == 0) {
+                flags[(round + 1) & 1] = 0;
+                pcnt[(round + 1) & 1] = 0;
+            }
+            drain(n);
+            __syncthreads();
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) {
+                uint32_t lo = (uint32_t)(lists[qloc[ni] * KCAP + k - 1] >> 32);
+                tauf[ni] = fmaxf(tauf[ni], tau_float(lo));
+            }
+            ++round;
+            if (!ovf) break;  // last tile and nothing left to retry
+        }
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+    }
+
+    // lists are complete (the last tile always drains) and sorted: write the slab's candidates
+    __syncthreads();
+    for (int i = tid; i < BQ * k; i += 512) {
+        int q = i / k, j = i - q * k;
+        if (q0 + q < a.nq) a.out[((long long)slab * a.nq + q0 + q) * k + j] = lists[q * KCAP + j];
+    }
+}
+
+hipError_t lvs_tile2_launch(const LvsTileArgs& a, hipStream_t stream) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)lvs_tile2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           LDS_TOTAL);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    dim3 grid(lvs_tile_grid_blocks(a.nqt, a.nslab, a.gq)), block(512);
+    hipLaunchKernelGGL(lvs_tile2_kernel, grid, block, LDS_TOTAL, stream, a);
+    return hipGetLastError();
+}
