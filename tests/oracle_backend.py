@@ -70,7 +70,7 @@ class OracleBackend:
         keys = np.sort(keys, axis=1)[:, ::-1]
         if keys.shape[1] < k:
             keys = np.concatenate([keys, np.zeros((keys.shape[0], k - keys.shape[1]), np.uint64)], axis=1)
-        return torch.from_numpy(np.ascontiguousarray(keys).view(np.int64))
+        return torch.from_numpy(np.array(keys, dtype=np.uint64, order="C", copy=True).view(np.int64))
 
     def merge_keys(self, parts):
         p = parts.numpy().view(np.uint64)
@@ -78,7 +78,7 @@ class OracleBackend:
         allk = np.transpose(p, (1, 0, 2)).reshape(nq, P * k)
         out = np.sort(allk, axis=1)[:, ::-1][:, :k]
         self.calls.append(("merge", P, nq, k))
-        return torch.from_numpy(np.ascontiguousarray(out).view(np.int64))
+        return torch.from_numpy(np.array(out, dtype=np.uint64, order="C", copy=True).view(np.int64))
 
     def keys_to_result(self, keys, metric, id_map=None):
         k = keys.numpy().view(np.uint64)
