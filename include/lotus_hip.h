@@ -72,14 +72,15 @@ int32_t lvs_gather_f32(const float* src, const int64_t* ids, int64_t n_ids, floa
 /* ---- exact top-k search: replaces faiss `IndexFlat::search` behind `index.search(query_vectors, K)`
  * (faiss_vs.py:67,75) - tiled MFMA distance + fused per-query top-k. ---- */
 /* bytes of scratch lvs_flat_search_keys needs for this problem */
-int64_t lvs_flat_search_workspace_bytes(int64_t nq, int64_t nb, int32_t d, int32_t pack_mode, int32_t k);
-/* xb: [nb][ld] packed corpus shard, xq: [nq][ld] packed queries.
+int64_t lvs_flat_search_workspace_bytes(int64_t nq, int64_t nb, int32_t d, int32_t k);
+/* xb: [nb][ld(xb_pack)] packed corpus shard, xq: [nq][ld(xq_pack)] packed queries; the two sides may use
+ * different pack modes (e.g. fp16 points against fp32-accurate centroids).
  * xb_norms_sq / xq_norms_sq: |.|^2 per row, required for LVS_METRIC_L2, ignored for IP.
  * id_offset: global id of shard row 0 (keys carry global ids < 2^32).
  * row_ids (nullable): [nb] uint32 - id to report for each shard row instead of id_offset + row (subset search).
  * out_keys: [nq][k] uint64, best first. */
-int32_t lvs_flat_search_keys(const void* xb, int64_t nb, const void* xq, int64_t nq, int32_t d, int32_t pack_mode,
-                             int32_t metric, int32_t k, const float* xb_norms_sq, const float* xq_norms_sq,
+int32_t lvs_flat_search_keys(const void* xb, int32_t xb_pack, int64_t nb, const void* xq, int32_t xq_pack, int64_t nq,
+                             int32_t d, int32_t metric, int32_t k, const float* xb_norms_sq, const float* xq_norms_sq,
                              int64_t id_offset, const uint32_t* row_ids, uint64_t* out_keys, void* workspace,
                              int64_t workspace_bytes, void* stream);
 /* Merge `nparts` candidate lists (e.g. the all-gathered per-shard lists): parts [nparts][nq][k] -> out [nq][k]. */
@@ -93,9 +94,24 @@ int32_t lvs_keys_to_result(const uint64_t* keys, int64_t nq, int32_t k, int32_t 
 
 /* ---- full score rows (callers that ask for K = N: sem_dedup.py:45, sem_filter.py:491-497, sem_join.py:367):
  * out [nq][ld_out] float32 "better" scores (IP: the product; L2: minus the squared distance). ---- */
-int32_t lvs_scores(const void* xb, int64_t nb, const void* xq, int64_t nq, int32_t d, int32_t pack_mode,
+int32_t lvs_scores(const void* xb, int32_t xb_pack, int64_t nb, const void* xq, int32_t xq_pack, int64_t nq, int32_t d,
                    int32_t metric, const float* xb_norms_sq, const float* xq_norms_sq, float* out, int64_t ld_out,
                    void* stream);
+/* ---- k-means pieces: replace faiss `Kmeans(d, k, niter).train(x)` (lotus/utils.py:61-62); the assignment step and
+ * the final `kmeans.index.search(x, 1)` (utils.py:65) are lvs_flat_search_keys with k = 1 and LVS_METRIC_L2. ---- */
+int64_t lvs_kmeans_accumulate_workspace_bytes(int64_t n, int32_t k);
+/* sums [k][d] float32 += packed rows of x grouped by assign[i] (int64, values outside [0,k) are skipped);
+ * counts [k] float32 += group sizes.  Both must be initialised by the caller.  Rows of one centroid are added
+ * in row order (faiss compute_centroids order), so the result is deterministic. */
+int32_t lvs_kmeans_accumulate(const void* x, int64_t n, int32_t d, int32_t pack_mode, const int64_t* assign,
+                              int32_t k, float* sums, float* counts, void* workspace, int64_t workspace_bytes,
+                              void* stream);
+/* HOST helpers (plain host pointers), bit-exact with faiss: rand_perm(n, seed) = Fisher-Yates on std::mt19937
+ * (training subsample and initial centroids), and split_clusters (empty-cluster re-seeding, RNG seed 1234). */
+int32_t lvs_rand_perm_host(int64_t n, int64_t seed, int64_t* out_perm);
+int32_t lvs_kmeans_split_clusters_host(int32_t d, int32_t k, int64_t n, float* hassign, float* centroids,
+                                       int32_t* out_nsplit);
+
 /* ---- measurement hook: average duration in ms of the dominant search kernel's launches since the last reset,
  * measured with HIP events on the launch stream (enabled with lvs_timing_enable(1)). ---- */
 int32_t lvs_timing_enable(int32_t on);

@@ -101,15 +101,15 @@ class HipBackend:
                     row_ids=None):
         """-> int64 tensor [nq, k] holding the uint64 result keys (bit pattern)."""
         torch = self.torch
-        if corpus.d != queries.d or corpus.mode != queries.mode:
-            raise ValueError("corpus / query layout mismatch")
+        if corpus.d != queries.d:
+            raise ValueError("corpus / query dimension mismatch")
         keys = torch.empty((queries.n, k), dtype=torch.int64, device=self.device)
-        need = int(self.lib.lvs_flat_search_workspace_bytes(queries.n, corpus.n, corpus.d, corpus.mode, k))
+        need = int(self.lib.lvs_flat_search_workspace_bytes(queries.n, corpus.n, corpus.d, k))
         if need < 0:
             raise LotusHipError("lvs_flat_search_workspace_bytes rejected the shape")
         ws = self._workspace(need)
         _capi.check(self.lib.lvs_flat_search_keys(
-            _ptr(corpus.rows), corpus.n, _ptr(queries.rows), queries.n, corpus.d, corpus.mode, metric, k,
+            _ptr(corpus.rows), corpus.mode, corpus.n, _ptr(queries.rows), queries.mode, queries.n, corpus.d, metric, k,
             _ptr(corpus.norms), _ptr(queries.norms), int(id_offset), _ptr(row_ids), _ptr(keys), _ptr(ws),
             int(ws.numel()), self._stream()), "lvs_flat_search_keys")
         return keys
@@ -135,10 +135,36 @@ class HipBackend:
     def scores(self, corpus: PackedRows, queries: PackedRows, metric: int):
         torch = self.torch
         out = torch.empty((queries.n, corpus.n), dtype=torch.float32, device=self.device)
-        _capi.check(self.lib.lvs_scores(_ptr(corpus.rows), corpus.n, _ptr(queries.rows), queries.n, corpus.d,
-                                        corpus.mode, metric, _ptr(corpus.norms), _ptr(queries.norms), _ptr(out),
+        _capi.check(self.lib.lvs_scores(_ptr(corpus.rows), corpus.mode, corpus.n, _ptr(queries.rows), queries.mode,
+                                        queries.n, corpus.d, metric, _ptr(corpus.norms), _ptr(queries.norms), _ptr(out),
                                         corpus.n, self._stream()), "lvs_scores")
         return out
+
+    # ---- k-means pieces ----
+    def kmeans_accumulate(self, x: PackedRows, assign, k: int):
+        """-> (sums float32 [k,d], counts float32 [k]) of the rows of x grouped by assign (int64 device tensor)."""
+        torch = self.torch
+        sums = torch.zeros((k, x.d), dtype=torch.float32, device=self.device)
+        counts = torch.zeros((k,), dtype=torch.float32, device=self.device)
+        need = int(self.lib.lvs_kmeans_accumulate_workspace_bytes(x.n, k))
+        ws = self._workspace(need)
+        _capi.check(self.lib.lvs_kmeans_accumulate(_ptr(x.rows), x.n, x.d, x.mode, _ptr(assign), k, _ptr(sums),
+                                                   _ptr(counts), _ptr(ws), int(ws.numel()), self._stream()),
+                    "lvs_kmeans_accumulate")
+        return sums, counts
+
+    def rand_perm(self, n: int, seed: int) -> np.ndarray:
+        out = np.empty(n, np.int64)
+        _capi.check(self.lib.lvs_rand_perm_host(n, seed, out.ctypes.data), "lvs_rand_perm_host")
+        return out
+
+    def split_clusters(self, n: int, hassign: np.ndarray, centroids: np.ndarray) -> int:
+        assert hassign.dtype == np.float32 and centroids.dtype == np.float32 and centroids.flags.c_contiguous
+        k, d = centroids.shape
+        ns = ctypes.c_int32(0)
+        _capi.check(self.lib.lvs_kmeans_split_clusters_host(d, k, n, hassign.ctypes.data, centroids.ctypes.data,
+                                                            ctypes.byref(ns)), "lvs_kmeans_split_clusters_host")
+        return int(ns.value)
 
     # ---- measurement ----
     def timing_enable(self, on: bool) -> None:

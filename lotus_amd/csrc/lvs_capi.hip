@@ -283,7 +283,8 @@ extern "C" int32_t lvs_gather_f32(const float* src, const int64_t* ids, int64_t 
 // ---------------------------------------------------------------------------------------------------------------
 namespace {
 struct Plan {
-    int dpad, nkd, nk, ld;
+    int dpad, nkd, nk, ldb, ldq, nseg;
+    int seg_q[3], seg_c[3];
     int ntiles, nqt, nslab, tiles_per_slab;
     int kpass, npass;
     int gq;
@@ -291,13 +292,27 @@ struct Plan {
     int64_t off_gtau, off_partial, off_pass, total;
 };
 
-int make_plan(int64_t nq, int64_t nb, int32_t d, int32_t pack_mode, int32_t k, Plan& p, bool allow_v2 = true) {
+int make_plan(int64_t nq, int64_t nb, int32_t d, int32_t xb_pack, int32_t xq_pack, int32_t k, Plan& p,
+              bool allow_v2 = true) {
     if (nq < 0 || nb < 0 || d <= 0 || k < 0) return LVS_EINVAL;
-    if (pack_mode != LVS_PACK_F16 && pack_mode != LVS_PACK_SPLIT) return LVS_EINVAL;
+    if (xb_pack != LVS_PACK_F16 && xb_pack != LVS_PACK_SPLIT) return LVS_EINVAL;
+    if (xq_pack != LVS_PACK_F16 && xq_pack != LVS_PACK_SPLIT) return LVS_EINVAL;
     p.dpad = (int)lvs_round_up(d, LVS_BK);
     p.nkd = p.dpad / LVS_BK;
-    p.nk = pack_mode == LVS_PACK_SPLIT ? 3 * p.nkd : p.nkd;
-    p.ld = pack_mode == LVS_PACK_SPLIT ? 2 * p.dpad : p.dpad;
+    p.ldb = xb_pack == LVS_PACK_SPLIT ? 2 * p.dpad : p.dpad;
+    p.ldq = xq_pack == LVS_PACK_SPLIT ? 2 * p.dpad : p.dpad;
+    // x = hi + lo on either side; keep hi*hi plus the first-order cross terms (lo*lo ~ 2^-22 relative is dropped)
+    p.nseg = 0;
+    auto seg = [&](int qo, int co) {
+        p.seg_q[p.nseg] = qo;
+        p.seg_c[p.nseg] = co;
+        ++p.nseg;
+    };
+    p.seg_q[0] = p.seg_q[1] = p.seg_q[2] = p.seg_c[0] = p.seg_c[1] = p.seg_c[2] = 0;
+    seg(0, 0);
+    if (xb_pack == LVS_PACK_SPLIT) seg(0, p.dpad);
+    if (xq_pack == LVS_PACK_SPLIT) seg(p.dpad, 0);
+    p.nk = p.nseg * p.nkd;
     p.ntiles = (int)lvs_ceil_div(nb > 0 ? nb : 1, LVS_BC);
     p.v2 = allow_v2 && k >= 1 && k <= LVS2_KCAP;
     if (const char* e = getenv("LVS_KERNEL")) {  // tuning override: 1 = 256x128 kernel, 2 = 256x256 kernel
@@ -344,19 +359,19 @@ __global__ void copy_pass_kernel(const u64* __restrict__ src, long long nq, int 
 }
 }  // namespace
 
-extern "C" int64_t lvs_flat_search_workspace_bytes(int64_t nq, int64_t nb, int32_t d, int32_t pack_mode, int32_t k) {
+extern "C" int64_t lvs_flat_search_workspace_bytes(int64_t nq, int64_t nb, int32_t d, int32_t k) {
     Plan p;
-    if (make_plan(nq, nb, d, pack_mode, k, p) != LVS_OK) return LVS_EINVAL;
+    if (make_plan(nq, nb, d, LVS_PACK_F16, LVS_PACK_F16, k, p) != LVS_OK) return LVS_EINVAL;
     return p.total;
 }
 
-extern "C" int32_t lvs_flat_search_keys(const void* xb, int64_t nb, const void* xq, int64_t nq, int32_t d,
-                                        int32_t pack_mode, int32_t metric, int32_t k, const float* xb_norms_sq,
+extern "C" int32_t lvs_flat_search_keys(const void* xb, int32_t xb_pack, int64_t nb, const void* xq, int32_t xq_pack,
+                                        int64_t nq, int32_t d, int32_t metric, int32_t k, const float* xb_norms_sq,
                                         const float* xq_norms_sq, int64_t id_offset, const uint32_t* row_ids,
                                         uint64_t* out_keys, void* workspace, int64_t workspace_bytes, void* stream) {
     Plan p;
-    LVS_REQUIRE(make_plan(nq, nb, d, pack_mode, k, p) == LVS_OK, "bad shape nq=%lld nb=%lld d=%d k=%d pack=%d",
-                (long long)nq, (long long)nb, d, k, pack_mode);
+    LVS_REQUIRE(make_plan(nq, nb, d, xb_pack, xq_pack, k, p) == LVS_OK,
+                "bad shape nq=%lld nb=%lld d=%d k=%d pack=%d/%d", (long long)nq, (long long)nb, d, k, xb_pack, xq_pack);
     LVS_REQUIRE(metric == LVS_METRIC_IP || metric == LVS_METRIC_L2, "bad metric %d", metric);
     LVS_REQUIRE(k <= LVS_MAX_K, "k=%d exceeds LVS_MAX_K", k);
     LVS_REQUIRE(id_offset >= 0 && id_offset + nb < 0xFFFFFFFFll, "ids must stay below 2^32-1");
@@ -389,7 +404,13 @@ extern "C" int32_t lvs_flat_search_keys(const void* xb, int64_t nb, const void* 
     a.out = partial;
     a.nb = nb;
     a.nq = nq;
-    a.ld = p.ld;
+    a.ldb = p.ldb;
+    a.ldq = p.ldq;
+    a.nseg = p.nseg;
+    for (int i = 0; i < 3; ++i) {
+        a.seg_q[i] = p.seg_q[i];
+        a.seg_c[i] = p.seg_c[i];
+    }
     a.id_offset = id_offset;
     a.nkd = p.nkd;
     a.nk = p.nk;
@@ -412,7 +433,7 @@ extern "C" int32_t lvs_flat_search_keys(const void* xb, int64_t nb, const void* 
         {
             ScopedKernelTimer timer(st);
             if (p.v2)
-                LVS_HIP_CHECK(lvs_tile2_launch(a, st));
+                LVS_HIP_CHECK(lvs_tile2_launch(k == 1 && !row_ids ? LVS_MODE_TOP1 : LVS_MODE_TOPK, a, st));
             else
                 LVS_HIP_CHECK(lvs_tile_launch(LVS_MODE_TOPK, a, st));
         }
@@ -457,11 +478,11 @@ extern "C" int32_t lvs_keys_to_result(const uint64_t* keys, int64_t nq, int32_t 
     return LVS_OK;
 }
 
-extern "C" int32_t lvs_scores(const void* xb, int64_t nb, const void* xq, int64_t nq, int32_t d, int32_t pack_mode,
-                              int32_t metric, const float* xb_norms_sq, const float* xq_norms_sq, float* out,
+extern "C" int32_t lvs_scores(const void* xb, int32_t xb_pack, int64_t nb, const void* xq, int32_t xq_pack, int64_t nq,
+                              int32_t d, int32_t metric, const float* xb_norms_sq, const float* xq_norms_sq, float* out,
                               int64_t ld_out, void* stream) {
     Plan p;
-    LVS_REQUIRE(make_plan(nq, nb, d, pack_mode, 1, p, false) == LVS_OK, "bad shape");
+    LVS_REQUIRE(make_plan(nq, nb, d, xb_pack, xq_pack, 1, p, false) == LVS_OK, "bad shape");
     LVS_REQUIRE(metric == LVS_METRIC_IP || metric == LVS_METRIC_L2, "bad metric %d", metric);
     if (nq == 0 || nb == 0) return LVS_OK;
     LVS_REQUIRE(xb && xq && out && ld_out >= nb, "bad buffers");
@@ -476,7 +497,13 @@ extern "C" int32_t lvs_scores(const void* xb, int64_t nb, const void* xq, int64_
     a.ld_scores = ld_out;
     a.nb = nb;
     a.nq = nq;
-    a.ld = p.ld;
+    a.ldb = p.ldb;
+    a.ldq = p.ldq;
+    a.nseg = p.nseg;
+    for (int i = 0; i < 3; ++i) {
+        a.seg_q[i] = p.seg_q[i];
+        a.seg_c[i] = p.seg_c[i];
+    }
     a.nkd = p.nkd;
     a.nk = p.nk;
     a.metric = metric;

@@ -1,0 +1,185 @@
+// k-means pieces behind lotus.utils.cluster (lotus/utils.py:61-65 -> faiss Kmeans.train + index.search(x, 1)).
+//
+// Assignment is the tile kernel in top-1 / squared-L2 mode (lvs_flat_search_keys with k = 1).  This file holds the
+// centroid update and the host-side pieces of faiss's Clustering::train that must match bit for bit:
+//   * lvs_kmeans_accumulate: rows are bucketed by centroid with a STABLE radix sort on the assignment bits
+//     (rocPRIM), then every (centroid, 256-dim chunk) is reduced by one workgroup that walks its bucket in row
+//     order - the accumulation order of faiss compute_centroids, so results are reproducible run to run;
+//   * lvs_rand_perm_host / lvs_kmeans_split_clusters_host: std::mt19937-driven subsample/init permutation and
+//     empty-cluster re-seeding exactly as faiss.
+#include <cstring>
+#include <random>
+
+#include <rocprim/rocprim.hpp>
+
+#include "lvs_common.h"
+#include "lvs_tile.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void km_keys_kernel(const long long* __restrict__ assign, long long n, int k,
+                                                      uint32_t* __restrict__ keys, uint32_t* __restrict__ vals,
+                                                      uint32_t* __restrict__ counts) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    long long c = assign[i];
+    uint32_t cc = (c < 0 || c >= k) ? (uint32_t)k : (uint32_t)c;  // out-of-range assignments are ignored
+    keys[i] = cc;
+    vals[i] = (uint32_t)i;
+    if (cc < (uint32_t)k) atomicAdd(&counts[cc], 1u);  // integer atomics: order-independent
+}
+
+// exclusive scan of counts[0..k] (k + 1 entries incl. the "ignored" bucket) by one workgroup
+__global__ __launch_bounds__(1024) void km_scan_kernel(const uint32_t* __restrict__ counts, int k,
+                                                       uint32_t* __restrict__ offsets) {
+    __shared__ uint32_t carry;
+    __shared__ uint32_t buf[1024];
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < k; base += 1024) {
+        int i = base + threadIdx.x;
+        uint32_t v = i < k ? counts[i] : 0;
+        buf[threadIdx.x] = v;
+        __syncthreads();
+        for (int off = 1; off < 1024; off <<= 1) {
+            uint32_t t = threadIdx.x >= off ? buf[threadIdx.x - off] : 0;
+            __syncthreads();
+            buf[threadIdx.x] += t;
+            __syncthreads();
+        }
+        if (i < k) offsets[i] = carry + buf[threadIdx.x] - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry += buf[1023];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) offsets[k] = carry;
+}
+
+// grid = (k, ceil(d / 256)); thread t owns dimension chunk*256 + t of centroid blockIdx.x
+__global__ __launch_bounds__(256) void km_reduce_kernel(const _Float16* __restrict__ x, long long ld, int d, int dpad,
+                                                        int split, const uint32_t* __restrict__ rows,
+                                                        const uint32_t* __restrict__ offsets,
+                                                        float* __restrict__ sums, float* __restrict__ cnt_out) {
+    const int c = blockIdx.x;
+    const int j = blockIdx.y * 256 + threadIdx.x;
+    const uint32_t b = offsets[c], e = offsets[c + 1];
+    if (blockIdx.y == 0 && threadIdx.x == 0) cnt_out[c] += (float)(e - b);
+    if (j >= d) return;
+    float acc = 0.f;
+    for (uint32_t p = b; p < e; ++p) {
+        const _Float16* row = x + (long long)rows[p] * ld;
+        float v = (float)row[j];
+        if (split) v += (float)row[dpad + j];
+        acc += v;  // sequential, in row order
+    }
+    sums[(long long)c * d + j] += acc;
+}
+
+}  // namespace
+
+extern "C" int64_t lvs_kmeans_accumulate_workspace_bytes(int64_t n, int32_t k) {
+    if (n < 0 || k <= 0) return LVS_EINVAL;
+    size_t tmp = 0;
+    uint32_t* nil = nullptr;
+    (void)rocprim::radix_sort_pairs(nullptr, tmp, nil, nil, nil, nil, (size_t)(n > 0 ? n : 1), 0u, 32u);
+    int64_t bytes = lvs_round_up((int64_t)tmp, 256);
+    bytes += 4 * lvs_round_up(n * 4, 256);             // keys in/out, vals in/out
+    bytes += 2 * lvs_round_up((int64_t)(k + 2) * 4, 256);  // counts, offsets
+    return bytes;
+}
+
+extern "C" int32_t lvs_kmeans_accumulate(const void* x, int64_t n, int32_t d, int32_t pack_mode, const int64_t* assign,
+                                         int32_t k, float* sums, float* counts, void* workspace, int64_t workspace_bytes,
+                                         void* stream) {
+    LVS_REQUIRE(n >= 0 && d > 0 && k > 0, "bad shape n=%lld d=%d k=%d", (long long)n, d, k);
+    LVS_REQUIRE(pack_mode == LVS_PACK_F16 || pack_mode == LVS_PACK_SPLIT, "bad pack_mode");
+    LVS_REQUIRE(n < 0xFFFFFFFFll, "n must be below 2^32");
+    if (n == 0) return LVS_OK;
+    LVS_REQUIRE(x && assign && sums && counts && workspace, "NULL buffer");
+    const int64_t need = lvs_kmeans_accumulate_workspace_bytes(n, k);
+    if (workspace_bytes < need) {
+        lvs_set_error("workspace too small: need %lld bytes", (long long)need);
+        return LVS_ENOMEM;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    size_t tmp = 0;
+    uint32_t* nil = nullptr;
+    (void)rocprim::radix_sort_pairs(nullptr, tmp, nil, nil, nil, nil, (size_t)n, 0u, 32u);
+    char* w = (char*)workspace;
+    void* d_tmp = w;
+    w += lvs_round_up((int64_t)tmp, 256);
+    uint32_t* keys_in = (uint32_t*)w;
+    w += lvs_round_up(n * 4, 256);
+    uint32_t* keys_out = (uint32_t*)w;
+    w += lvs_round_up(n * 4, 256);
+    uint32_t* vals_in = (uint32_t*)w;
+    w += lvs_round_up(n * 4, 256);
+    uint32_t* vals_out = (uint32_t*)w;
+    w += lvs_round_up(n * 4, 256);
+    uint32_t* cnt = (uint32_t*)w;
+    w += lvs_round_up((int64_t)(k + 2) * 4, 256);
+    uint32_t* offs = (uint32_t*)w;
+
+    LVS_HIP_CHECK(hipMemsetAsync(cnt, 0, (size_t)(k + 2) * 4, st));
+    hipLaunchKernelGGL(km_keys_kernel, dim3((unsigned)lvs_ceil_div(n, 256)), dim3(256), 0, st, (const long long*)assign,
+                       (long long)n, k, keys_in, vals_in, cnt);
+    unsigned bits = 1;
+    while ((1u << bits) < (unsigned)(k + 1)) ++bits;
+    LVS_HIP_CHECK(rocprim::radix_sort_pairs(d_tmp, tmp, keys_in, keys_out, vals_in, vals_out, (size_t)n, 0u, bits, st));
+    hipLaunchKernelGGL(km_scan_kernel, dim3(1), dim3(1024), 0, st, cnt, k, offs);
+    const int dpad = (int)lvs_round_up(d, LVS_BK);
+    const long long ld = pack_mode == LVS_PACK_SPLIT ? 2 * dpad : dpad;
+    hipLaunchKernelGGL(km_reduce_kernel, dim3((unsigned)k, (unsigned)lvs_ceil_div(d, 256)), dim3(256), 0, st,
+                       (const _Float16*)x, ld, d, dpad, pack_mode == LVS_PACK_SPLIT ? 1 : 0, vals_out, offs, sums,
+                       counts);
+    LVS_HIP_CHECK(hipGetLastError());
+    return LVS_OK;
+}
+
+// ---- host-side pieces of faiss Clustering (bit-exact: std::mt19937 is the generator faiss uses) -------------
+extern "C" int32_t lvs_rand_perm_host(int64_t n, int64_t seed, int64_t* out_perm) {
+    LVS_REQUIRE(n >= 0 && (n == 0 || out_perm), "bad arguments");
+    std::mt19937 mt((unsigned)seed);
+    for (int64_t i = 0; i < n; ++i) out_perm[i] = i;
+    for (int64_t i = 0; i + 1 < n; ++i) {
+        int64_t i2 = i + (int64_t)(mt() % (uint32_t)(n - i));  // faiss rand_int(max) = mt() % max
+        int64_t t = out_perm[i];
+        out_perm[i] = out_perm[i2];
+        out_perm[i2] = t;
+    }
+    return LVS_OK;
+}
+
+extern "C" int32_t lvs_kmeans_split_clusters_host(int32_t d, int32_t k, int64_t n, float* hassign, float* centroids,
+                                                  int32_t* out_nsplit) {
+    LVS_REQUIRE(d > 0 && k > 0 && n > k && hassign && centroids, "bad arguments");
+    const float EPS = 1.0f / 1024.0f;
+    std::mt19937 mt(1234u);
+    int32_t nsplit = 0;
+    for (int32_t ci = 0; ci < k; ++ci) {
+        if (hassign[ci] != 0.f) continue;
+        int32_t cj;
+        for (cj = 0;; cj = (cj + 1) % k) {
+            float p = (hassign[cj] - 1.0f) / (float)(n - k);
+            float r = (float)mt() / (float)mt.max();  // faiss rand_float()
+            if (r < p) break;
+        }
+        float* a = centroids + (int64_t)ci * d;
+        float* b = centroids + (int64_t)cj * d;
+        memcpy(a, b, sizeof(float) * (size_t)d);
+        for (int32_t j = 0; j < d; ++j) {
+            if (j % 2 == 0) {
+                a[j] *= 1 + EPS;
+                b[j] *= 1 - EPS;
+            } else {
+                a[j] *= 1 - EPS;
+                b[j] *= 1 + EPS;
+            }
+        }
+        hassign[ci] = hassign[cj] / 2;
+        hassign[cj] -= hassign[ci];
+        ++nsplit;
+    }
+    if (out_nsplit) *out_nsplit = nsplit;
+    return LVS_OK;
+}

@@ -15,6 +15,7 @@
 
 #define LVS_MODE_TOPK 0
 #define LVS_MODE_SCORES 1
+#define LVS_MODE_TOP1 2
 
 struct LvsTileArgs {
     const void* xb;           // [nb][ld] fp16 packed corpus shard
@@ -28,10 +29,13 @@ struct LvsTileArgs {
     u64* out;                 // [nslab][nq][k] per-slab candidate keys
     float* scores;            // LVS_MODE_SCORES: [nq][ld_scores]
     long long ld_scores;
-    long long nb, nq, ld;     // ld in halfs
+    long long nb, nq;
+    long long ldb, ldq;       // leading dimensions in halfs (corpus / queries)
     long long id_offset;
     int nkd;                  // padded d / 64
-    int nk;                   // K-steps per tile: nkd (fp16) or 3 * nkd (split fp32)
+    int nk;                   // K-steps per tile = nseg * nkd
+    int nseg;                 // K segments: product = sum over segments of q[seg_q..] . y[seg_c..]
+    int seg_q[3], seg_c[3];   // column offsets (halfs) of each segment in the query / corpus rows
     int metric;
     int k;                    // <= LVS_KPASS
     int ntiles, tiles_per_slab, nslab, nqt;
@@ -41,4 +45,4 @@ struct LvsTileArgs {
 
 int lvs_tile_grid_blocks(int nqt, int nslab, int gq);
 hipError_t lvs_tile_launch(int mode, const LvsTileArgs& a, hipStream_t stream);
-hipError_t lvs_tile2_launch(const LvsTileArgs& a, hipStream_t stream);
+hipError_t lvs_tile2_launch(int mode, const LvsTileArgs& a, hipStream_t stream);

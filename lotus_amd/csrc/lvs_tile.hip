@@ -88,8 +88,8 @@ __global__ __launch_bounds__(LVS_TILE_THREADS, 2) void lvs_tile_kernel(const Lvs
 
     const _Float16* __restrict__ xb = (const _Float16*)a.xb;
     const _Float16* __restrict__ xq = (const _Float16*)a.xq;
-    const long long ld = a.ld;
-    const int nk = a.nk, nkd = a.nkd, dpad = a.nkd * LVS_BK;
+    const long long ldb = a.ldb, ldq = a.ldq;
+    const int nk = a.nk, nkd = a.nkd;
 
     // ---- per-lane staging addresses --------------------------------------------------------------------
     // one glds covers 8 rows x 128 B: lane -> (row = R0 + lane/8, physical chunk p = lane%8) holds logical
@@ -108,21 +108,21 @@ __global__ __launch_bounds__(LVS_TILE_THREADS, 2) void lvs_tile_kernel(const Lvs
         int row = wave * 16 + i * 8 + srow;
         long long grow = a.debug_hot ? row : q0 + row;
         if (grow > a.nq - 1) grow = a.nq - 1;
-        q_src[i] = xq + grow * ld + (sp ^ ((row >> 1) & 7)) * 8;
+        q_src[i] = xq + grow * ldq + (sp ^ ((row >> 1) & 7)) * 8;
     }
 
     auto stage = [&](int t, int buf) {
         int ti = t / nk, ks = t - ti * nk;
         int seg = ks / nkd, r = ks - seg * nkd;
-        int qcol = (seg == 2 ? dpad : 0) + r * LVS_BK;
-        int ccol = (seg == 1 ? dpad : 0) + r * LVS_BK;
+        int qcol = a.seg_q[seg] + r * LVS_BK;
+        int ccol = a.seg_c[seg] + r * LVS_BK;
         long long trow0 = a.debug_hot ? 0 : (long long)(tile0 + ti) * LVS_BC;
         char* base = smem + buf * STAGE_BYTES;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             long long grow = trow0 + c_row[i];
             if (grow > a.nb - 1) grow = a.nb - 1;
-            glds16(xb + grow * ld + ccol + c_col[i], base + (wave * 32 + i * 8) * ROWB);
+            glds16(xb + grow * ldb + ccol + c_col[i], base + (wave * 32 + i * 8) * ROWB);
         }
 #pragma unroll
         for (int i = 0; i < 2; ++i) glds16(q_src[i] + qcol, base + LVS_BC * ROWB + (wave * 16 + i * 8) * ROWB);

@@ -57,6 +57,7 @@ __device__ inline bool item_of_block(const LvsTileArgs& a, int b, int& qt, int& 
 
 }  // namespace
 
+template <int MODE>  // LVS_MODE_TOPK: lists + pool (1 < k <= KCAP);  LVS_MODE_TOP1: k == 1, per-lane running best
 __global__ __launch_bounds__(512, 2) void lvs_tile2_kernel(const LvsTileArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -76,11 +77,13 @@ __global__ __launch_bounds__(512, 2) void lvs_tile2_kernel(const LvsTileArgs a) 
     unsigned short* pown = (unsigned short*)(smem + OFF_POWN);
     uint32_t* pcnt = (uint32_t*)(smem + OFF_CTRL);  // [2]
     uint32_t* flags = pcnt + 2;                       // [2]
+    float* bnl = (float*)(smem + OFF_LIST);           // TOP1: |y|^2 of the current corpus tile [BC]
+    u64* part = (u64*)(smem + OFF_LIST + BC * 4);     // TOP1: [BQ][4] per-lane partial best keys
 
     const _Float16* __restrict__ xb = (const _Float16*)a.xb;
     const _Float16* __restrict__ xq = (const _Float16*)a.xq;
-    const long long ld = a.ld;
-    const int nk = a.nk, nkd = a.nkd, dpad = a.nkd * BK;
+    const long long ldb = a.ldb, ldq = a.ldq;
+    const int nk = a.nk, nkd = a.nkd;
     const int k = a.k;
 
     // ---- staging addresses: wave stages corpus rows [wave*32, +32) and query rows [wave*32, +32) --------------
@@ -97,21 +100,21 @@ __global__ __launch_bounds__(512, 2) void lvs_tile2_kernel(const LvsTileArgs a) 
     for (int i = 0; i < 4; ++i) {
         long long grow = a.debug_hot ? s_row[i] : q0 + s_row[i];
         if (grow > a.nq - 1) grow = a.nq - 1;
-        q_src[i] = xq + grow * ld + s_col[i];
+        q_src[i] = xq + grow * ldq + s_col[i];
     }
 
     auto stage = [&](int t, int buf) {
         int ti = t / nk, ks = t - ti * nk;
         int seg = ks / nkd, r = ks - seg * nkd;
-        int qcol = (seg == 2 ? dpad : 0) + r * BK;
-        int ccol = (seg == 1 ? dpad : 0) + r * BK;
+        int qcol = a.seg_q[seg] + r * BK;
+        int ccol = a.seg_c[seg] + r * BK;
         long long trow0 = a.debug_hot ? 0 : (long long)(tile0 + ti) * BC;
         char* base = smem + buf * STAGE_BYTES;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             long long grow = trow0 + s_row[i];
             if (grow > a.nb - 1) grow = a.nb - 1;
-            glds16(xb + grow * ld + ccol + s_col[i], base + (wave * 32 + i * 8) * ROWB);
+            glds16(xb + grow * ldb + ccol + s_col[i], base + (wave * 32 + i * 8) * ROWB);
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) glds16(q_src[i] + qcol, base + BC * ROWB + (wave * 32 + i * 8) * ROWB);
@@ -144,8 +147,12 @@ __global__ __launch_bounds__(512, 2) void lvs_tile2_kernel(const LvsTileArgs a) 
         }
     }
 
-    for (int i = tid; i < BQ * KCAP; i += 512) lists[i] = 0;
-    if (tid < 4) pcnt[tid] = 0;
+    if (MODE == LVS_MODE_TOPK) {
+        for (int i = tid; i < BQ * KCAP; i += 512) lists[i] = 0;
+        if (tid < 4) pcnt[tid] = 0;
+    }
+    float bestv[2] = {-INFINITY, -INFINITY};
+    uint32_t besti[2] = {0xFFFFFFFFu, 0xFFFFFFFFu};
 
     f32x16 acc[4][2];
 #pragma unroll
@@ -196,8 +203,8 @@ __global__ __launch_bounds__(512, 2) void lvs_tile2_kernel(const LvsTileArgs a) 
         const int n_ti = tn / nk;
         const int n_ks = tn - n_ti * nk;
         const int n_seg = n_ks / nkd, n_r = n_ks - n_seg * nkd;
-        const int n_qcol = (n_seg == 2 ? dpad : 0) + n_r * BK;
-        const int n_ccol = (n_seg == 1 ? dpad : 0) + n_r * BK;
+        const int n_qcol = a.seg_q[n_seg] + n_r * BK;
+        const int n_ccol = a.seg_c[n_seg] + n_r * BK;
         const long long n_trow0 = a.debug_hot ? 0 : (long long)(tile0 + n_ti) * BC;
         half8 Bf[2][2], Af[3];
         Bf[0][0] = *(const half8*)(sb + b_base + foff[0]);
@@ -219,7 +226,7 @@ __global__ __launch_bounds__(512, 2) void lvs_tile2_kernel(const LvsTileArgs a) 
                 if (f < 4) {
                     long long grow = n_trow0 + s_row[f];
                     if (grow > a.nb - 1) grow = a.nb - 1;
-                    glds16(xb + grow * ld + n_ccol + s_col[f], n_base + (wave * 32 + f * 8) * ROWB);
+                    glds16(xb + grow * ldb + n_ccol + s_col[f], n_base + (wave * 32 + f * 8) * ROWB);
                 } else {
                     glds16(q_src[f - 4] + n_qcol, n_base + BC * ROWB + (wave * 32 + (f - 4) * 8) * ROWB);
                 }
@@ -235,20 +242,64 @@ __global__ __launch_bounds__(512, 2) void lvs_tile2_kernel(const LvsTileArgs a) 
         ++ti;
         const int lrow_base = wm * 128 + 4 * (lane >> 5);  // + mi*32 + (r&3) + 8*(r>>2)
 
-        if (a.metric == LVS_METRIC_L2) {
+        if (MODE == LVS_MODE_TOP1) {
+            // ---- k == 1: per-lane running best, no lists.  Rows are visited in increasing order, so a strict
+            // "greater" keeps the lowest row among equal scores (the oracle's tie rule). ----
+            if (a.metric == LVS_METRIC_L2) {
+                __syncthreads();
+                if (tid < BC) {
+                    const long long row = trow0 + tid;
+                    bnl[tid] = row < a.nb ? a.bn[row] : INFINITY;  // rows past the end never win
+                }
+                __syncthreads();
+            }
+#pragma unroll 1
+            for (int mi = 0; mi < 4; ++mi) {  // rolled: keeps the epilogue's register footprint small
+                f32x16 t0, t1;
+                switch (mi) {
+                    case 0: t0 = acc[0][0]; t1 = acc[0][1]; break;
+                    case 1: t0 = acc[1][0]; t1 = acc[1][1]; break;
+                    case 2: t0 = acc[2][0]; t1 = acc[2][1]; break;
+                    default: t0 = acc[3][0]; t1 = acc[3][1]; break;
+                }
 #pragma unroll
-            for (int mi = 0; mi < 4; ++mi)
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    const int lrow = lrow_base + mi * 32 + 8 * r4;
+                    f32x4 bn4 = {0.f, 0.f, 0.f, 0.f};
+                    if (a.metric == LVS_METRIC_L2) bn4 = *(const f32x4*)(bnl + lrow);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    long long row = trow0 + lrow_base + mi * 32 + (r & 3) + 8 * (r >> 2);
-                    float bnv = row < a.nb ? a.bn[row] : 0.f;
+                    for (int e = 0; e < 4; ++e) {
+                        const long long row = trow0 + lrow + e;
 #pragma unroll
-                    for (int ni = 0; ni < 2; ++ni) {
-                        float dis = (qnv[ni] + bnv) - 2.0f * acc[mi][ni][r];
-                        acc[mi][ni][r] = -fmaxf(dis, 0.f);
+                        for (int ni = 0; ni < 2; ++ni) {
+                            float s = ni ? t1[r4 * 4 + e] : t0[r4 * 4 + e];
+                            if (a.metric == LVS_METRIC_L2)
+                                s = -fmaxf((qnv[ni] + bn4[e]) - 2.0f * s, 0.f);
+                            else
+                                s = row < a.nb ? s : -INFINITY;
+                            if (s > bestv[ni]) {
+                                bestv[ni] = s;
+                                besti[ni] = (uint32_t)row;
+                            }
+                        }
                     }
                 }
-        }
+            }
+        } else {
+        if (a.metric == LVS_METRIC_L2) {
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        long long row = trow0 + lrow_base + mi * 32 + (r & 3) + 8 * (r >> 2);
+                        float bnv = row < a.nb ? a.bn[row] : 0.f;
+#pragma unroll
+                        for (int ni = 0; ni < 2; ++ni) {
+                            float dis = (qnv[ni] + bnv) - 2.0f * acc[mi][ni][r];
+                            acc[mi][ni][r] = -fmaxf(dis, 0.f);
+                        }
+                    }
+            }
 
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni)
@@ -338,6 +389,7 @@ __global__ __launch_bounds__(512, 2) void lvs_tile2_kernel(const LvsTileArgs a) 
             ++round;
             if (!ovf) break;  // last tile and nothing left to retry
         }
+        }  // MODE
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
@@ -346,6 +398,24 @@ __global__ __launch_bounds__(512, 2) void lvs_tile2_kernel(const LvsTileArgs a) 
                 for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
     }
 
+    if (MODE == LVS_MODE_TOP1) {
+        // four lanes (l, l+32 of waves wm = 0, 1) hold partial winners of each query: combine by key
+        __syncthreads();
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            u64 key = 0;
+            if (besti[ni] != 0xFFFFFFFFu) key = lvs_pack_key(bestv[ni], (uint32_t)(besti[ni] + a.id_offset));
+            part[qloc[ni] * 4 + wm * 2 + (lane >> 5)] = key;
+        }
+        __syncthreads();
+        if (tid < BQ && q0 + tid < a.nq) {
+            u64 b = part[tid * 4];
+#pragma unroll
+            for (int j = 1; j < 4; ++j) b = part[tid * 4 + j] > b ? part[tid * 4 + j] : b;
+            a.out[(long long)slab * a.nq + q0 + tid] = b;
+        }
+        return;
+    }
     // lists are complete (the last tile always drains) and sorted: write the slab's candidates
     __syncthreads();
     for (int i = tid; i < BQ * k; i += 512) {
@@ -354,15 +424,21 @@ __global__ __launch_bounds__(512, 2) void lvs_tile2_kernel(const LvsTileArgs a) 
     }
 }
 
-hipError_t lvs_tile2_launch(const LvsTileArgs& a, hipStream_t stream) {
+hipError_t lvs_tile2_launch(int mode, const LvsTileArgs& a, hipStream_t stream) {
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)lvs_tile2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           LDS_TOTAL);
+        hipError_t e = hipFuncSetAttribute((const void*)lvs_tile2_kernel<LVS_MODE_TOPK>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);
+        if (e != hipSuccess) return e;
+        e = hipFuncSetAttribute((const void*)lvs_tile2_kernel<LVS_MODE_TOP1>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);
         if (e != hipSuccess) return e;
         attr_done = true;
     }
     dim3 grid(lvs_tile_grid_blocks(a.nqt, a.nslab, a.gq)), block(512);
-    hipLaunchKernelGGL(lvs_tile2_kernel, grid, block, LDS_TOTAL, stream, a);
+    if (mode == LVS_MODE_TOP1)
+        hipLaunchKernelGGL(lvs_tile2_kernel<LVS_MODE_TOP1>, grid, block, LDS_TOTAL, stream, a);
+    else
+        hipLaunchKernelGGL(lvs_tile2_kernel<LVS_MODE_TOPK>, grid, block, LDS_TOTAL, stream, a);
     return hipGetLastError();
 }

@@ -84,3 +84,21 @@ class OracleBackend:
         k = keys.numpy().view(np.uint64)
         D, I = _finish(k, metric, None if id_map is None else id_map.numpy())
         return torch.from_numpy(D), torch.from_numpy(I)
+
+    # ---- k-means pieces ----
+    def kmeans_accumulate(self, x, assign, k):
+        vals = x.rows.numpy()
+        a = assign.numpy().astype(np.int64)
+        sums = np.zeros((k, vals.shape[1]), np.float32)
+        ok = (a >= 0) & (a < k)
+        np.add.at(sums, a[ok], vals[ok])  # unbuffered: in row order, like the device kernel
+        counts = np.bincount(a[ok], minlength=k).astype(np.float32)
+        return torch.from_numpy(sums), torch.from_numpy(counts)
+
+    def rand_perm(self, n, seed):
+        return oracle.rand_perm(n, seed)
+
+    def split_clusters(self, n, hassign, centroids):
+        from oracle.kmeans import _split_clusters
+
+        return _split_clusters(n, hassign, centroids, None)

@@ -33,15 +33,15 @@ def test_host_side_entry_points_without_a_gpu():
     assert lib.lvs_packed_ld(100, _capi.PACK_F16) == 128
     assert lib.lvs_packed_ld(384, _capi.PACK_SPLIT) == 768
     assert lib.lvs_packed_ld(0, _capi.PACK_F16) < 0 and lib.lvs_packed_ld(8, 7) < 0
-    ws = lib.lvs_flat_search_workspace_bytes(100000, 1000000, 768, _capi.PACK_F16, 10)
+    ws = lib.lvs_flat_search_workspace_bytes(100000, 1000000, 768, 10)
     assert 100000 * 10 * 8 <= ws < 1 << 30
-    assert lib.lvs_flat_search_workspace_bytes(-1, 10, 8, 0, 1) < 0
+    assert lib.lvs_flat_search_workspace_bytes(-1, 10, 8, 1) < 0
     # argument validation happens before any device work
-    st = lib.lvs_flat_search_keys(None, 10, None, 10, 8, 0, 5, 3, None, None, 0, None, None, None, 0, None)
+    st = lib.lvs_flat_search_keys(None, 0, 10, None, 0, 10, 8, 5, 3, None, None, 0, None, None, None, 0, None)
     assert st == _capi.EINVAL and b"metric" in lib.lvs_last_error()
     st = lib.lvs_merge_keys(None, 2, 5, 100, None, None)
     assert st == _capi.EINVAL
-    assert lib.lvs_flat_search_keys(None, 10, None, 0, 8, 0, 0, 3, None, None, 0, None, None, None, 0, None) == 0
+    assert lib.lvs_flat_search_keys(None, 0, 10, None, 0, 0, 8, 0, 3, None, None, 0, None, None, None, 0, None) == 0
 
 
 def test_missing_library_fails_loudly(monkeypatch):

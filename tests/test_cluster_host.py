@@ -1,0 +1,88 @@
+"""Host logic of lotus_amd.cluster (faiss-parity k-means driver + the lotus.utils.cluster replacement) on the CPU
+with the oracle-backed test double; the device kernels it drives are covered by tests/test_gpu_kmeans.py."""
+import numpy as np
+import pandas as pd
+import pytest
+
+import oracle
+import ref_harness
+from oracle_backend import OracleBackend, _emulate_storage
+
+
+def blobs(n=1500, k=6, d=16, seed=0):
+    rng = np.random.default_rng(seed)
+    c = rng.standard_normal((k, d)).astype(np.float32) * 4
+    return (c[rng.integers(0, k, n)] + 0.3 * rng.standard_normal((n, d))).astype(np.float32)
+
+
+def test_kmeans_driver_equals_the_oracle_restatement():
+    from lotus_amd.cluster import kmeans
+
+    x = blobs()
+    x = _emulate_storage(x, 1)  # values the device would hold, so both sides see identical inputs
+    r = kmeans(x, 6, niter=7, backend=OracleBackend())
+    o = oracle.kmeans_faiss(x, 6, niter=7)
+    assert np.array_equal(r.assign, o.assign) and np.allclose(r.centroids, o.centroids, atol=1e-6)
+    assert np.allclose(r.obj, o.obj, rtol=1e-6) and np.array_equal(r.train_ids, o.train_ids)
+
+
+def test_subsample_n_equals_k_and_errors():
+    from lotus_amd.cluster import kmeans
+
+    x = _emulate_storage(blobs(900, 3, 8, seed=2), 1)
+    r = kmeans(x, 3, niter=3, max_points_per_centroid=100, backend=OracleBackend())
+    o = oracle.kmeans_faiss(x, 3, niter=3, max_points_per_centroid=100)
+    assert len(r.train_ids) == 300 and np.array_equal(r.train_ids, o.train_ids) and np.array_equal(r.assign, o.assign)
+    full = kmeans(x, 3, niter=3, max_points_per_centroid=None, backend=OracleBackend())
+    assert len(full.train_ids) == 900
+    rk = kmeans(x[:5], 5, niter=4, backend=OracleBackend())
+    assert np.array_equal(rk.centroids, x[:5])
+    with pytest.raises(ValueError):
+        kmeans(x[:3], 5, backend=OracleBackend())
+
+
+def test_empty_cluster_split_path():
+    from lotus_amd.cluster import kmeans
+
+    xd = np.repeat(np.random.default_rng(3).standard_normal((3, 8)).astype(np.float32), 20, axis=0)
+    xd = _emulate_storage(xd, 1)
+    r = kmeans(xd, 5, niter=4, backend=OracleBackend())
+    o = oracle.kmeans_faiss(xd, 5, niter=4)
+    assert r.nsplit.tolist() == o.nsplit.tolist() and r.nsplit[0] >= 2
+    assert np.allclose(r.centroids, o.centroids, atol=1e-6) and np.array_equal(r.assign, o.assign)
+
+
+@pytest.mark.skipif(not ref_harness.available(), reason="reference checkout not present")
+def test_installed_cluster_matches_the_reference_function(tmp_path):
+    """sem_cluster_by through the REAL accessor: reference lotus.utils.cluster (faiss shim) vs our replacement."""
+    lotus = ref_harness.import_lotus()
+    from lotus.models.rm import RM
+    from lotus.vector_store.faiss_vs import FaissVS
+
+    import fake_rm
+    from lotus_amd import HipVS, cluster as lcluster
+
+    words = sum(fake_rm.TOPICS.values(), [])
+    rng = np.random.default_rng(1)
+    texts = [" ".join(rng.choice(words, 3)) for _ in range(90)]
+
+    def run(d):
+        df = pd.DataFrame({"T": texts}).sem_index("T", d)
+        return df.sem_cluster_by("T", 4, niter=6)
+
+    lotus.settings.configure(rm=fake_rm.make_rm(RM), vs=FaissVS())
+    a = run(str(tmp_path / "f"))
+    lotus.settings.configure(rm=fake_rm.make_rm(RM), vs=HipVS(backend=OracleBackend()))
+    lcluster.install()
+    try:
+        assert lotus.utils.cluster is lcluster.cluster
+        b = run(str(tmp_path / "h"))
+        df = pd.DataFrame({"T": texts}).sem_index("T", str(tmp_path / "h2"))
+        with pytest.raises(ValueError, match="Number of centroids"):
+            df.sem_cluster_by("T", 91)
+        with pytest.raises(ValueError, match="not found"):
+            lcluster.cluster("missing", 2)(df)
+    finally:
+        lcluster.uninstall()
+    assert lotus.utils.cluster is not lcluster.cluster
+    assert a["cluster_id"].tolist() == b["cluster_id"].tolist() and len(set(a["cluster_id"])) == 4

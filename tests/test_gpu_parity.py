@@ -65,6 +65,22 @@ def test_search_parity(hip_backend, nq, nb, d, k, mode, metric):
         assert (I == Ir).mean() > 0.999  # identical inputs: only summation-order near-ties may swap
 
 
+@pytest.mark.parametrize("cmode,qmode", [(F16, SPLIT), (SPLIT, F16)])
+@pytest.mark.parametrize("k", [1, 7, 20])
+def test_mixed_precision_operands(hip_backend, cmode, qmode, k):
+    """fp16-stored rows on one side, fp32-accurate (hi|lo) rows on the other: two K segments."""
+    be = hip_backend
+    xb = synth.corpus(3000, 200, seed=12) * 1.2
+    xq, _ = synth.queries(xb, 260, seed=5)
+    cb = be.pack(xb.astype(np.float16) if cmode == F16 else xb, cmode)
+    cq = be.pack(xq.astype(np.float16) if qmode == F16 else xq, qmode)
+    for metric in (IP, L2):
+        D, I = be.keys_to_result(be.search_keys(cb, cq, k, metric), metric)
+        Dr, Ir = oracle.flat_search(_stored(xb, cmode), _stored(xq, qmode), k, metric)
+        err, hard, recall = synth.compare_topk(Dr, Ir, D.cpu().numpy(), I.cpu().numpy(), atol=3e-5)
+        assert err <= 3e-5 and hard == 0 and recall >= 0.9999
+
+
 def test_duplicates_follow_the_total_order(hip_backend):
     """Exact duplicate rows give exactly equal scores; ids must come back ascending inside each tie group."""
     base = synth.corpus(50, 128, seed=5)
