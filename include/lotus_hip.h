@@ -97,6 +97,18 @@ int32_t lvs_keys_to_result(const uint64_t* keys, int64_t nq, int32_t k, int32_t 
 int32_t lvs_scores(const void* xb, int32_t xb_pack, int64_t nb, const void* xq, int32_t xq_pack, int64_t nq, int32_t d,
                    int32_t metric, const float* xb_norms_sq, const float* xq_norms_sq, float* out, int64_t ld_out,
                    void* stream);
+/* ---- threshold join: replaces `sem_sim_join(self, K = len(df))` + `_scores > threshold` (sem_dedup.py:45-46), which
+ * materialises N^2 results in the reference.  Emits (query, corpus row id, score) for every score STRICTLY greater
+ * than `threshold` (for L2 the score is minus the squared distance).  q_row0 >= 0 selects the self-join: query r is
+ * corpus row q_row0 + r and only pairs with id > q_row0 + r are kept (each unordered pair once), tiles below the
+ * diagonal are skipped.  qt_stride / qt_phase deal 128-query tiles round-robin to ranks (multi-GPU, corpus replicated).
+ * out_count (device uint64, zeroed by the caller) receives the number of qualifying pairs; pairs beyond `capacity`
+ * are counted but not stored, so a caller can size the buffers and run again.  Pair order is unspecified. ---- */
+int32_t lvs_range_join(const void* xb, int32_t xb_pack, int64_t nb, const void* xq, int32_t xq_pack, int64_t nq,
+                       int32_t d, int32_t metric, const float* xb_norms_sq, const float* xq_norms_sq, float threshold,
+                       int64_t q_row0, int64_t id_offset, int32_t qt_stride, int32_t qt_phase, int64_t capacity,
+                       int64_t* out_q, int64_t* out_j, float* out_s, uint64_t* out_count, void* stream);
+
 /* ---- k-means pieces: replace faiss `Kmeans(d, k, niter).train(x)` (lotus/utils.py:61-62); the assignment step and
  * the final `kmeans.index.search(x, 1)` (utils.py:65) are lvs_flat_search_keys with k = 1 and LVS_METRIC_L2. ---- */
 int64_t lvs_kmeans_accumulate_workspace_bytes(int64_t n, int32_t k);

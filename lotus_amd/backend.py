@@ -140,6 +140,26 @@ class HipBackend:
                                         corpus.n, self._stream()), "lvs_scores")
         return out
 
+    # ---- threshold join (sem_dedup) ----
+    def range_join(self, corpus: PackedRows, queries: PackedRows, threshold: float, metric: int = _capi.METRIC_IP,
+                   q_row0: int = -1, id_offset: int = 0, stride: int = 1, phase: int = 0, capacity: int = 1 << 22):
+        """All (query, corpus id, score) with score > threshold.  q_row0 >= 0: self-join, pairs with id > query row
+        only.  Returns three device tensors (int64, int64, float32); order unspecified."""
+        torch = self.torch
+        while True:
+            oq = torch.empty((capacity,), dtype=torch.int64, device=self.device)
+            oj = torch.empty((capacity,), dtype=torch.int64, device=self.device)
+            os_ = torch.empty((capacity,), dtype=torch.float32, device=self.device)
+            cnt = torch.zeros((1,), dtype=torch.int64, device=self.device)
+            _capi.check(self.lib.lvs_range_join(
+                _ptr(corpus.rows), corpus.mode, corpus.n, _ptr(queries.rows), queries.mode, queries.n, corpus.d, metric,
+                _ptr(corpus.norms), _ptr(queries.norms), float(threshold), int(q_row0), int(id_offset), int(stride),
+                int(phase), int(capacity), _ptr(oq), _ptr(oj), _ptr(os_), _ptr(cnt), self._stream()), "lvs_range_join")
+            n = int(cnt.item())
+            if n <= capacity:
+                return oq[:n], oj[:n], os_[:n]
+            capacity = n  # counted but not stored: size the buffers and run again
+
     # ---- k-means pieces ----
     def kmeans_accumulate(self, x: PackedRows, assign, k: int):
         """-> (sums float32 [k,d], counts float32 [k]) of the rows of x grouped by assign (int64 device tensor)."""

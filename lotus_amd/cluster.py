@@ -148,7 +148,14 @@ def cluster(col_name: str, ncentroids: int):
         ids = df.index.tolist()
         vec_set = vs.get_vectors_from_index(col_index_dir, ids)
         backend = getattr(vs, "backend", None)
-        res = kmeans(vec_set, ncentroids, niter=niter, backend=backend)
+        packed = None
+        if hasattr(vs, "packed_rows"):
+            try:
+                packed = vs.packed_rows(ids)  # reuse the resident device image instead of re-uploading vec_set
+            except ValueError:
+                packed = None
+        res = kmeans(vec_set, ncentroids, niter=niter, backend=backend, packed=packed,
+                     pack_mode=None if packed is None else packed.mode)
         if verbose:
             for it, o in enumerate(res.obj):
                 print(f"  Iteration {it} objective={o:.6g} splits={int(res.nsplit[it])}")

@@ -516,3 +516,54 @@ extern "C" int32_t lvs_scores(const void* xb, int32_t xb_pack, int64_t nb, const
     LVS_HIP_CHECK(lvs_tile_launch(LVS_MODE_SCORES, a, (hipStream_t)stream));
     return LVS_OK;
 }
+
+extern "C" int32_t lvs_range_join(const void* xb, int32_t xb_pack, int64_t nb, const void* xq, int32_t xq_pack, int64_t nq,
+                                  int32_t d, int32_t metric, const float* xb_norms_sq, const float* xq_norms_sq,
+                                  float threshold, int64_t q_row0, int64_t id_offset, int32_t qt_stride,
+                                  int32_t qt_phase, int64_t capacity, int64_t* out_q, int64_t* out_j, float* out_s,
+                                  uint64_t* out_count, void* stream) {
+    Plan p;
+    LVS_REQUIRE(make_plan(nq, nb, d, xb_pack, xq_pack, 1, p, false) == LVS_OK, "bad shape");
+    LVS_REQUIRE(metric == LVS_METRIC_IP || metric == LVS_METRIC_L2, "bad metric %d", metric);
+    LVS_REQUIRE(capacity >= 0 && out_count, "bad output buffers");
+    LVS_REQUIRE(qt_stride >= 1 && qt_phase >= 0 && qt_phase < qt_stride, "bad tile dealing %d/%d", qt_phase, qt_stride);
+    if (nq == 0 || nb == 0) return LVS_OK;
+    LVS_REQUIRE(xb && xq && (capacity == 0 || (out_q && out_j && out_s)), "NULL buffer");
+    LVS_REQUIRE(metric != LVS_METRIC_L2 || (xb_norms_sq && xq_norms_sq), "L2 needs both norm vectors");
+    LvsTileArgs a;
+    memset(&a, 0, sizeof(a));
+    a.xb = xb;
+    a.xq = xq;
+    a.bn = xb_norms_sq;
+    a.qn = xq_norms_sq;
+    a.nb = nb;
+    a.nq = nq;
+    a.ldb = p.ldb;
+    a.ldq = p.ldq;
+    a.nseg = p.nseg;
+    for (int i = 0; i < 3; ++i) {
+        a.seg_q[i] = p.seg_q[i];
+        a.seg_c[i] = p.seg_c[i];
+    }
+    a.id_offset = id_offset;
+    a.nkd = p.nkd;
+    a.nk = p.nk;
+    a.metric = metric;
+    a.k = 1;
+    a.ntiles = p.ntiles;
+    a.tiles_per_slab = p.tiles_per_slab;
+    a.nslab = p.nslab;
+    a.nqt = p.nqt;
+    a.gq = p.gq;
+    a.pair_q = (long long*)out_q;
+    a.pair_j = (long long*)out_j;
+    a.pair_s = out_s;
+    a.pair_count = (unsigned long long*)out_count;
+    a.pair_capacity = capacity;
+    a.q_row0 = q_row0;
+    a.threshold = threshold;
+    a.qt_stride = qt_stride;
+    a.qt_phase = qt_phase;
+    LVS_HIP_CHECK(lvs_tile_launch(LVS_MODE_RANGE, a, (hipStream_t)stream));
+    return LVS_OK;
+}

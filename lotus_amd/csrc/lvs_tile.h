@@ -16,6 +16,7 @@
 #define LVS_MODE_TOPK 0
 #define LVS_MODE_SCORES 1
 #define LVS_MODE_TOP1 2
+#define LVS_MODE_RANGE 3
 
 struct LvsTileArgs {
     const void* xb;           // [nb][ld] fp16 packed corpus shard
@@ -28,6 +29,15 @@ struct LvsTileArgs {
     uint32_t* gtau;           // [nq] shared running thresholds (ord32 of the k-th best score), zero-initialised
     u64* out;                 // [nslab][nq][k] per-slab candidate keys
     float* scores;            // LVS_MODE_SCORES: [nq][ld_scores]
+    // LVS_MODE_RANGE: emit (query, corpus row, score) for score > threshold
+    long long* pair_q;
+    long long* pair_j;
+    float* pair_s;
+    unsigned long long* pair_count;
+    long long pair_capacity;
+    long long q_row0;         // >= 0: self-join, query r is corpus row q_row0 + r and only pairs j > i are kept
+    float threshold;
+    int qt_stride, qt_phase;  // only query tiles with qt % qt_stride == qt_phase are processed (multi-GPU deal)
     long long ld_scores;
     long long nb, nq;
     long long ldb, ldq;       // leading dimensions in halfs (corpus / queries)

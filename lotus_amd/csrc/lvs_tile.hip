@@ -77,8 +77,15 @@ __global__ __launch_bounds__(LVS_TILE_THREADS, 2) void lvs_tile_kernel(const Lvs
     int qt, slab;
     if (!item_of_block(a, blockIdx.x, qt, slab)) return;
     const long long q0 = (long long)qt * LVS_BQ;
-    const int tile0 = slab * a.tiles_per_slab;
+    int tile0 = slab * a.tiles_per_slab;
     const int tile1 = min(a.ntiles, tile0 + a.tiles_per_slab);
+    if (MODE == LVS_MODE_RANGE) {
+        if (a.qt_stride > 1 && (qt % a.qt_stride) != a.qt_phase) return;
+        if (a.q_row0 >= 0) {  // self-join: tiles whose rows are all <= every query row of this tile hold no j > i
+            const long long first = (a.q_row0 + q0 - a.id_offset) / LVS_BC;
+            if (first > tile0) tile0 = (int)(first < tile1 ? first : tile1);
+        }
+    }
     if (tile0 >= tile1) return;
 
     u64* lists = (u64*)(smem + OFF_LIST);
@@ -235,6 +242,31 @@ __global__ __launch_bounds__(LVS_TILE_THREADS, 2) void lvs_tile_kernel(const Lvs
                             if (row + e < a.nb) orow[row + e] = acc[mi][ni][r4 * 4 + e];
                     }
                 }
+        } else if (MODE == LVS_MODE_RANGE) {
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) {
+                    const bool th = qvalid[ni] && (max16(acc[mi][ni]) > a.threshold);
+                    if (!__any(th)) continue;
+                    if (!th) continue;
+                    const long long qg = q0 + qloc[ni];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float s = acc[mi][ni][r];
+                        if (!(s > a.threshold)) continue;  // strict, as sem_dedup.py:46
+                        const long long row = trow0 + lrow_base + mi * 32 + (r & 3) + 8 * (r >> 2);
+                        if (row >= a.nb) continue;
+                        const long long jg = row + a.id_offset;
+                        if (a.q_row0 >= 0 && jg <= a.q_row0 + qg) continue;
+                        const unsigned long long pos = atomicAdd(a.pair_count, 1ull);
+                        if ((long long)pos < a.pair_capacity) {
+                            a.pair_q[pos] = qg;
+                            a.pair_j[pos] = jg;
+                            a.pair_s[pos] = s;
+                        }
+                    }
+                }
         } else if (MODE == LVS_MODE_TOPK) {
             // refresh the cross-workgroup threshold (any slab's k-th best is a valid lower bound for the final
             // k-th best; a stale value is only conservative)
@@ -347,6 +379,7 @@ __global__ __launch_bounds__(LVS_TILE_THREADS, 2) void lvs_tile_kernel(const Lvs
 
 template __global__ void lvs_tile_kernel<LVS_MODE_TOPK>(const LvsTileArgs);
 template __global__ void lvs_tile_kernel<LVS_MODE_SCORES>(const LvsTileArgs);
+template __global__ void lvs_tile_kernel<LVS_MODE_RANGE>(const LvsTileArgs);
 
 // ---- launch helpers (called from lvs_capi.hip) -------------------------------------------------------------
 int lvs_tile_grid_blocks(int nqt, int nslab, int gq) {
@@ -365,11 +398,16 @@ hipError_t lvs_tile_launch(int mode, const LvsTileArgs& a, hipStream_t stream) {
         e = hipFuncSetAttribute((const void*)lvs_tile_kernel<LVS_MODE_SCORES>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);
         if (e != hipSuccess) return e;
+        e = hipFuncSetAttribute((const void*)lvs_tile_kernel<LVS_MODE_RANGE>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);
+        if (e != hipSuccess) return e;
         attr_done = true;
     }
     dim3 grid(lvs_tile_grid_blocks(a.nqt, a.nslab, a.gq)), block(LVS_TILE_THREADS);
     if (mode == LVS_MODE_TOPK)
         hipLaunchKernelGGL(lvs_tile_kernel<LVS_MODE_TOPK>, grid, block, LDS_TOTAL, stream, a);
+    else if (mode == LVS_MODE_RANGE)
+        hipLaunchKernelGGL(lvs_tile_kernel<LVS_MODE_RANGE>, grid, block, LDS_TOTAL, stream, a);
     else
         hipLaunchKernelGGL(lvs_tile_kernel<LVS_MODE_SCORES>, grid, block, LDS_TOTAL, stream, a);
     return hipGetLastError();

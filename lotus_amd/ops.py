@@ -1,0 +1,118 @@
+"""Fast-path accessors: the reference operators' semantics without their Python hot loops.
+
+``sem_sim_join`` in the reference walks Q x K results in a Python double loop with set look-ups and builds a list of
+tuples (``lotus/sem_ops/sem_sim_join.py:132-145``), and ``sem_dedup`` materialises an N x N join
+(``sem_dedup.py:45``).  These functions produce the same frames from the same inputs with vectorised post-processing,
+and work with any ``VS`` that returns ndarrays (they are plain functions: ``sem_sim_join(df1, df2, ...)``)."""
+from __future__ import annotations
+
+import numpy as np
+import pandas as pd
+
+from . import dedup as _dedup
+
+
+def _settings(rm, vs):
+    if rm is None or vs is None:
+        try:
+            import lotus
+
+            rm = rm if rm is not None else lotus.settings.rm
+            vs = vs if vs is not None else lotus.settings.vs
+        except Exception:
+            pass
+    if vs is None:
+        raise ValueError("a vector store is required: pass vs= or configure lotus.settings")
+    return rm, vs
+
+
+def sem_index(df: pd.DataFrame, col_name: str, index_dir: str, rm=None, vs=None, embeddings=None) -> pd.DataFrame:
+    """``df.sem_index`` (``sem_index.py:61-77``): embed the column (or take ``embeddings``), index it, remember the dir."""
+    rm, vs = _settings(rm, vs)
+    if embeddings is None:
+        if rm is None:
+            raise ValueError("a retrieval model (rm) or precomputed embeddings are required")
+        embeddings = rm(df[col_name].tolist())
+    vs.index(df[col_name], embeddings, index_dir)
+    df.attrs.setdefault("index_dirs", {})[col_name] = index_dir
+    return df
+
+
+def sem_search(df: pd.DataFrame, col_name: str, query, K: int, rm=None, vs=None, return_scores: bool = False,
+               suffix: str = "_sim_score") -> pd.DataFrame:
+    """``df.sem_search`` without the K-doubling loop (``sem_search.py:116-144``): rows that are no longer in ``df``
+    are excluded up front by passing their positions as ``ids``, so one search suffices."""
+    rm, vs = _settings(rm, vs)
+    col_index_dir = df.attrs["index_dirs"][col_name]
+    if vs.index_dir != col_index_dir:
+        vs.load_index(col_index_dir)
+    K = min(int(K), len(df))
+    qv = query if isinstance(query, np.ndarray) else rm.convert_query_to_query_vector(query)
+    out = vs(qv, K, ids=df.index.tolist())
+    idx = np.asarray(out.indices)[0]
+    sc = np.asarray(out.distances)[0]
+    ok = idx >= 0
+    new_df = df.loc[idx[ok]]
+    new_df.attrs["index_dirs"] = df.attrs.get("index_dirs", None)
+    if return_scores:
+        new_df["vec_scores" + suffix] = sc[ok]
+    return new_df
+
+
+def sem_sim_join(df1: pd.DataFrame, df2: pd.DataFrame, left_on: str, right_on: str, K: int, rm=None, vs=None,
+                 lsuffix: str = "", rsuffix: str = "", score_suffix: str = "", keep_index: bool = False) -> pd.DataFrame:
+    """``df1.sem_sim_join(df2, ...)`` (``sem_sim_join.py:84-166``) with the post-filter and the result frame built from
+    arrays.  Same columns, same row order (left rows in order, best match first), same ``_scores`` dtype."""
+    rm, vs = _settings(rm, vs)
+    if isinstance(df2, pd.Series):
+        if df2.name is None:
+            raise ValueError("Other Series must have a name")
+        df2 = pd.DataFrame({df2.name: df2})
+    if left_on in df1.attrs.get("index_dirs", []):
+        qdir = df1.attrs["index_dirs"][left_on]
+        if vs.index_dir != qdir:
+            vs.load_index(qdir)
+        try:
+            queries = vs.get_vectors_from_index(qdir, df1.index)
+        except NotImplementedError:
+            queries = df1[left_on]
+    else:
+        queries = df1[left_on]
+    try:
+        col_index_dir = df2.attrs["index_dirs"][right_on]
+    except KeyError:
+        raise ValueError(f"Index directory for column {right_on} not found in DataFrame")
+    if vs.index_dir != col_index_dir:
+        vs.load_index(col_index_dir)
+    qv = queries if isinstance(queries, np.ndarray) else rm.convert_query_to_query_vector(queries)
+    right_index = np.asarray(df2.index)
+    out = vs(qv, K, ids=right_index.tolist())
+    I = np.asarray(out.indices)
+    D = np.asarray(out.distances)
+    ok = I >= 0  # ids come from df2.index, so every non-padded hit is a right row
+    qpos = np.broadcast_to(np.arange(I.shape[0])[:, None], I.shape)[ok]
+    right_ids = I[ok]
+    left_ids = np.asarray(df1.index)[qpos]
+    d1 = df1.copy()
+    d2 = df2.copy()
+    d1["_left_id"] = d1.index
+    d2["_right_id"] = d2.index
+    temp = pd.DataFrame({"_left_id": left_ids, "_right_id": right_ids, "_scores" + score_suffix: D[ok]})
+    joined = d1.join(temp.set_index("_left_id"), how="right", on="_left_id").join(
+        d2.set_index("_right_id"), how="left", on="_right_id", lsuffix=lsuffix, rsuffix=rsuffix)
+    if not keep_index:
+        joined.drop(columns=["_left_id", "_right_id"], inplace=True)
+    return joined
+
+
+def sem_dedup(df: pd.DataFrame, col_name: str, threshold: float, rm=None, vs=None, shard: bool = False) -> pd.DataFrame:
+    """``df.sem_dedup`` (``sem_dedup.py:32-91``) through the GPU threshold self-join: O(pairs) memory instead of
+    O(N^2).  Survivor of each duplicate group = its first value in frame order."""
+    rm, vs = _settings(rm, vs)
+    col_index_dir = df.attrs["index_dirs"][col_name]
+    if vs.index_dir != col_index_dir:
+        vs.load_index(col_index_dir)
+    packed = vs.packed_rows(df.index)
+    i, j, _ = _dedup.threshold_pairs(vs.backend, packed, threshold, vs.metric, shard=shard)
+    mask = _dedup.keep_mask(df[col_name].tolist(), i, j)
+    return df[mask]

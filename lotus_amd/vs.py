@@ -225,6 +225,22 @@ class HipVS(VS):
         I[:, :k_eff] = Id.cpu().numpy()
         return RMOutput(distances=D, indices=I)
 
+    def packed_rows(self, ids=None):
+        """Device image (backend ``PackedRows``) of the current index restricted to positional ``ids`` (all rows
+        when ``ids`` is None or covers them in order) - what the GPU-side operators (dedup, k-means) consume.
+        Needs the whole index on this rank (``shard=False``)."""
+        ent = self._current()
+        if ent.lo != 0 or ent.hi != ent.n:
+            raise ValueError("packed_rows needs an unsharded index")
+        if ids is None:
+            return ent.packed
+        sub = np.asarray(ids, dtype=np.int64).reshape(-1)
+        if sub.size == ent.n and np.array_equal(sub, np.arange(ent.n)):
+            return ent.packed
+        if sub.size and (sub.min() < 0 or sub.max() >= ent.n):
+            raise IndexError("ids out of range for the loaded index")
+        return self.backend.gather(ent.packed, self.backend.to_device(sub))
+
     # ------------------------------------------------------------------------------------------ multi-GPU
     def _allgather_merge(self, keys, world: int):
         """All-gather the per-shard candidate keys [Q,k] (8 B each) and merge them on every rank."""

@@ -85,6 +85,21 @@ class OracleBackend:
         D, I = _finish(k, metric, None if id_map is None else id_map.numpy())
         return torch.from_numpy(D), torch.from_numpy(I)
 
+    # ---- threshold join ----
+    def range_join(self, corpus, queries, threshold, metric=0, q_row0=-1, id_offset=0, stride=1, phase=0,
+                   capacity=1 << 22):
+        xb, xq = corpus.rows.numpy(), queries.rows.numpy()
+        s = xq @ xb.T
+        if metric == 1:
+            s = -np.maximum((queries.norms.numpy()[:, None] + corpus.norms.numpy()[None, :]) - 2 * s, 0)
+        q, j = np.nonzero(s > np.float32(threshold))
+        keep = ((q // 128) % stride) == phase
+        if q_row0 >= 0:
+            keep &= (j + id_offset) > (q + q_row0)
+        q, j = q[keep], j[keep]
+        return (torch.from_numpy(q.astype(np.int64)), torch.from_numpy((j + id_offset).astype(np.int64)),
+                torch.from_numpy(s[q, j].astype(np.float32)))
+
     # ---- k-means pieces ----
     def kmeans_accumulate(self, x, assign, k):
         vals = x.rows.numpy()

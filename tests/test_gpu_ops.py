@@ -1,0 +1,128 @@
+"""End-to-end on the real HIP path: HipVS + lotus_amd.ops / dedup / cluster against (i) golden frames produced by the
+REFERENCE accessors (tests/golden/make_golden_frames.py) and (ii) the oracle's threshold join."""
+import json
+import os
+
+import numpy as np
+import pandas as pd
+import pytest
+
+import fake_rm
+import oracle
+import synth
+from lotus_amd import RM, HipVS, _capi, ops
+from lotus_amd.dedup import keep_mask, threshold_pairs
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope="module")
+def gold():
+    with open(os.path.join(HERE, "golden", "frames_scenarios.json")) as f:
+        return json.load(f)
+
+
+def frame(d):
+    df = pd.DataFrame(d["data"], columns=d["columns"])
+    return df.set_index(d["columns"][0]).rename_axis(None)
+
+
+def check(ref, got, score_cols):
+    got = got.copy()
+    assert ref.index.tolist() == got.index.tolist()
+    assert ref.columns.tolist() == got.columns.tolist()
+    for c in ref.columns:
+        if c in score_cols:
+            assert np.allclose(ref[c].astype(float), got[c].astype(float), atol=1e-5), c
+        else:
+            assert ref[c].tolist() == got[c].tolist(), c
+
+
+def test_ops_match_reference_frames(hip_backend, gold, tmp_path):
+    inp = gold["inputs"]
+    rm = fake_rm.make_rm(RM)
+    vs = HipVS(backend=hip_backend)
+    df1 = pd.DataFrame({"L": inp["left"]})
+    df2 = ops.sem_index(pd.DataFrame({"R": inp["right"], "keep": np.arange(400) % 5 != 2}), "R", str(tmp_path / "r"),
+                        rm=rm, vs=vs)
+    check(frame(gold["join_full_k3"]), ops.sem_sim_join(df1, df2, "L", "R", 3, rm=rm, vs=vs), {"_scores"})
+    check(frame(gold["join_filtered_k4"]),
+          ops.sem_sim_join(df1, df2[df2["keep"]], "L", "R", 4, rm=rm, vs=vs, keep_index=True, score_suffix="_s"),
+          {"_scores_s"})
+    check(frame(gold["search_k5"]),
+          ops.sem_search(df2, "R", "optimization geometry cooking", 5, rm=rm, vs=vs, return_scores=True),
+          {"vec_scores_sim_score"})
+    check(frame(gold["search_filtered_k3"]),
+          ops.sem_search(df2[df2["keep"]], "R", "harry potter history", 3, rm=rm, vs=vs, return_scores=True),
+          {"vec_scores_sim_score"})
+    dd = ops.sem_index(pd.DataFrame({"Text": inp["dedup"]}), "Text", str(tmp_path / "d"), rm=rm, vs=vs)
+    assert len(ops.sem_dedup(dd, "Text", 0.9, vs=vs)) == gold["dedup_kept_count"]
+    from lotus_amd.cluster import kmeans
+
+    r = kmeans(fake_rm.embed(inp["dedup"]), 4, niter=8, backend=hip_backend)
+    assert (r.assign == np.array(gold["cluster_ids"])).mean() >= 0.99
+
+
+def test_range_join_matches_oracle_and_golden(hip_backend):
+    z = np.load(os.path.join(HERE, "golden", "dedup_pairs.npz"))
+    be = hip_backend
+    packed = be.pack(z["x"], _capi.PACK_F16)
+    i, j, s = threshold_pairs(be, packed, float(z["thr"]))
+    up = z["pi"] < z["pj"]
+    assert np.array_equal(i, z["pi"][up]) and np.array_equal(j, z["pj"][up])
+    assert np.allclose(s, z["ps"][up], atol=1e-5)
+    # larger random case incl. many tiles below the diagonal, both storage layouts, capacity regrowth
+    x = synth.corpus(3000, 96, seed=5)
+    x[1000:1400] = x[:400] + 0.05 * synth.corpus(400, 96, seed=6)
+    x /= np.linalg.norm(x, axis=1, keepdims=True)
+    for mode in (_capi.PACK_F16, _capi.PACK_SPLIT):
+        xs = x.astype(np.float16).astype(np.float32) if mode == _capi.PACK_F16 else x
+        pk = be.pack(x.astype(np.float16) if mode == _capi.PACK_F16 else x, mode)
+        q, jj, ss = be.range_join(pk, pk, 0.9, q_row0=0, capacity=16)  # forces the count-then-rerun path
+        got = set(zip(q.cpu().numpy().tolist(), jj.cpu().numpy().tolist()))
+        sc = xs @ xs.T
+        sure = {(a, b) for a, b in zip(*np.nonzero(sc > 0.9 + 2e-5)) if a < b}
+        maybe = {(a, b) for a, b in zip(*np.nonzero(sc > 0.9 - 2e-5)) if a < b}
+        assert sure <= got <= maybe and len(got) >= 400
+    # non-self join and tile dealing: the union over phases equals the undealt result
+    qx = be.pack(x[:700].astype(np.float16), _capi.PACK_F16)
+    pk = be.pack(x.astype(np.float16), _capi.PACK_F16)
+    full = be.range_join(pk, qx, 0.9)
+    parts = [be.range_join(pk, qx, 0.9, stride=3, phase=p) for p in range(3)]
+    tot = sum(len(p[0]) for p in parts)
+    assert tot == len(full[0]) and tot >= 400
+    u = set()
+    for p in parts:
+        u |= set(zip(p[0].cpu().numpy().tolist(), p[1].cpu().numpy().tolist()))
+    assert u == set(zip(full[0].cpu().numpy().tolist(), full[1].cpu().numpy().tolist()))
+
+
+def test_dedup_at_scale_finds_planted_duplicate_chains(hip_backend):
+    """200k rows: 10k planted near-duplicates (cos ~ 0.98) incl. dup-of-dup chains + hard negatives (cos ~ 0.89)."""
+    import torch
+
+    be = hip_backend
+    n0, d = 180_000, 768
+    g = torch.Generator(device=be.device)
+    g.manual_seed(9)
+    base = torch.nn.functional.normalize(torch.randn((n0, d), generator=g, device=be.device), dim=1)
+
+    def noisy(src, amp):
+        return torch.nn.functional.normalize(
+            src + amp * torch.nn.functional.normalize(torch.randn(src.shape, generator=g, device=be.device), dim=1), dim=1)
+
+    dup1 = noisy(base[:10_000], 0.2)
+    dup2 = noisy(dup1[:5_000], 0.2)      # chain: base -> dup1 -> dup2
+    neg = noisy(base[10_000:15_000], 0.5)
+    x = torch.cat([base, dup1, dup2, neg]).to(torch.float16)
+    packed = be.pack(x, _capi.PACK_F16)
+    i, j, s = threshold_pairs(be, packed, 0.95)
+    assert (s > 0.95).all() and (i < j).all()
+    pairs = set(zip(i.tolist(), j.tolist()))
+    assert all((r, n0 + r) in pairs for r in range(0, 10_000, 97))          # base ~ dup1
+    assert all((n0 + r, n0 + 10_000 + r) in pairs for r in range(0, 5_000, 97))  # dup1 ~ dup2
+    assert not any(a >= n0 + 15_000 or b >= n0 + 15_000 for a, b in pairs)  # hard negatives stay out
+    vals = [f"row{r}" for r in range(len(x))]
+    keep = keep_mask(vals, i, j)
+    assert int((~keep).sum()) == 15_000 and keep[:n0].all()  # every chain collapses onto its base row

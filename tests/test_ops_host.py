@@ -1,0 +1,120 @@
+"""Fast-path accessors (lotus_amd.ops) against the reference's own accessors on identical inputs, and the dedup graph
+rule against the oracle restatement.  CPU only (oracle-backed test double); also writes nothing - the golden frames
+used on the GPU box are produced by tests/golden/make_golden_frames.py from the same scenarios."""
+import numpy as np
+import pandas as pd
+import pytest
+
+import oracle
+import ref_harness
+import synth
+from oracle_backend import OracleBackend
+
+
+def test_keep_mask_equals_oracle_rule_on_random_graphs():
+    from lotus_amd.dedup import component_labels, keep_mask
+
+    rng = np.random.default_rng(0)
+    for trial in range(20):
+        n = int(rng.integers(5, 60))
+        vals = [f"v{int(v)}" for v in rng.integers(0, max(2, n // 2), n)]  # repeated values on purpose
+        m = int(rng.integers(0, 2 * n))
+        i = rng.integers(0, n, m)
+        j = rng.integers(0, n, m)
+        ok = i < j
+        i, j = i[ok], j[ok]
+        # oracle rule, fed with the same pairs
+        first = {}
+        node = np.array([first.setdefault(v, r) for r, v in enumerate(vals)])
+        a, b = node[i], node[j]
+        d = a != b
+        lab = oracle.dedup_components(n, a[d], b[d])
+        in_pair = np.zeros(n, bool)
+        in_pair[a[d]] = True
+        in_pair[b[d]] = True
+        expect = ~(in_pair & (lab != np.arange(n)))[node]
+        assert np.array_equal(keep_mask(vals, i, j), expect)
+        assert np.array_equal(component_labels(n, a[d], b[d]), lab)
+
+
+def test_threshold_pairs_equals_oracle_range_join():
+    from lotus_amd.dedup import threshold_pairs
+
+    z = np.load(__import__("os").path.join(__import__("os").path.dirname(__file__), "golden", "dedup_pairs.npz"))
+    be = OracleBackend()
+    packed = be.pack(z["x"], 0)
+    i, j, s = threshold_pairs(be, packed, float(z["thr"]))
+    up = z["pi"] < z["pj"]
+    assert np.array_equal(i, z["pi"][up]) and np.array_equal(j, z["pj"][up])
+
+
+@pytest.mark.skipif(not ref_harness.available(), reason="reference checkout not present")
+def test_fast_path_ops_equal_reference_accessors(tmp_path):
+    lotus = ref_harness.import_lotus()
+    from lotus.models.rm import RM
+
+    import fake_rm
+    from lotus_amd import HipVS, ops
+
+    words = sum(fake_rm.TOPICS.values(), [])
+    rng = np.random.default_rng(4)
+    left = [" ".join(rng.choice(words, 3)) for _ in range(60)]
+    right = [" ".join(rng.choice(words, 2)) for _ in range(200)]
+    rm = fake_rm.make_rm(RM)
+    vs = HipVS(backend=OracleBackend())
+    lotus.settings.configure(rm=rm, vs=vs)
+
+    df1 = pd.DataFrame({"L": left, "n": np.arange(60)})
+    df2 = pd.DataFrame({"R": right, "keep": np.arange(200) % 4 != 1}).sem_index("R", str(tmp_path / "r"))
+    df2f = df2[df2["keep"]]
+    for other, kw in ((df2, dict(K=3)), (df2f, dict(K=5, score_suffix="_s", keep_index=True)),
+                      (df2f, dict(K=2, lsuffix="_a", rsuffix="_b"))):
+        ref = df1.sem_sim_join(other, left_on="L", right_on="R", **kw)
+        got = ops.sem_sim_join(df1, other, "L", "R", **kw)
+        pd.testing.assert_frame_equal(ref, got)
+
+    idx1 = pd.DataFrame({"L": left}).sem_index("L", str(tmp_path / "l"))  # indexed left column
+    ref = idx1.sem_sim_join(df2, left_on="L", right_on="R", K=2)
+    got = ops.sem_sim_join(idx1, df2, "L", "R", 2)
+    pd.testing.assert_frame_equal(ref, got)
+
+    for frame, K in ((df2, 4), (df2f, 3), (df2f[df2f.index > 150], 500)):
+        ref = frame.sem_search("R", "probability cooking", K=K, return_scores=True)
+        got = ops.sem_search(frame, "R", "probability cooking", K, return_scores=True)
+        pd.testing.assert_frame_equal(ref, got, check_dtype=False)
+
+    # dedup: the reference keeps a hash-order-dependent survivor; compare what is well defined
+    texts = ["Probability and Random Processes", "Probability and Markov Chains", "Harry Potter", "Harry James Potter",
+             "Cooking", "Cooking", "Riemannian Geometry"]
+    dd = pd.DataFrame({"Text": texts}).sem_index("Text", str(tmp_path / "d"))
+    ref = dd.sem_dedup("Text", threshold=0.85)
+    got = ops.sem_dedup(dd, "Text", 0.85)
+    assert len(ref) == len(got) == 5
+    assert sorted(t.split()[0] for t in got["Text"]) == sorted(t.split()[0] for t in ref["Text"])
+    assert got["Text"].tolist() == ["Probability and Random Processes", "Harry Potter", "Cooking", "Cooking",
+                                    "Riemannian Geometry"]  # first value of every group survives, equal values stay
+    sub = dd[dd.index != 0]  # filtered frame: positions are remapped through the gather
+    assert ops.sem_dedup(sub, "Text", 0.85)["Text"].tolist() == ["Probability and Markov Chains", "Harry Potter",
+                                                                  "Cooking", "Cooking", "Riemannian Geometry"]
+
+
+def test_ops_work_without_lotus_settings(tmp_path):
+    """Standalone use (what runs on the GPU box, where LOTUS is absent): explicit vs= and precomputed embeddings."""
+    from lotus_amd import HipVS, ops
+
+    xb = synth.corpus(300, 32, seed=3)
+    xq, planted = synth.queries(xb, 20, seed=4)
+    vs = HipVS(backend=OracleBackend())
+    right = ops.sem_index(pd.DataFrame({"R": [f"r{i}" for i in range(300)]}), "R", str(tmp_path / "r"), vs=vs,
+                          embeddings=xb)
+    left = pd.DataFrame({"L": [f"l{i}" for i in range(20)]})
+
+    class PassThroughRM:
+        def convert_query_to_query_vector(self, q):
+            return xq
+
+    out = ops.sem_sim_join(left, right, "L", "R", 2, rm=PassThroughRM(), vs=vs)
+    assert out["R"].iloc[::2].tolist() == [f"r{j}" for j in planted]
+    assert out["_scores"].dtype == np.float32 and len(out) == 40
+    hit = ops.sem_search(right, "R", xq[:1], 3, vs=vs, return_scores=True)
+    assert hit["R"].iloc[0] == f"r{planted[0]}"
