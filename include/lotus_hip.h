@@ -97,6 +97,12 @@ int32_t lvs_keys_to_result(const uint64_t* keys, int64_t nq, int32_t k, int32_t 
 int32_t lvs_scores(const void* xb, int32_t xb_pack, int64_t nb, const void* xq, int32_t xq_pack, int64_t nq, int32_t d,
                    int32_t metric, const float* xb_norms_sq, const float* xq_norms_sq, float* out, int64_t ld_out,
                    void* stream);
+/* Rank every score row best-first: scores [nq][ld] (from lvs_scores) -> out_keys [nq][nb], ids = id_offset + column.
+ * nq * nb must stay below 2^32.  Serves K = N callers beyond LVS_MAX_K. */
+int64_t lvs_sort_rows_workspace_bytes(int64_t nq, int64_t nb);
+int32_t lvs_sort_rows_desc(const float* scores, int64_t nq, int64_t nb, int64_t ld, int64_t id_offset,
+                           uint64_t* out_keys, void* workspace, int64_t workspace_bytes, void* stream);
+
 /* ---- threshold join: replaces `sem_sim_join(self, K = len(df))` + `_scores > threshold` (sem_dedup.py:45-46), which
  * materialises N^2 results in the reference.  Emits (query, corpus row id, score) for every score STRICTLY greater
  * than `threshold` (for L2 the score is minus the squared distance).  q_row0 >= 0 selects the self-join: query r is

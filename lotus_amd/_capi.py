@@ -36,6 +36,8 @@ SIGNATURES = {
     "lvs_merge_keys": (_i32, [_vp, _i32, _i64, _i32, _vp, _vp]),
     "lvs_keys_to_result": (_i32, [_vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp]),
     "lvs_scores": (_i32, [_vp, _i32, _i64, _vp, _i32, _i64, _i32, _i32, _vp, _vp, _vp, _i64, _vp]),
+    "lvs_sort_rows_workspace_bytes": (_i64, [_i64, _i64]),
+    "lvs_sort_rows_desc": (_i32, [_vp, _i64, _i64, _i64, _i64, _vp, _vp, _i64, _vp]),
     "lvs_range_join": (_i32, [_vp, _i32, _i64, _vp, _i32, _i64, _i32, _i32, _vp, _vp, ctypes.c_float, _i64, _i64, _i32,
                               _i32, _i64, _vp, _vp, _vp, _vp, _vp]),
     "lvs_kmeans_accumulate_workspace_bytes": (_i64, [_i64, _i32]),

@@ -140,6 +140,19 @@ class HipBackend:
                                         corpus.n, self._stream()), "lvs_scores")
         return out
 
+    def rank_all(self, corpus: PackedRows, queries: PackedRows, metric: int, id_offset: int = 0):
+        """Every corpus row ranked for every query (K = N callers): int64 key tensor [nq, nb], best first."""
+        torch = self.torch
+        if queries.n * corpus.n >= 2**32 - 1:
+            raise ValueError("K = N ranking is limited to nq * nb < 2^32 scores")
+        sc = self.scores(corpus, queries, metric)
+        keys = torch.empty((queries.n, corpus.n), dtype=torch.int64, device=self.device)
+        need = int(self.lib.lvs_sort_rows_workspace_bytes(queries.n, corpus.n))
+        ws = self._workspace(need)
+        _capi.check(self.lib.lvs_sort_rows_desc(_ptr(sc), queries.n, corpus.n, corpus.n, int(id_offset), _ptr(keys),
+                                                _ptr(ws), int(ws.numel()), self._stream()), "lvs_sort_rows_desc")
+        return keys
+
     # ---- threshold join (sem_dedup) ----
     def range_join(self, corpus: PackedRows, queries: PackedRows, threshold: float, metric: int = _capi.METRIC_IP,
                    q_row0: int = -1, id_offset: int = 0, stride: int = 1, phase: int = 0, capacity: int = 1 << 22):

@@ -202,13 +202,21 @@ class HipVS(VS):
         I = np.full((nq, K), -1, np.int64)
         if k_eff == 0:
             return RMOutput(distances=D, indices=I)
-        if k_eff > _capi.MAX_K:
-            raise ValueError(f"K={K} over {n_eff} rows exceeds the supported maximum of {_capi.MAX_K} results per query")
+        rank_all = k_eff > _capi.MAX_K  # K = N callers (sem_dedup.py:45, sem_filter.py:491-497): full score rows + sort
+        rank, world = self._dist()
+        if rank_all and (world > 1 or nq * n_eff >= 2**32 - 1):
+            raise ValueError(f"K={K} over {n_eff} rows: more than {_capi.MAX_K} results per query are only supported "
+                             "on an unsharded index with nq * rows < 2^32")
 
         queries = be.pack(q, ent.packed.mode)
-        rank, world = self._dist()
         id_map = None
-        if sub is None:
+        if rank_all:
+            corpus = ent.packed
+            if sub is not None:
+                corpus = be.gather(ent.packed, be.to_device(sub))
+                id_map = be.to_device(sub)
+            keys = be.rank_all(corpus, queries, self.metric)[:, :k_eff].contiguous()
+        elif sub is None:
             keys = be.search_keys(ent.packed, queries, k_eff, self.metric, id_offset=ent.lo)
         else:
             # positions (in `ids`) of the subset rows that live in this rank's shard

@@ -85,6 +85,9 @@ class OracleBackend:
         D, I = _finish(k, metric, None if id_map is None else id_map.numpy())
         return torch.from_numpy(D), torch.from_numpy(I)
 
+    def rank_all(self, corpus, queries, metric, id_offset=0):
+        return self.search_keys(corpus, queries, corpus.n, metric, id_offset=id_offset)
+
     # ---- threshold join ----
     def range_join(self, corpus, queries, threshold, metric=0, q_row0=-1, id_offset=0, stride=1, phase=0,
                    capacity=1 << 22):

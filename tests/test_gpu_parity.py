@@ -177,6 +177,25 @@ def test_pack_rows_values_and_norms(hip_backend):
     assert np.abs(nrm - 1).max() < 2e-3
 
 
+def test_rank_all_rows_for_k_equal_n(hip_backend, tmp_path):
+    """K = N beyond LVS_MAX_K through HipVS: full score rows + segmented sort."""
+    from lotus_amd import HipVS
+
+    xb = synth.corpus(3000, 96, seed=2).astype(np.float16)
+    xq, _ = synth.queries(xb.astype(np.float32), 37, seed=3)
+    xq = xq.astype(np.float16)
+    vs = HipVS(backend=hip_backend)
+    vs.index(None, xb, str(tmp_path / "i"))
+    out = vs(xq, 3000)
+    Dr, Ir = oracle.flat_search(xb.astype(np.float32), xq.astype(np.float32), 3000)
+    err, hard, recall = synth.compare_topk(Dr, Ir, out.distances, out.indices)
+    assert err <= 1e-5 and hard == 0 and recall == 1.0
+    assert (np.sort(out.indices, axis=1) == np.arange(3000)).all()
+    ids = np.arange(3000)[::-1][:2500].copy()
+    out = vs(xq[:5], 2500, ids=ids.tolist())
+    assert set(out.indices[0].tolist()) == set(ids.tolist())
+
+
 def test_merge_keys(hip_backend):
     be = hip_backend
     rng = np.random.default_rng(5)

@@ -164,6 +164,14 @@ def test_storage_modes_select_the_pack_layout(tmp_path):
         assert vs.backend.calls[0] == ("pack", (30, 16), mode)
 
 
-def test_large_k_limit(indexed):
+def test_k_equal_n_and_beyond_max_k(indexed, tmp_path):
     vs, xb, _ = indexed
     assert vs(xb[:1], 400).indices.shape == (1, 400)  # K = N callers (sem_dedup.py:45) at small N
+    big = synth.corpus(2600, 8, seed=2)  # more rows than LVS_MAX_K: full ranking path
+    v2 = make_vs()
+    v2.index(None, big, str(tmp_path / "big"))
+    out = v2(big[:3], 2600)
+    D, I = oracle.flat_search(_emulate_storage(big, 1), _emulate_storage(big[:3], 1), 2600)
+    assert np.array_equal(out.indices, I) and any(c[0] == "search" and c[3] == 2600 for c in v2.backend.calls)
+    sub = list(range(0, 2600, 1))[5:]
+    assert v2(big[:2], 2595, ids=sub).indices.shape == (2, 2595)
