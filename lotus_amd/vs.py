@@ -249,6 +249,20 @@ class HipVS(VS):
             raise IndexError("ids out of range for the loaded index")
         return self.backend.gather(ent.packed, self.backend.to_device(sub))
 
+    def kmeans(self, vec_set, ncentroids: int, niter: int = 20, ids=None, **kw):
+        """faiss-parity k-means of the current index's rows ``ids`` (``lotus/utils.py:61-65``) on the GPU that already
+        holds them; returns the cluster id of every row."""
+        from .cluster import kmeans as _kmeans
+
+        packed = None
+        try:
+            packed = self.packed_rows(ids)
+        except ValueError:
+            pass
+        res = _kmeans(vec_set, ncentroids, niter=niter, backend=self.backend, packed=packed,
+                      pack_mode=None if packed is None else packed.mode, **kw)
+        return res.assign
+
     # ------------------------------------------------------------------------------------------ multi-GPU
     def _allgather_merge(self, keys, world: int):
         """All-gather the per-shard candidate keys [Q,k] (8 B each) and merge them on every rank."""
