@@ -319,20 +319,34 @@ int make_plan(int64_t nq, int64_t nb, int32_t d, int32_t xb_pack, int32_t xq_pac
         if (atoi(e) == 1) p.v2 = 0;
     }
     p.nqt = (int)lvs_ceil_div(nq > 0 ? nq : 1, p.v2 ? LVS2_BQ : LVS_BQ);
-    // enough (query tile, slab) items to load-balance 256 CUs (~32 items per CU), slabs kept >= 8 tiles
-    int64_t want = lvs_ceil_div(8192, p.nqt);
-    int64_t max_slabs = lvs_ceil_div(p.ntiles, 8);
+    // XCD group = gq query tiles x (32 / gq) slabs resident on one XCD at a time.  Wide groups (one corpus stream per
+    // XCD) are fastest (profiles/r01_tuning.md) but must be full: groups are dealt round-robin to the 8 XCDs, so a
+    // half-empty group idles half an XCD.  Take the widest gq that wastes < 15 % of its query-tile slots.
+    p.gq = 1;
+    const int gq_max = p.v2 ? 32 : 8;
+    for (int g = gq_max; g >= 1; g >>= 1) {
+        const double fill = (double)p.nqt / (double)(lvs_ceil_div(p.nqt, g) * g);
+        if (fill >= 0.85) {
+            p.gq = g;
+            break;
+        }
+    }
+    if (const char* e = getenv("LVS_GQ")) {
+        int v = atoi(e);
+        if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16 || v == 32) p.gq = v;
+    }
+    const int gs = 32 / p.gq;
+    // enough (query tile, slab) items to load-balance 256 CUs, slabs kept >= 32 tiles, a multiple of gs slabs
+    int64_t want = lvs_ceil_div(4096, p.nqt);
+    int64_t max_slabs = lvs_ceil_div(p.ntiles, 32);
     int64_t s = want < 1 ? 1 : want;
     if (s > max_slabs) s = max_slabs;
+    s = lvs_round_up(s, gs);
+    if (s > p.ntiles) s = p.ntiles;
     if (s < 1) s = 1;
     if (const char* e = getenv("LVS_NSLAB")) {  // tuning override
         int64_t v = atoll(e);
         if (v >= 1 && v <= p.ntiles) s = v;
-    }
-    p.gq = p.v2 ? 32 : 8;  // measured on MI355X at 100k x 1M (profiles/r01_tuning.md)
-    if (const char* e = getenv("LVS_GQ")) {
-        int v = atoi(e);
-        if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16 || v == 32) p.gq = v;
     }
     p.tiles_per_slab = (int)lvs_ceil_div(p.ntiles, s);
     p.nslab = (int)lvs_ceil_div(p.ntiles, p.tiles_per_slab);

@@ -10,7 +10,7 @@
 #define LVS_TILE_THREADS 512
 #define LVS_TILE_LDS_BYTES (2 * (LVS_BC + LVS_BQ) * LVS_BK * 2 + LVS_BQ * LVS_LCAP * 8 + LVS_BQ * 8 + LVS_BQ * 4 + 16)
 
-#define LVS2_KCAP 12        // largest k of the 256x256 kernel (lvs_tile2.hip)
+#define LVS2_KCAP 15        // largest k of the 256x256 kernel (lvs_tile2.hip)
 #define LVS2_BQ 256
 
 #define LVS_MODE_TOPK 0

@@ -5,10 +5,10 @@
 //   score tile   256 corpus rows (MFMA M) x 256 queries (MFMA N): 128 flop per byte staged from L2 (v1: 85)
 //   wave layout  2 (corpus) x 4 (queries); each wave 128 x 64 = 4 x 2 accumulators of v_mfma_f32_32x32x16_f16
 //                (128 accumulator VGPRs), 32 MFMAs per wave between barriers
-//   LDS          2 x 512 rows x 128 B staging = 128 KB, which leaves 32 KB for candidates; so instead of fixed
-//                slots per query the workgroup keeps one sorted k-list per query (256 x KCAP x 8 B) and a shared
-//                append pool (768 keys + owners).  A full pool is drained into the lists (each wave owns 32
-//                queries and scans the pool), which is also when thresholds tighten.
+//   LDS          2 x 512 rows x 128 B staging = 128 KB, which leaves 32 KB for candidates: one sorted k-list per
+//                query (256 x KCAP x 8 B) plus a lock word per query.  A score that beats its query's current k-th
+//                best is inserted at once under the query's LDS spin lock (hits are rare: ~k ln(N/k) per query per
+//                pass), so thresholds tighten immediately and the epilogue needs no workgroup barrier.
 #include "lvs_common.h"
 #include "lvs_tile.h"
 
@@ -18,12 +18,9 @@ constexpr int BC = 256, BQ = 256, BK = 64;
 constexpr int ROWB = BK * 2;
 constexpr int STAGE_BYTES = (BC + BQ) * ROWB;  // 65536
 constexpr int KCAP = LVS2_KCAP;                // 12
-constexpr int PCAP = 768;                      // pool entries
 constexpr int OFF_LIST = 2 * STAGE_BYTES;      // u64 [BQ][KCAP] sorted descending, first k used
-constexpr int OFF_PKEY = OFF_LIST + BQ * KCAP * 8;
-constexpr int OFF_POWN = OFF_PKEY + PCAP * 8;  // u16 [PCAP] local query of each pool entry
-constexpr int OFF_CTRL = OFF_POWN + PCAP * 2;  // u32 pool_cnt[2], flags[2]
-constexpr int LDS_TOTAL = OFF_CTRL + 16;
+constexpr int OFF_LOCK = OFF_LIST + BQ * KCAP * 8;  // u32 [BQ] spin locks
+constexpr int LDS_TOTAL = OFF_LOCK + BQ * 4;
 static_assert(LDS_TOTAL <= 160 * 1024, "LDS budget");
 
 typedef __attribute__((address_space(3))) void lds_void_t;
@@ -73,10 +70,7 @@ __global__ __launch_bounds__(512, 2) void lvs_tile2_kernel(const LvsTileArgs a) 
     if (tile0 >= tile1) return;
 
     u64* lists = (u64*)(smem + OFF_LIST);
-    u64* pkey = (u64*)(smem + OFF_PKEY);
-    unsigned short* pown = (unsigned short*)(smem + OFF_POWN);
-    uint32_t* pcnt = (uint32_t*)(smem + OFF_CTRL);  // [2]
-    uint32_t* flags = pcnt + 2;                       // [2]
+    uint32_t* locks = (uint32_t*)(smem + OFF_LOCK);
     float* bnl = (float*)(smem + OFF_LIST);           // TOP1: |y|^2 of the current corpus tile [BC]
     u64* part = (u64*)(smem + OFF_LIST + BC * 4);     // TOP1: [BQ][4] per-lane partial best keys
 
@@ -149,7 +143,7 @@ __global__ __launch_bounds__(512, 2) void lvs_tile2_kernel(const LvsTileArgs a) 
 
     if (MODE == LVS_MODE_TOPK) {
         for (int i = tid; i < BQ * KCAP; i += 512) lists[i] = 0;
-        if (tid < 4) pcnt[tid] = 0;
+        for (int i = tid; i < BQ; i += 512) locks[i] = 0;
     }
     float bestv[2] = {-INFINITY, -INFINITY};
     uint32_t besti[2] = {0xFFFFFFFFu, 0xFFFFFFFFu};
@@ -162,31 +156,26 @@ __global__ __launch_bounds__(512, 2) void lvs_tile2_kernel(const LvsTileArgs a) 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
-    // Drain the pool into the per-query sorted lists.  Called by all waves between two barriers; wave w owns
-    // queries [32w, 32w+32), one per lane of its lower half.  n = number of valid pool entries.
-    auto drain = [&](uint32_t n) {
-        if (lane < 32) {
-            const int q = wave * 32 + lane;
-            u64* L = lists + q * KCAP;
-            bool changed = false;
-            for (uint32_t e = 0; e < n; ++e) {
-                if (pown[e] != (unsigned short)q) continue;
-                const u64 key = pkey[e];
-                if (key <= L[k - 1]) continue;
-                int j = k - 1;
-                while (j > 0 && L[j - 1] < key) {
-                    L[j] = L[j - 1];
-                    --j;
-                }
-                L[j] = key;
-                changed = true;
-            }
-            const u64 tk = L[k - 1];
-            if (changed && tk != 0 && (q0 + q) < a.nq) atomicMax(&a.gtau[q0 + q], (uint32_t)(tk >> 32));
+    // per-lane byte offsets of the staging loads relative to the tile's / query tile's first row
+    unsigned c_loff[4], q_loff[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        long long qrow = a.debug_hot ? s_row[i] : q0 + s_row[i];
+        if (qrow > a.nq - 1) qrow = a.nq - 1;
+        q_loff[i] = (unsigned)(((qrow - (a.debug_hot ? 0 : q0)) * ldq + s_col[i]) * 2);
+    }
+    auto set_tile_offsets = [&](int tile_rel) {  // rows past the end of the shard re-read the last valid row
+        const long long trow0 = (long long)(tile0 + tile_rel) * BC;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            long long grow = trow0 + s_row[i];
+            if (grow > a.nb - 1) grow = a.nb - 1;
+            c_loff[i] = (unsigned)(((grow - trow0) * ldb + s_col[i]) * 2);
         }
     };
+    set_tile_offsets(0);
+    int n_tile = 0, n_seg = 0, n_r = 0;  // (tile, segment, k-block) of the K-step being prefetched
 
-    int round = 0;
     const int T = (tile1 - tile0) * nk;
     stage(0, 0);
     int ks_in_tile = 0, ti = 0;
@@ -197,15 +186,22 @@ __global__ __launch_bounds__(512, 2) void lvs_tile2_kernel(const LvsTileArgs a) 
         // ---- one K-step, software-pipelined by hand: 16 steps f = kk*4 + mi of {A-fragment read two steps ahead,
         // one staging load of the NEXT K-step (first 8 steps), 2 MFMAs}; B fragments double-buffered per kk ----
         const char* sb = smem + buf * STAGE_BYTES;
-        // the step after the last one re-loads the last K-step into the idle buffer (never read): no branches
+        // next K-step's source: uniform 64-bit bases (SGPRs) + constant per-lane 32-bit byte offsets, advanced
+        // incrementally (no divisions, no per-load 64-bit VALU).  The step after the last one re-loads the last
+        // K-step into the idle buffer (never read), so there is no branch around the loads.
         char* n_base = smem + (buf ^ 1) * STAGE_BYTES;
-        const int tn = t + 1 < T ? t + 1 : T - 1;
-        const int n_ti = tn / nk;
-        const int n_ks = tn - n_ti * nk;
-        const int n_seg = n_ks / nkd, n_r = n_ks - n_seg * nkd;
-        const int n_qcol = a.seg_q[n_seg] + n_r * BK;
-        const int n_ccol = a.seg_c[n_seg] + n_r * BK;
-        const long long n_trow0 = a.debug_hot ? 0 : (long long)(tile0 + n_ti) * BC;
+        if (t + 1 < T) {
+            if (++n_r == nkd) {
+                n_r = 0;
+                if (++n_seg == a.nseg) {
+                    n_seg = 0;
+                    ++n_tile;
+                    set_tile_offsets(n_tile);
+                }
+            }
+        }
+        const char* c_sbase = (const char*)xb + ((long long)(tile0 + n_tile) * BC * ldb + a.seg_c[n_seg] + n_r * BK) * 2;
+        const char* q_sbase = (const char*)xq + (q0 * ldq + a.seg_q[n_seg] + n_r * BK) * 2;
         half8 Bf[2][2], Af[3];
         Bf[0][0] = *(const half8*)(sb + b_base + foff[0]);
         Bf[0][1] = *(const half8*)(sb + b_base + 32 * ROWB + foff[0]);
@@ -223,13 +219,10 @@ __global__ __launch_bounds__(512, 2) void lvs_tile2_kernel(const LvsTileArgs a) 
                 Bf[(kk + 1) & 1][1] = *(const half8*)(sb + b_base + 32 * ROWB + foff[kk + 1]);
             }
             if (f < 8) {
-                if (f < 4) {
-                    long long grow = n_trow0 + s_row[f];
-                    if (grow > a.nb - 1) grow = a.nb - 1;
-                    glds16(xb + grow * ldb + n_ccol + s_col[f], n_base + (wave * 32 + f * 8) * ROWB);
-                } else {
-                    glds16(q_src[f - 4] + n_qcol, n_base + BC * ROWB + (wave * 32 + (f - 4) * 8) * ROWB);
-                }
+                if (f < 4)
+                    glds16(c_sbase + c_loff[f], n_base + (wave * 32 + f * 8) * ROWB);
+                else
+                    glds16(q_sbase + q_loff[f - 4], n_base + BC * ROWB + (wave * 32 + (f - 4) * 8) * ROWB);
             }
             acc[mi][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Af[f % 3], Bf[kk & 1][0], acc[mi][0], 0, 0, 0);
             acc[mi][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Af[f % 3], Bf[kk & 1][1], acc[mi][1], 0, 0, 0);
@@ -308,86 +301,87 @@ __global__ __launch_bounds__(512, 2) void lvs_tile2_kernel(const LvsTileArgs a) 
                 gord[ni] = g > gord[ni] ? g : gord[ni];
                 tauf[ni] = fmaxf(tauf[ni], tau_float(gord[ni]));
             }
-        u64 done0 = 0, done1 = 0;
-        const bool last_tile = (t + 1 == T);
-        for (;;) {
-            bool anyhit = false;
+        // own lists' current thresholds (they may have risen since this lane last looked)
 #pragma unroll
-            for (int mi = 0; mi < 4; ++mi)
+        for (int ni = 0; ni < 2; ++ni) {
+            uint32_t lo = (uint32_t)(lists[qloc[ni] * KCAP + k - 1] >> 32);
+            tauf[ni] = fmaxf(tauf[ni], tau_float(lo));
+        }
+        bool anyhit = false;
 #pragma unroll
-                for (int ni = 0; ni < 2; ++ni) anyhit |= qvalid[ni] && (max16(acc[mi][ni]) >= tauf[ni]);
-            if (__any(anyhit)) {
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) anyhit |= qvalid[ni] && (max16(acc[mi][ni]) >= tauf[ni]);
+        if (__any(anyhit)) {
 #pragma unroll 1
-                for (int tsel = 0; tsel < 8; ++tsel) {
-                    const int mi = tsel >> 1, ni = tsel & 1;
-                    f32x16 tv;
-                    switch (tsel) {
-                        case 0: tv = acc[0][0]; break;
-                        case 1: tv = acc[0][1]; break;
-                        case 2: tv = acc[1][0]; break;
-                        case 3: tv = acc[1][1]; break;
-                        case 4: tv = acc[2][0]; break;
-                        case 5: tv = acc[2][1]; break;
-                        case 6: tv = acc[3][0]; break;
-                        default: tv = acc[3][1]; break;
-                    }
-                    const float tf = ni ? tauf[1] : tauf[0];
-                    const bool qv = ni ? qvalid[1] : qvalid[0];
-                    const bool th = qv && (max16(tv) >= tf);
-                    if (!__any(th)) continue;
-                    if (th) {
-                        const int q = ni ? qloc[1] : qloc[0];
-                        const u64 ubq = ni ? ubk[1] : ubk[0];
-                        const uint32_t go = ni ? gord[1] : gord[0];
-                        const u64 tk = lists[q * KCAP + k - 1];
-                        const long long rbase = trow0 + lrow_base + mi * 32;
-                        u64 done = tsel < 4 ? done0 : done1;
+            for (int tsel = 0; tsel < 8; ++tsel) {
+                const int mi = tsel >> 1, ni = tsel & 1;
+                f32x16 tv;
+                switch (tsel) {
+                    case 0: tv = acc[0][0]; break;
+                    case 1: tv = acc[0][1]; break;
+                    case 2: tv = acc[1][0]; break;
+                    case 3: tv = acc[1][1]; break;
+                    case 4: tv = acc[2][0]; break;
+                    case 5: tv = acc[2][1]; break;
+                    case 6: tv = acc[3][0]; break;
+                    default: tv = acc[3][1]; break;
+                }
+                float tf = ni ? tauf[1] : tauf[0];
+                const bool qv = ni ? qvalid[1] : qvalid[0];
+                const bool th = qv && (max16(tv) >= tf);
+                if (!__any(th)) continue;
+                const int q = ni ? qloc[1] : qloc[0];
+                const u64 ubq = ni ? ubk[1] : ubk[0];
+                const uint32_t go = ni ? gord[1] : gord[0];
+                u64* L = lists + q * KCAP;
+                const long long rbase = trow0 + lrow_base + mi * 32;
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            const float s = tv[r];
-                            const u64 bit = 1ull << ((tsel & 3) * 16 + r);
-                            if (s >= tf && !(done & bit)) {
-                                const long long row = rbase + (r & 3) + 8 * (r >> 2);
-                                done |= bit;
-                                if (row < a.nb) {
-                                    const uint32_t id = a.row_ids ? a.row_ids[row] : (uint32_t)(row + a.id_offset);
-                                    const u64 key = lvs_pack_key(s, id);
-                                    if (key > tk && key < ubq && (uint32_t)(key >> 32) >= go) {
-                                        const uint32_t pos = atomicAdd(&pcnt[round & 1], 1u);
-                                        if (pos < PCAP) {
-                                            pkey[pos] = key;
-                                            pown[pos] = (unsigned short)q;
-                                        } else {
-                                            flags[round & 1] = 1u;  // pool full: retried after the drain
-                                            done &= ~bit;
-                                        }
+                for (int r = 0; r < 16; ++r) {
+                    const float s = tv[r];
+                    bool pending = false;
+                    u64 key = 0;
+                    if (th && s >= tf) {
+                        const long long row = rbase + (r & 3) + 8 * (r >> 2);
+                        if (row < a.nb) {
+                            const uint32_t id = a.row_ids ? a.row_ids[row] : (uint32_t)(row + a.id_offset);
+                            key = lvs_pack_key(s, id);
+                            pending = key > L[k - 1] && key < ubq && (uint32_t)(key >> 32) >= go;
+                        }
+                    }
+                    // locked sorted insertion; the critical section completes inside one loop iteration, so lanes of
+                    // one wave contending for the same lock cannot dead-lock each other
+                    while (__any(pending)) {
+                        if (pending) {
+                            uint32_t expect = 0;
+                            if (__hip_atomic_compare_exchange_strong(&locks[q], &expect, 1u, __ATOMIC_ACQUIRE,
+                                                                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
+                                if (key > L[k - 1]) {
+                                    int j = k - 1;
+                                    while (j > 0 && L[j - 1] < key) {
+                                        L[j] = L[j - 1];
+                                        --j;
                                     }
+                                    L[j] = key;
                                 }
+                                const uint32_t lo = (uint32_t)(L[k - 1] >> 32);
+                                __hip_atomic_store(&locks[q], 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                tf = fmaxf(tf, tau_float(lo));
+                                pending = false;
                             }
                         }
-                        if (tsel < 4) done0 = done; else done1 = done;
                     }
                 }
+                if (ni) tauf[1] = fmaxf(tauf[1], tf); else tauf[0] = fmaxf(tauf[0], tf);
             }
-            __syncthreads();
-            const uint32_t ovf = flags[round & 1];
-            if (!ovf && !last_tile) break;
-            // ---- drain (pool full, or the item's last tile) ----
-            uint32_t n = pcnt[round & 1];
-            n = n < PCAP ? n : PCAP;
-            if (tid == 0) {
-                flags[(round + 1) & 1] = 0;
-                pcnt[(round + 1) & 1] = 0;
-            }
-            drain(n);
-            __syncthreads();
+        }
+        // publish thresholds for the other slabs of these queries every 8 tiles and at the end of the item
+        if (((ti & 7) == 0) || t + 1 == T) {
 #pragma unroll
             for (int ni = 0; ni < 2; ++ni) {
-                uint32_t lo = (uint32_t)(lists[qloc[ni] * KCAP + k - 1] >> 32);
-                tauf[ni] = fmaxf(tauf[ni], tau_float(lo));
+                const uint32_t lo = (uint32_t)(lists[qloc[ni] * KCAP + k - 1] >> 32);
+                if (qvalid[ni] && lane < 32 && wm == 0 && lo > gord[ni]) atomicMax(&a.gtau[q0 + qloc[ni]], lo);
             }
-            ++round;
-            if (!ovf) break;  // last tile and nothing left to retry
         }
         }  // MODE
 #pragma unroll
@@ -416,7 +410,7 @@ __global__ __launch_bounds__(512, 2) void lvs_tile2_kernel(const LvsTileArgs a) 
         }
         return;
     }
-    // lists are complete (the last tile always drains) and sorted: write the slab's candidates
+    // lists are sorted and complete: write the slab's candidates
     __syncthreads();
     for (int i = tid; i < BQ * k; i += 512) {
         int q = i / k, j = i - q * k;
