@@ -312,7 +312,7 @@ __global__ __launch_bounds__(512, 2) void lvs_tile2_kernel(const LvsTileArgs a) 
         for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
             for (int ni = 0; ni < 2; ++ni) anyhit |= qvalid[ni] && (max16(acc[mi][ni]) >= tauf[ni]);
-        if (__any(anyhit)) {
+        if (__any(anyhit) && a.debug_hot != 2) {
 #pragma unroll 1
             for (int tsel = 0; tsel < 8; ++tsel) {
                 const int mi = tsel >> 1, ni = tsel & 1;
@@ -349,27 +349,38 @@ __global__ __launch_bounds__(512, 2) void lvs_tile2_kernel(const LvsTileArgs a) 
                             pending = key > L[k - 1] && key < ubq && (uint32_t)(key >> 32) >= go;
                         }
                     }
-                    // locked sorted insertion; the critical section completes inside one loop iteration, so lanes of
-                    // one wave contending for the same lock cannot dead-lock each other
-                    while (__any(pending)) {
-                        if (pending) {
+                    // Wave-cooperative insertion, one pending hit at a time: the hit is broadcast, lane j < 16 owns
+                    // slot j of that query's sorted list and computes its new content in ONE step
+                    // (new[j] = L[j] if L[j] > key, else key if L[j-1] > key, else L[j-1]) - cost independent of k.
+                    // The list's lock is taken by lane 0 only (waves wm = 0, 1 share queries).
+                    unsigned long long pm = __ballot(pending);
+                    while (pm) {
+                        const int src = __ffsll((long long)pm) - 1;
+                        pm &= pm - 1;
+                        const uint32_t klo = __builtin_amdgcn_readlane((uint32_t)key, src);
+                        const uint32_t khi = __builtin_amdgcn_readlane((uint32_t)(key >> 32), src);
+                        const u64 ukey = ((u64)khi << 32) | klo;
+                        const int uq = __builtin_amdgcn_readlane(q, src);
+                        if (lane == 0) {
                             uint32_t expect = 0;
-                            if (__hip_atomic_compare_exchange_strong(&locks[q], &expect, 1u, __ATOMIC_ACQUIRE,
-                                                                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
-                                if (key > L[k - 1]) {
-                                    int j = k - 1;
-                                    while (j > 0 && L[j - 1] < key) {
-                                        L[j] = L[j - 1];
-                                        --j;
-                                    }
-                                    L[j] = key;
-                                }
-                                const uint32_t lo = (uint32_t)(L[k - 1] >> 32);
-                                __hip_atomic_store(&locks[q], 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                                tf = fmaxf(tf, tau_float(lo));
-                                pending = false;
-                            }
+                            while (!__hip_atomic_compare_exchange_strong(&locks[uq], &expect, 1u, __ATOMIC_ACQUIRE,
+                                                                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))
+                                expect = 0;
                         }
+                        __builtin_amdgcn_wave_barrier();
+                        u64* UL = lists + uq * KCAP;
+                        u64 newv = 0;
+                        if (lane < k) {
+                            const u64 mine = UL[lane];
+                            const u64 prev = lane > 0 ? UL[lane - 1] : ~0ull;
+                            newv = mine > ukey ? mine : (prev > ukey ? ukey : prev);
+                        }
+                        __builtin_amdgcn_wave_barrier();
+                        if (lane < k) UL[lane] = newv;
+                        const uint32_t ntau = __builtin_amdgcn_readlane((uint32_t)(newv >> 32), k - 1);
+                        if (lane == 0)
+                            __hip_atomic_store(&locks[uq], 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        if (q == uq) tf = fmaxf(tf, tau_float(ntau));
                     }
                 }
                 if (ni) tauf[1] = fmaxf(tauf[1], tf); else tauf[0] = fmaxf(tauf[0], tf);
