@@ -37,7 +37,7 @@ def parse():
     ap.add_argument("--corpus", type=int, default=1_000_000)
     ap.add_argument("--dim", type=int, default=768)
     ap.add_argument("--k", type=int, default=10)
-    ap.add_argument("--cpu-sample", type=int, default=4096, help="queries in the CPU-oracle sample (N=1 only)")
+    ap.add_argument("--cpu-sample", type=int, default=2048, help="queries in the CPU-oracle sample (N=1 only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     return ap.parse_args()
 
@@ -150,8 +150,8 @@ def main():
                        "queries": nq, "corpus_rows": n, "dim": d, "k": k, "shard_rows": hi - lo},
             "planted_neighbour_at_rank1": planted_at_1,
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP16_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP16_MFMA_TFLOPS, "traffic": None,
-                         "kernel": "lvs_tile_kernel<TOPK>", "kernel_ms": kernel_ms, "launches": klaunches,
+                         "frac": achieved / PEAK_FP16_MFMA_TFLOPS, "traffic": pmc_traffic(n, nq, world),
+                         "kernel": "lvs_tile2_kernel<TOPK>", "kernel_ms": kernel_ms, "launches": klaunches,
                          "algorithmic_flops_per_launch": flops_per_launch,
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "hbm_frac_secondary": alg_bytes / (kernel_ms * 1e-3) / 1e9 / PEAK_HBM_GBS},
@@ -162,6 +162,21 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def pmc_traffic(n, nq, world):
+    """HBM-side bytes per launch of the tile kernel from the committed rocprofv3 PMC passes of this same command
+    (profiles/latest_pmc.json: FETCH_SIZE x 2 x 1024 per the gfx950 correction of MI355X_MICROARCH.md, + WRITE_SIZE x
+    1024; separate --pmc runs, tools/pmc_summary.py).  Counters cannot be read from inside the timed process, so the
+    figure is only reported for the configuration it was collected on (1 GPU, default sizes); otherwise null."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "latest_pmc.json")) as f:
+            pmc = json.load(f)
+        if world == 1 and n == 1_000_000 and nq == 100_000:
+            return pmc.get("traffic_bytes_per_launch")
+    except Exception:
+        pass
+    return None
 
 
 def cpu_baseline(np, torch, xb, xq, D, I, sample, k):

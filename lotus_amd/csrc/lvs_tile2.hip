@@ -307,14 +307,18 @@ __global__ __launch_bounds__(512, 2) void lvs_tile2_kernel(const LvsTileArgs a) 
             uint32_t lo = (uint32_t)(lists[qloc[ni] * KCAP + k - 1] >> 32);
             tauf[ni] = fmaxf(tauf[ni], tau_float(lo));
         }
-        bool anyhit = false;
+        // fast filter: which of the eight 32x32 blocks hold a score that may enter some query's list?
+        uint32_t hitmask = 0;  // wave-uniform, bit tsel = mi * 2 + ni
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-            for (int ni = 0; ni < 2; ++ni) anyhit |= qvalid[ni] && (max16(acc[mi][ni]) >= tauf[ni]);
-        if (__any(anyhit) && a.debug_hot != 2) {
-#pragma unroll 1
-            for (int tsel = 0; tsel < 8; ++tsel) {
+            for (int ni = 0; ni < 2; ++ni)
+                if (__any(qvalid[ni] && (max16(acc[mi][ni]) >= tauf[ni]))) hitmask |= 1u << (mi * 2 + ni);
+        if (a.debug_hot == 2) hitmask = 0;
+        {
+            while (hitmask) {  // rare path: only blocks with candidates are visited
+                const int tsel = __builtin_ctz(hitmask);
+                hitmask &= hitmask - 1;
                 const int mi = tsel >> 1, ni = tsel & 1;
                 f32x16 tv;
                 switch (tsel) {
@@ -354,6 +358,7 @@ __global__ __launch_bounds__(512, 2) void lvs_tile2_kernel(const LvsTileArgs a) 
                     // (new[j] = L[j] if L[j] > key, else key if L[j-1] > key, else L[j-1]) - cost independent of k.
                     // The list's lock is taken by lane 0 only (waves wm = 0, 1 share queries).
                     unsigned long long pm = __ballot(pending);
+                    if (a.debug_hot == 3) pm = 0;  // tuning aid: scan for hits but skip the insertions
                     while (pm) {
                         const int src = __ffsll((long long)pm) - 1;
                         pm &= pm - 1;
