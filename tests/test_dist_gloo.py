@@ -65,3 +65,63 @@ def test_sharded_search_equals_single_process(tmp_path):
         assert np.array_equal(r[3], I) and np.allclose(r[4], D, atol=1e-6)  # every rank holds the merged result
         assert np.array_equal(r[5], Is) and np.allclose(r[6], Ds, atol=1e-6)
         assert (r[7][:, 40:] == -1).all() and sorted(r[7][0, :40].tolist()) == sorted(ids[:40])
+
+
+def _worker_km(rank, world, port, out_q):
+    sys.path.insert(0, os.path.dirname(HERE))
+    sys.path.insert(0, HERE)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from lotus_amd.cluster import kmeans
+        from lotus_amd.dedup import threshold_pairs
+        from oracle_backend import OracleBackend, _emulate_storage
+
+        rng = np.random.default_rng(3)
+        c = rng.standard_normal((5, 12)).astype(np.float32) * 4
+        x = _emulate_storage((c[rng.integers(0, 5, 700)] + 0.3 * rng.standard_normal((700, 12))).astype(np.float32), 1)
+        r = kmeans(x, 5, niter=5, max_points_per_centroid=64, backend=OracleBackend(), shard=True)
+        xd = synth.corpus(300, 16, seed=8)
+        xd[150:200] = xd[:50] + 0.02 * synth.corpus(50, 16, seed=9)
+        xd /= np.linalg.norm(xd, axis=1, keepdims=True)
+        be = OracleBackend()
+        i, j, s_ = threshold_pairs(be, be.pack(xd, 1), 0.97, shard=True)
+        out_q.put((rank, r.centroids, r.assign, r.obj, i, j))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_kmeans_and_dedup_equal_single_process():
+    import oracle
+    from lotus_amd.cluster import kmeans
+    from lotus_amd.dedup import threshold_pairs
+    from oracle_backend import OracleBackend, _emulate_storage
+
+    world = 2
+    port = 31500 + (os.getpid() % 2000)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_km, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=180) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    rng = np.random.default_rng(3)
+    c = rng.standard_normal((5, 12)).astype(np.float32) * 4
+    x = _emulate_storage((c[rng.integers(0, 5, 700)] + 0.3 * rng.standard_normal((700, 12))).astype(np.float32), 1)
+    one = kmeans(x, 5, niter=5, max_points_per_centroid=64, backend=OracleBackend())
+    xd = synth.corpus(300, 16, seed=8)
+    xd[150:200] = xd[:50] + 0.02 * synth.corpus(50, 16, seed=9)
+    xd /= np.linalg.norm(xd, axis=1, keepdims=True)
+    be = OracleBackend()
+    i1, j1, _ = threshold_pairs(be, be.pack(xd, 1), 0.97)
+    assert len(i1) >= 50
+    for r in res:
+        # the all-reduced sums are added in a different order than the single-process in-row-order sum: tiny drift
+        assert np.allclose(r[1], one.centroids, atol=1e-5) and (r[2] == one.assign).mean() >= 0.999
+        assert np.allclose(r[3], one.obj, rtol=1e-5)
+        assert np.array_equal(r[4], i1) and np.array_equal(r[5], j1)

@@ -1,0 +1,76 @@
+"""Operator-level timings on one MI355X for BASELINE.md section 4 (development aid; the judged line is bench.py)."""
+import json, os, sys, tempfile, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, pandas as pd, torch
+from lotus_amd import HipVS, ops, _capi
+from lotus_amd.backend import HipBackend
+from lotus_amd.cluster import kmeans
+from lotus_amd.dedup import threshold_pairs, keep_mask
+
+be = HipBackend("cuda:0")
+dev = be.device
+res = {}
+
+def gen(n, d, seed, dtype=torch.float16):
+    g = torch.Generator(device=dev); g.manual_seed(seed)
+    out = torch.empty((n, d), dtype=dtype, device=dev)
+    for r0 in range(0, n, 1 << 18):
+        r1 = min(n, r0 + (1 << 18))
+        out[r0:r1] = torch.nn.functional.normalize(torch.randn((r1 - r0, d), generator=g, device=dev), dim=1).to(dtype)
+    return out
+
+def timed(fn, reps=3, warm=1):
+    for _ in range(warm): fn()
+    be.synchronize(); ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter(); fn(); be.synchronize(); ts.append(time.perf_counter() - t0)
+    return sorted(ts)[len(ts) // 2]
+
+class PassRM:
+    def __init__(self, v): self.v = v
+    def convert_query_to_query_vector(self, q): return self.v
+
+with tempfile.TemporaryDirectory() as td:
+    # cfg1: 1k x 10k, d=384 fp32 (hi|lo path), k=5 - through HipVS host to host
+    xb = gen(10_000, 384, 1, torch.float32).cpu().numpy(); xq = gen(1_000, 384, 2, torch.float32).cpu().numpy()
+    vs = HipVS(backend=be); vs.index(None, xb, td + "/c1")
+    t = timed(lambda: vs(xq, 5), reps=5); res["cfg1_call_ms"] = t * 1e3
+    # cfg2: 10k x 1M fp16 k=10
+    xb = gen(1_000_000, 768, 3); xq = gen(100_000, 768, 4)
+    xb_h = xb.cpu().numpy(); xq_h = xq.cpu().numpy()
+    t0 = time.perf_counter(); vs.index(None, xb_h, td + "/c2"); be.synchronize(); res["index_1M_s"] = time.perf_counter() - t0
+    t = timed(lambda: vs(xq_h[:10_000], 10)); res["cfg2_call_ms"] = t * 1e3; res["cfg2_call_qps"] = 10_000 / t
+    # cfg3: 100k x 1M, host to host, and the accessor
+    t = timed(lambda: vs(xq_h, 10), reps=3); res["cfg3_call_ms"] = t * 1e3; res["cfg3_call_qps"] = 100_000 / t
+    right = pd.DataFrame({"R": np.arange(1_000_000)}); right.attrs["index_dirs"] = {"R": td + "/c2"}
+    left = pd.DataFrame({"L": np.arange(100_000)})
+    t = timed(lambda: ops.sem_sim_join(left, right, "L", "R", 10, rm=PassRM(xq_h), vs=vs), reps=2, warm=1)
+    res["cfg3_ops_sem_sim_join_s"] = t
+    # literal single-query sem_search (HBM-bound regime)
+    t = timed(lambda: vs(xq_h[:1], 10), reps=10); res["single_query_1M_ms"] = t * 1e3
+    del vs
+    # cfg4 (scaled to 1 GPU): dedup threshold self-join, 2M rows with 100k planted near-duplicates
+    n = 2_000_000
+    base = gen(n - 100_000, 768, 5, torch.float32)
+    g = torch.Generator(device=dev); g.manual_seed(6)
+    dup = torch.nn.functional.normalize(base[:100_000] + 0.2 * torch.nn.functional.normalize(torch.randn((100_000, 768), generator=g, device=dev), dim=1), dim=1)
+    x = torch.cat([base, dup]).to(torch.float16); del base, dup
+    pk = be.pack(x, _capi.PACK_F16)
+    t0 = time.perf_counter(); i, j, s = threshold_pairs(be, pk, 0.95); t = time.perf_counter() - t0
+    res["cfg4_2M_threshold_join_s"] = t; res["cfg4_pairs"] = int(len(i)); res["cfg4_tflops_symmetric"] = n * n * 768 / t / 1e12
+    del x, pk
+    # cfg5 (1 GPU): k-means 10M x 768 fp16, K=1024, 20 iters - faiss-parity mode (262 144-row subsample + final assign)
+    n = 10_000_000
+    x = gen(n, 768, 7)
+    pk = be.pack(x, _capi.PACK_F16)
+    xh = np.empty((n, 768), np.float16)  # host copy only feeds the initial centroids
+    step = 1 << 20
+    for r0 in range(0, n, step): xh[r0:r0 + step] = x[r0:r0 + step].cpu().numpy()
+    del x
+    t0 = time.perf_counter(); r = kmeans(xh, 1024, niter=20, backend=be, packed=pk, pack_mode=_capi.PACK_F16); t = time.perf_counter() - t0
+    res["cfg5_parity_mode_s"] = t; res["cfg5_obj_first_last"] = [float(r.obj[0]), float(r.obj[-1])]
+    t0 = time.perf_counter(); r = kmeans(xh, 1024, niter=20, backend=be, packed=pk, pack_mode=_capi.PACK_F16, centroid_precision="fp16"); t = time.perf_counter() - t0
+    res["cfg5_parity_mode_fp16_centroids_s"] = t
+    t0 = time.perf_counter(); r = kmeans(xh, 1024, niter=2, backend=be, packed=pk, pack_mode=_capi.PACK_F16, max_points_per_centroid=None, final_assign=False); t = time.perf_counter() - t0
+    res["cfg5_full_data_per_iter_s"] = t / 2
+print(json.dumps(res, indent=1))
