@@ -293,7 +293,7 @@ struct Plan {
 };
 
 int make_plan(int64_t nq, int64_t nb, int32_t d, int32_t xb_pack, int32_t xq_pack, int32_t k, Plan& p,
-              bool allow_v2 = true) {
+              bool allow_v2 = true, bool force_v2 = false) {
     if (nq < 0 || nb < 0 || d <= 0 || k < 0) return LVS_EINVAL;
     if (xb_pack != LVS_PACK_F16 && xb_pack != LVS_PACK_SPLIT) return LVS_EINVAL;
     if (xq_pack != LVS_PACK_F16 && xq_pack != LVS_PACK_SPLIT) return LVS_EINVAL;
@@ -314,7 +314,7 @@ int make_plan(int64_t nq, int64_t nb, int32_t d, int32_t xb_pack, int32_t xq_pac
     if (xq_pack == LVS_PACK_SPLIT) seg(p.dpad, 0);
     p.nk = p.nseg * p.nkd;
     p.ntiles = (int)lvs_ceil_div(nb > 0 ? nb : 1, LVS_BC);
-    p.v2 = allow_v2 && k >= 1 && k <= LVS2_KCAP;
+    p.v2 = force_v2 || (allow_v2 && k >= 1 && k <= LVS2_KCAP);
     if (const char* e = getenv("LVS_KERNEL")) {  // tuning override: 1 = 256x128 kernel, 2 = 256x256 kernel
         if (atoi(e) == 1) p.v2 = 0;
     }
@@ -496,7 +496,7 @@ extern "C" int32_t lvs_scores(const void* xb, int32_t xb_pack, int64_t nb, const
                               int32_t d, int32_t metric, const float* xb_norms_sq, const float* xq_norms_sq, float* out,
                               int64_t ld_out, void* stream) {
     Plan p;
-    LVS_REQUIRE(make_plan(nq, nb, d, xb_pack, xq_pack, 1, p, false) == LVS_OK, "bad shape");
+    LVS_REQUIRE(make_plan(nq, nb, d, xb_pack, xq_pack, 1, p, true, true) == LVS_OK, "bad shape");
     LVS_REQUIRE(metric == LVS_METRIC_IP || metric == LVS_METRIC_L2, "bad metric %d", metric);
     if (nq == 0 || nb == 0) return LVS_OK;
     LVS_REQUIRE(xb && xq && out && ld_out >= nb, "bad buffers");
@@ -527,7 +527,8 @@ extern "C" int32_t lvs_scores(const void* xb, int32_t xb_pack, int64_t nb, const
     a.nslab = p.nslab;
     a.nqt = p.nqt;
     a.gq = p.gq;
-    LVS_HIP_CHECK(lvs_tile_launch(LVS_MODE_SCORES, a, (hipStream_t)stream));
+    LVS_HIP_CHECK(p.v2 ? lvs_tile2_launch(LVS_MODE_SCORES, a, (hipStream_t)stream)
+                       : lvs_tile_launch(LVS_MODE_SCORES, a, (hipStream_t)stream));
     return LVS_OK;
 }
 
@@ -537,7 +538,7 @@ extern "C" int32_t lvs_range_join(const void* xb, int32_t xb_pack, int64_t nb, c
                                   int32_t qt_phase, int64_t capacity, int64_t* out_q, int64_t* out_j, float* out_s,
                                   uint64_t* out_count, void* stream) {
     Plan p;
-    LVS_REQUIRE(make_plan(nq, nb, d, xb_pack, xq_pack, 1, p, false) == LVS_OK, "bad shape");
+    LVS_REQUIRE(make_plan(nq, nb, d, xb_pack, xq_pack, 1, p, true, true) == LVS_OK, "bad shape");
     LVS_REQUIRE(metric == LVS_METRIC_IP || metric == LVS_METRIC_L2, "bad metric %d", metric);
     LVS_REQUIRE(capacity >= 0 && out_count, "bad output buffers");
     LVS_REQUIRE(qt_stride >= 1 && qt_phase >= 0 && qt_phase < qt_stride, "bad tile dealing %d/%d", qt_phase, qt_stride);
@@ -578,6 +579,7 @@ extern "C" int32_t lvs_range_join(const void* xb, int32_t xb_pack, int64_t nb, c
     a.threshold = threshold;
     a.qt_stride = qt_stride;
     a.qt_phase = qt_phase;
-    LVS_HIP_CHECK(lvs_tile_launch(LVS_MODE_RANGE, a, (hipStream_t)stream));
+    LVS_HIP_CHECK(p.v2 ? lvs_tile2_launch(LVS_MODE_RANGE, a, (hipStream_t)stream)
+                       : lvs_tile_launch(LVS_MODE_RANGE, a, (hipStream_t)stream));
     return LVS_OK;
 }

@@ -54,7 +54,7 @@ __device__ inline bool item_of_block(const LvsTileArgs& a, int b, int& qt, int& 
 
 }  // namespace
 
-template <int MODE>  // LVS_MODE_TOPK: lists + pool (1 < k <= KCAP);  LVS_MODE_TOP1: k == 1, per-lane running best
+template <int MODE>  // TOPK: sorted lists (1 < k <= KCAP); TOP1: k == 1, per-lane best; RANGE: threshold join; SCORES: matrix out
 __global__ __launch_bounds__(512, 2) void lvs_tile2_kernel(const LvsTileArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -65,8 +65,16 @@ __global__ __launch_bounds__(512, 2) void lvs_tile2_kernel(const LvsTileArgs a) 
     int qt, slab;
     if (!item_of_block(a, blockIdx.x, qt, slab)) return;
     const long long q0 = (long long)qt * BQ;
-    const int tile0 = slab * a.tiles_per_slab;
-    const int tile1 = min(a.ntiles, tile0 + a.tiles_per_slab);
+    int tile0_ = slab * a.tiles_per_slab;
+    const int tile1 = min(a.ntiles, tile0_ + a.tiles_per_slab);
+    if (MODE == LVS_MODE_RANGE) {
+        if (a.qt_stride > 1 && (qt % a.qt_stride) != a.qt_phase) return;
+        if (a.q_row0 >= 0) {  // self-join: tiles whose rows are all <= every query row of this tile hold no j > i
+            const long long first = (a.q_row0 + q0 - a.id_offset) / BC;
+            if (first > tile0_) tile0_ = (int)(first < tile1 ? first : tile1);
+        }
+    }
+    const int tile0 = tile0_;
     if (tile0 >= tile1) return;
 
     u64* lists = (u64*)(smem + OFF_LIST);
@@ -179,10 +187,20 @@ __global__ __launch_bounds__(512, 2) void lvs_tile2_kernel(const LvsTileArgs a) 
     const int T = (tile1 - tile0) * nk;
     stage(0, 0);
     int ks_in_tile = 0, ti = 0;
+    uint32_t gpre[2] = {0u, 0u};  // cross-workgroup thresholds, prefetched one K-step before the tile epilogue
     for (int t = 0; t < T; ++t) {
         const int buf = t & 1;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        if (a.debug_hot == 4) {  // tuning aid: no wait for the staging loads (results are garbage, timing only)
+            __builtin_amdgcn_s_barrier();
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+        if (MODE == LVS_MODE_TOPK && ks_in_tile == nk - 1) {
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+                if (qvalid[ni]) gpre[ni] = a.gtau[q0 + qloc[ni]];
+        }
         // ---- one K-step, software-pipelined by hand: 16 steps f = kk*4 + mi of {A-fragment read two steps ahead,
         // one staging load of the NEXT K-step (first 8 steps), 2 MFMAs}; B fragments double-buffered per kk ----
         const char* sb = smem + buf * STAGE_BYTES;
@@ -235,7 +253,54 @@ __global__ __launch_bounds__(512, 2) void lvs_tile2_kernel(const LvsTileArgs a) 
         ++ti;
         const int lrow_base = wm * 128 + 4 * (lane >> 5);  // + mi*32 + (r&3) + 8*(r>>2)
 
-        if (MODE == LVS_MODE_TOP1) {
+        if (MODE == LVS_MODE_RANGE || MODE == LVS_MODE_SCORES) {
+            if (a.metric == LVS_METRIC_L2) {
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const long long row = trow0 + lrow_base + mi * 32 + (r & 3) + 8 * (r >> 2);
+                        const float bnv = row < a.nb ? a.bn[row] : 0.f;
+#pragma unroll
+                        for (int ni = 0; ni < 2; ++ni)
+                            acc[mi][ni][r] = -fmaxf((qnv[ni] + bnv) - 2.0f * acc[mi][ni][r], 0.f);
+                    }
+            }
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) {
+                    const long long qg = q0 + qloc[ni];
+                    if (MODE == LVS_MODE_SCORES) {
+                        if (!qvalid[ni]) continue;
+                        float* orow = a.scores + qg * a.ld_scores;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const long long row = trow0 + lrow_base + mi * 32 + (r & 3) + 8 * (r >> 2);
+                            if (row < a.nb) orow[row] = acc[mi][ni][r];
+                        }
+                    } else {
+                        const bool th = qvalid[ni] && (max16(acc[mi][ni]) > a.threshold);
+                        if (!__any(th)) continue;
+                        if (!th) continue;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const float s = acc[mi][ni][r];
+                            if (!(s > a.threshold)) continue;  // strict, as sem_dedup.py:46
+                            const long long row = trow0 + lrow_base + mi * 32 + (r & 3) + 8 * (r >> 2);
+                            if (row >= a.nb) continue;
+                            const long long jg = row + a.id_offset;
+                            if (a.q_row0 >= 0 && jg <= a.q_row0 + qg) continue;
+                            const unsigned long long pos = atomicAdd(a.pair_count, 1ull);
+                            if ((long long)pos < a.pair_capacity) {
+                                a.pair_q[pos] = qg;
+                                a.pair_j[pos] = jg;
+                                a.pair_s[pos] = s;
+                            }
+                        }
+                    }
+                }
+        } else if (MODE == LVS_MODE_TOP1) {
             // ---- k == 1: per-lane running best, no lists.  Rows are visited in increasing order, so a strict
             // "greater" keeps the lowest row among equal scores (the oracle's tie rule). ----
             if (a.metric == LVS_METRIC_L2) {
@@ -297,7 +362,7 @@ __global__ __launch_bounds__(512, 2) void lvs_tile2_kernel(const LvsTileArgs a) 
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni)
             if (qvalid[ni]) {
-                uint32_t g = a.gtau[q0 + qloc[ni]];
+                const uint32_t g = gpre[ni];
                 gord[ni] = g > gord[ni] ? g : gord[ni];
                 tauf[ni] = fmaxf(tauf[ni], tau_float(gord[ni]));
             }
@@ -408,6 +473,7 @@ __global__ __launch_bounds__(512, 2) void lvs_tile2_kernel(const LvsTileArgs a) 
                 for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
     }
 
+    if (MODE == LVS_MODE_RANGE || MODE == LVS_MODE_SCORES) return;
     if (MODE == LVS_MODE_TOP1) {
         // four lanes (l, l+32 of waves wm = 0, 1) hold partial winners of each query: combine by key
         __syncthreads();
@@ -443,11 +509,21 @@ hipError_t lvs_tile2_launch(int mode, const LvsTileArgs& a, hipStream_t stream) 
         e = hipFuncSetAttribute((const void*)lvs_tile2_kernel<LVS_MODE_TOP1>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);
         if (e != hipSuccess) return e;
+        e = hipFuncSetAttribute((const void*)lvs_tile2_kernel<LVS_MODE_RANGE>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);
+        if (e != hipSuccess) return e;
+        e = hipFuncSetAttribute((const void*)lvs_tile2_kernel<LVS_MODE_SCORES>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);
+        if (e != hipSuccess) return e;
         attr_done = true;
     }
     dim3 grid(lvs_tile_grid_blocks(a.nqt, a.nslab, a.gq)), block(512);
     if (mode == LVS_MODE_TOP1)
         hipLaunchKernelGGL(lvs_tile2_kernel<LVS_MODE_TOP1>, grid, block, LDS_TOTAL, stream, a);
+    else if (mode == LVS_MODE_RANGE)
+        hipLaunchKernelGGL(lvs_tile2_kernel<LVS_MODE_RANGE>, grid, block, LDS_TOTAL, stream, a);
+    else if (mode == LVS_MODE_SCORES)
+        hipLaunchKernelGGL(lvs_tile2_kernel<LVS_MODE_SCORES>, grid, block, LDS_TOTAL, stream, a);
     else
         hipLaunchKernelGGL(lvs_tile2_kernel<LVS_MODE_TOPK>, grid, block, LDS_TOTAL, stream, a);
     return hipGetLastError();
