@@ -1,4 +1,3 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
-echo "== K=1 normal"; QB_K=1 QB_REPS=3 python tools/quick_bench.py 100000x1000000 2>&1 | grep -E "TFLOP"
-echo "== K=1 no-vmcnt-wait"; LVS_DEBUG_HOT=4 QB_K=1 QB_REPS=3 python tools/quick_bench.py 100000x1000000 2>&1 | grep -E "TFLOP"
+for S in 100000x1000000 100000x125000 10000x1000000 65536x131072 1000x10000; do echo "== K=10 $S"; QB_REPS=4 timeout 100 python tools/quick_bench.py $S 2>&1 | grep -E "TFLOP"; done
