@@ -73,6 +73,14 @@ def load():
         raise LotusHipError(
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950). lotus_amd has no CPU fallback.")
+    # PyTorch-ROCm wheels bundle their own libamdhip64.so.  The device buffers and streams this library receives come
+    # from torch, so both must share ONE HIP runtime: load torch's first, then our NEEDED libamdhip64.so.7 resolves to
+    # the copy already in the process.  (Loaded the other way round, our kernels run on a second runtime that knows
+    # nothing about torch's context: "no ROCm-capable device is detected".)
+    try:
+        import torch  # noqa: F401
+    except Exception:  # symbol checks still work without torch
+        pass
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
