@@ -403,7 +403,6 @@ __global__ __launch_bounds__(512, 2) void lvs_tile2_kernel(const LvsTileArgs a) 
                 const int q = ni ? qloc[1] : qloc[0];
                 const u64 ubq = ni ? ubk[1] : ubk[0];
                 const uint32_t go = ni ? gord[1] : gord[0];
-                u64* L = lists + q * KCAP;
                 const long long rbase = trow0 + lrow_base + mi * 32;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -415,7 +414,7 @@ __global__ __launch_bounds__(512, 2) void lvs_tile2_kernel(const LvsTileArgs a) 
                         if (row < a.nb) {
                             const uint32_t id = a.row_ids ? a.row_ids[row] : (uint32_t)(row + a.id_offset);
                             key = lvs_pack_key(s, id);
-                            pending = key > L[k - 1] && key < ubq && (uint32_t)(key >> 32) >= go;
+                            pending = key < ubq && (uint32_t)(key >> 32) >= go;  // re-checked under the lock
                         }
                     }
                     // Wave-cooperative insertion, one pending hit at a time: the hit is broadcast, lane j < 16 owns
@@ -431,20 +430,26 @@ __global__ __launch_bounds__(512, 2) void lvs_tile2_kernel(const LvsTileArgs a) 
                         const uint32_t khi = __builtin_amdgcn_readlane((uint32_t)(key >> 32), src);
                         const u64 ukey = ((u64)khi << 32) | klo;
                         const int uq = __builtin_amdgcn_readlane(q, src);
-                        if (lane == 0) {
-                            uint32_t expect = 0;
-                            while (!__hip_atomic_compare_exchange_strong(&locks[uq], &expect, 1u, __ATOMIC_ACQUIRE,
-                                                                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))
-                                expect = 0;
-                        }
-                        __builtin_amdgcn_wave_barrier();
+                        // Lock + slot reads under ONE wait: lane 0 issues the compare-and-swap, lanes < k issue their
+                        // slot reads right behind it.  LDS executes a wave's DS instructions in order, so when the
+                        // swap succeeded the reads saw the list under the lock; otherwise everything is retried.
                         u64* UL = lists + uq * KCAP;
-                        u64 newv = 0;
-                        if (lane < k) {
-                            const u64 mine = UL[lane];
-                            const u64 prev = lane > 0 ? UL[lane - 1] : ~0ull;
-                            newv = mine > ukey ? mine : (prev > ukey ? ukey : prev);
+                        u64 mine = 0, prev = ~0ull;
+                        for (;;) {
+                            uint32_t seen = 0;
+                            if (lane == 0) {
+                                __hip_atomic_compare_exchange_strong(&locks[uq], &seen, 1u, __ATOMIC_RELAXED,
+                                                                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            }
+                            asm volatile("" ::: "memory");  // keep the reads behind the swap in program order
+                            if (lane < k) {
+                                mine = UL[lane];
+                                if (lane > 0) prev = UL[lane - 1];
+                            }
+                            if (__builtin_amdgcn_readfirstlane(seen) == 0) break;  // lock word was 0: we own it
                         }
+                        u64 newv = 0;
+                        if (lane < k) newv = mine > ukey ? mine : (prev > ukey ? ukey : prev);
                         __builtin_amdgcn_wave_barrier();
                         if (lane < k) UL[lane] = newv;
                         const uint32_t ntau = __builtin_amdgcn_readlane((uint32_t)(newv >> 32), k - 1);
