@@ -1,0 +1,169 @@
+// Design-space probe (development aid, not part of the library): the tile kernel's main loop WITHOUT any top-k, as a
+// plain C[q][j] max-reduction GEMM, templated on the wave layout.  Build + run on the GPU box:
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/probe_gemm.hip -o /tmp/probe_gemm && /tmp/probe_gemm
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef const __attribute__((address_space(1))) void gbl_void_t;
+
+#define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
+
+constexpr int BC = 256, BQ = 256, BK = 64, ROWB = 128, STAGE = (BC + BQ) * ROWB;
+
+__device__ inline void glds16(const void* g, void* l) {
+    __builtin_amdgcn_global_load_lds((gbl_void_t*)g, (lds_void_t*)l, 16, 0, 0);
+}
+
+// WM x WN waves, each wave MI x NI accumulator blocks of 32x32:  WM*MI*32 == 256, WN*NI*32 == 256
+template <int WM, int WN, int MI, int NI, int WPE>
+__global__ __launch_bounds__(WM * WN * 64, WPE) void gemm_probe(const _Float16* __restrict__ xb, const _Float16* __restrict__ xq,
+                                                                 float* __restrict__ out, int ntiles, int nk, long long ld) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NW = WM * WN;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const long long q0 = (long long)blockIdx.x * BQ;
+    constexpr int RPW = 512 / NW;        // staged rows per wave per K-step (corpus + queries)
+    constexpr int GL = RPW / 8;          // glds per wave per K-step
+    // wave stages rows [wave*RPW, +RPW) of the 512-row (corpus | query) stack
+    unsigned loff[GL];
+    const char* sbase[GL];
+#pragma unroll
+    for (int i = 0; i < GL; ++i) {
+        int row = wave * RPW + i * 8 + (lane >> 3);
+        int col = ((lane & 7) ^ ((row >> 1) & 7)) * 8;
+        bool isq = row >= BC;
+        long long grow = isq ? q0 + (row - BC) : row;
+        loff[i] = (unsigned)((grow * ld + col) * 2);
+        sbase[i] = (const char*)(isq ? xq : xb);
+    }
+    int foff[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk)
+        foff[kk] = (lane & 31) * ROWB + ((((kk * 2) + (lane >> 5)) ^ (((lane & 31) >> 1) & 7)) << 4);
+    const int a_base = wm * MI * 32 * ROWB;
+    const int b_base = BC * ROWB + wn * NI * 32 * ROWB;
+    f32x16 acc[MI][NI];
+    float best[NI];
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) best[ni] = -1e30f;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+    const int T = ntiles * nk;
+    auto issue = [&](int t, int buf) {
+        int ti = t / nk, ks = t - ti * nk;
+#pragma unroll
+        for (int i = 0; i < GL; ++i) {
+            int row = wave * RPW + i * 8;
+            bool isq = row >= BC;
+            long long tile_off = isq ? 0 : (long long)ti * BC * ld * 2;
+            glds16(sbase[i] + tile_off + loff[i] + ks * BK * 2, smem + buf * STAGE + row * ROWB);
+        }
+    };
+    issue(0, 0);
+    int ksin = 0;
+    for (int t = 0; t < T; ++t) {
+        const int buf = t & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const char* sb = smem + buf * STAGE;
+        const int tn = t + 1 < T ? t + 1 : T - 1;
+        const int nti = tn / nk, nks = tn - nti * nk;
+        half8 Bf[2][NI], Af[3];
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) Bf[0][ni] = *(const half8*)(sb + b_base + ni * 32 * ROWB + foff[0]);
+        Af[0] = *(const half8*)(sb + a_base + foff[0]);
+        if (MI > 1) Af[1] = *(const half8*)(sb + a_base + 32 * ROWB + foff[0]);
+        constexpr int NF = 4 * MI;
+#pragma unroll
+        for (int f = 0; f < NF; ++f) {
+            const int kk = f / MI, mi = f % MI;
+            if (f + 2 < NF) {
+                const int f2 = f + 2;
+                Af[f2 % 3] = *(const half8*)(sb + a_base + (f2 % MI) * 32 * ROWB + foff[f2 / MI]);
+            } else if (MI == 1 && f + 1 < NF) {
+            }
+            if (mi == (MI > 1 ? 1 : 0) && kk + 1 < 4) {
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) Bf[(kk + 1) & 1][ni] = *(const half8*)(sb + b_base + ni * 32 * ROWB + foff[kk + 1]);
+            }
+            if (f < GL) {
+                int row = wave * RPW + f * 8;
+                bool isq = row >= BC;
+                long long tile_off = isq ? 0 : (long long)nti * BC * ld * 2;
+                glds16(sbase[f] + tile_off + loff[f] + nks * BK * 2, smem + (buf ^ 1) * STAGE + row * ROWB);
+            }
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Af[f % 3], Bf[kk & 1][ni], acc[mi][ni], 0, 0, 0);
+        }
+        if (++ksin < nk) continue;
+        ksin = 0;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) best[ni] = fmaxf(best[ni], acc[mi][ni][r]);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+            }
+    }
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) out[((long long)blockIdx.x * NW + wave) * 64 * NI + ni * 64 + lane] = best[ni];
+}
+
+template <int WM, int WN, int MI, int NI, int WPE>
+void run(const char* name, const _Float16* xb, const _Float16* xq, float* out, int nqt, int ntiles, int nk, long long ld) {
+    auto k = gemm_probe<WM, WN, MI, NI, WPE>;
+    CHECK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE));
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0));
+    CHECK(hipEventCreate(&e1));
+    float best = 1e30f;
+    for (int it = 0; it < 4; ++it) {
+        CHECK(hipEventRecord(e0));
+        hipLaunchKernelGGL(k, dim3(nqt), dim3(WM * WN * 64), 2 * STAGE, 0, xb, xq, out, ntiles, nk, ld);
+        CHECK(hipEventRecord(e1));
+        CHECK(hipEventSynchronize(e1));
+        float ms;
+        CHECK(hipEventElapsedTime(&ms, e0, e1));
+        if (it > 0 && ms < best) best = ms;
+    }
+    double fl = 2.0 * nqt * 256.0 * ntiles * 256.0 * nk * 64.0;
+    printf("%-28s %8.2f ms  %7.1f TFLOP/s\n", name, best, fl / (best * 1e-3) / 1e12);
+    fflush(stdout);
+}
+
+int main() {
+    const int d = 768, nk = d / 64;
+    const int nqt = 2048 * 2;             // 4096 query tiles of 256 = 1M queries (16 blocks per CU)
+    const int ntiles = 256;               // 65 536 corpus rows per block
+    const long long nq = (long long)nqt * 256, nb = (long long)ntiles * 256;
+    std::vector<_Float16> h((size_t)(nq > nb ? nq : nb) * d);
+    srand(1);
+    for (auto& v : h) v = (_Float16)((rand() % 2001 - 1000) / 1000.0f * 0.06f);
+    _Float16 *xb, *xq;
+    float* out;
+    CHECK(hipMalloc(&xb, nb * d * 2));
+    CHECK(hipMalloc(&xq, nq * d * 2));
+    CHECK(hipMalloc(&out, (size_t)nqt * 16 * 64 * 4 * 4));
+    CHECK(hipMemcpy(xb, h.data(), nb * d * 2, hipMemcpyHostToDevice));
+    CHECK(hipMemcpy(xq, h.data(), nq * d * 2, hipMemcpyHostToDevice));
+    run<2, 4, 4, 2, 2>("8 waves 2x4, 128x64/wave", xb, xq, out, nqt, ntiles, nk, d);
+    run<4, 2, 2, 4, 2>("8 waves 4x2, 64x128/wave", xb, xq, out, nqt, ntiles, nk, d);
+    run<2, 2, 4, 4, 1>("4 waves 2x2, 128x128/wave", xb, xq, out, nqt, ntiles, nk, d);
+    run<4, 4, 2, 2, 4>("16 waves 4x4, 64x64/wave", xb, xq, out, nqt, ntiles, nk, d);
+    run<1, 8, 8, 1, 2>("8 waves 1x8, 256x32/wave", xb, xq, out, nqt, ntiles, nk, d);
+    return 0;
+}
