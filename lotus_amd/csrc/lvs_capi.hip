@@ -359,6 +359,7 @@ int make_plan(int64_t nq, int64_t nb, int32_t d, int32_t xb_pack, int32_t xq_pac
     off += lvs_round_up((int64_t)p.nslab * nq * p.kpass * 8, 256);
     p.off_pass = off;  // [nq][kpass] merged keys of one pass (multi-pass only)
     off += p.npass > 1 ? lvs_round_up(nq * p.kpass * 8, 256) : 0;
+    off += 768ll * LVS_STREAM_MAXQ * 16 * 8;  // candidates of the small-batch streaming kernel (<= 768 workgroups)
     p.total = off;
     return LVS_OK;
 }
@@ -436,6 +437,53 @@ extern "C" int32_t lvs_flat_search_keys(const void* xb, int32_t xb_pack, int64_t
     a.gq = p.gq;
     a.debug_hot = getenv("LVS_DEBUG_HOT") ? atoi(getenv("LVS_DEBUG_HOT")) : 0;
 
+    // HBM-bound regime (the literal sem_search: one query per call): stream the corpus once, queries resident in LDS
+    {
+        const int nqseg = xq_pack == LVS_PACK_SPLIT ? 2 : 1;
+        const int jper = p.dpad / 16;
+        const bool fits = lvs_stream_lds_bytes(nqseg * jper) <= 150 * 1024;
+        const char* env = getenv("LVS_STREAM");
+        const bool want = env ? atoi(env) != 0 : true;
+        if (want && fits && nq <= LVS_STREAM_MAXQ && k <= 15 && nb >= 4096) {
+            LvsStreamArgs sa;
+            memset(&sa, 0, sizeof(sa));
+            sa.xb = xb;
+            sa.xq = xq;
+            sa.bn = xb_norms_sq;
+            sa.qn = xq_norms_sq;
+            sa.row_ids = row_ids;
+            sa.gtau = gtau;
+            sa.out = partial;
+            sa.nb = nb;
+            sa.ldb = p.ldb;
+            sa.ldq = p.ldq;
+            sa.id_offset = id_offset;
+            sa.nq = (int)nq;
+            sa.k = k;
+            sa.metric = metric;
+            sa.jper = jper;
+            sa.nseg = p.nseg;
+            sa.nj = p.nseg * jper;
+            sa.nbfrag = nqseg * jper;
+            for (int i = 0; i < 3; ++i) {
+                sa.seg_q[i] = p.seg_q[i];
+                sa.seg_c[i] = p.seg_c[i];
+                sa.seg_b[i] = p.seg_q[i] == 0 ? 0 : jper;
+            }
+            LVS_HIP_CHECK(hipMemsetAsync(gtau, 0, (size_t)nq * 4, st));
+            int nparts = 0;
+            {
+                ScopedKernelTimer timer(st);
+                LVS_HIP_CHECK(lvs_stream_launch(sa, st));
+                const int64_t nblocks = (nb + 31) / 32;
+                nparts = (int)((nblocks + sa.blocks_per_wg - 1) / sa.blocks_per_wg);
+            }
+            hipLaunchKernelGGL(merge_keys_kernel, dim3((unsigned)lvs_ceil_div(nq, 4)), dim3(256), 0, st, partial, nparts,
+                               (long long)nq, k, (u64*)out_keys, (long long)k);
+            LVS_HIP_CHECK(hipGetLastError());
+            return LVS_OK;
+        }
+    }
     for (int pass = 0; pass < p.npass; ++pass) {
         const int col0 = pass * p.kpass;
         const int kp = (k - col0) < p.kpass ? (k - col0) : p.kpass;

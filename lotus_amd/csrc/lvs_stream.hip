@@ -1,0 +1,220 @@
+// Small-batch search kernel: up to 32 queries against the whole corpus shard - the HBM-bound regime of the path
+// (the literal `sem_search` operator issues ONE query per call: lotus/sem_ops/sem_search.py:121-122 -> faiss_vs.py:75).
+//
+// Roofline: HBM.  Algorithmic bytes per launch = nb * ld * 2 (every corpus byte exactly once) + O(nq * ld);
+// at 1 M x 768 fp16 that is 1.536 GB -> 0.19 ms at 8 TB/s.  Nothing is staged through LDS except the queries:
+//   * the <= 32 queries live in LDS for the whole kernel, laid out as ready-made MFMA B fragments
+//     ([K/16][64 lanes][16 B], lane-linear -> conflict-free ds_read_b128);
+//   * corpus rows stream from HBM straight into registers as A fragments (lane (r, h) reads 16 B of row r; the two
+//     half-wave lanes of a row cover 32 contiguous bytes, four consecutive K-slices one 128-B line), 16 loads
+//     (16 KB per wave) in flight ahead of the MFMAs;
+//   * each wave owns 32-row blocks: 32 x 32 x K product on v_mfma_f32_32x32x16_f16, operands swapped as in the tile
+//     kernels (corpus = A, queries = B) so that a lane owns one query column and its threshold is a register;
+//   * hits go through the same wave-cooperative sorted insertion into per-query lists (LDS, 32 x 16 slots, one lock
+//     per query because the 4 waves of a workgroup share the queries); thresholds are shared across workgroups
+//     through the global per-query word; every workgroup writes its k candidates and lvs_merge_keys finishes.
+#include <stdlib.h>
+
+#include "lvs_common.h"
+#include "lvs_tile.h"
+
+namespace {
+
+constexpr int SQ = 32;          // queries per launch
+constexpr int WAVES = 4;        // waves per workgroup
+constexpr int KCAP = 16;        // list slots per query (k <= 15)
+constexpr int UNROLL = 16;      // A-fragment loads in flight per wave (16 x 1 KB)
+
+__device__ inline float tau_float(uint32_t ord) { return ord == 0 ? -INFINITY : lvs_unord32(ord); }
+
+__device__ inline float max16(const f32x16& v) {
+    float a = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
+    float b = fmaxf(fmaxf(v[4], v[5]), fmaxf(v[6], v[7]));
+    float c = fmaxf(fmaxf(v[8], v[9]), fmaxf(v[10], v[11]));
+    float d = fmaxf(fmaxf(v[12], v[13]), fmaxf(v[14], v[15]));
+    return fmaxf(fmaxf(a, b), fmaxf(c, d));
+}
+
+}  // namespace
+
+__global__ __launch_bounds__(WAVES * 64, 2) void lvs_stream_kernel(const LvsStreamArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    half8* bfrag = (half8*)smem;                                       // [nbfrag][64]
+    u64* lists = (u64*)(smem + (size_t)a.nbfrag * 1024);               // [SQ][KCAP]
+    uint32_t* locks = (uint32_t*)(smem + (size_t)a.nbfrag * 1024 + SQ * KCAP * 8);  // [SQ]
+    const int k = a.k;
+
+    // ---- queries -> LDS as B fragments: fragment j, lane l = query (l & 31), halfs seg_q + jj*16 + (l>>5)*8 .. +8
+    const _Float16* xq = (const _Float16*)a.xq;
+    for (int idx = tid; idx < a.nbfrag * 64; idx += WAVES * 64) {
+        const int f = idx >> 6, l = idx & 63;
+        const int part = f / a.jper, jj = f - part * a.jper;  // part 0: columns [0, dpad), part 1: [dpad, 2 dpad)
+        int qrow = l & 31;
+        if (qrow > a.nq - 1) qrow = a.nq - 1;
+        bfrag[idx] = *(const half8*)(xq + (long long)qrow * a.ldq + part * a.jper * 16 + jj * 16 + (l >> 5) * 8);
+    }
+    for (int i = tid; i < SQ * KCAP; i += WAVES * 64) lists[i] = 0;
+    if (tid < SQ) locks[tid] = 0;
+    __syncthreads();
+
+    const int q = lane & 31;  // this lane's query
+    const bool qvalid = q < a.nq;
+    float tauf = -INFINITY;
+    uint32_t gord = 0;
+    const float qnv = (a.metric == LVS_METRIC_L2 && qvalid) ? a.qn[q] : 0.f;
+
+    const _Float16* xb = (const _Float16*)a.xb;
+    const long long nblocks = (a.nb + 31) / 32;
+    const long long b0 = (long long)blockIdx.x * a.blocks_per_wg;
+    const long long b1 = b0 + a.blocks_per_wg < nblocks ? b0 + a.blocks_per_wg : nblocks;
+    const int nj = a.nj, jper = a.jper;
+
+    for (long long blk = b0 + wave; blk < b1; blk += WAVES) {
+        const long long row0 = blk * 32;
+        long long arow = row0 + (lane & 31);
+        if (arow > a.nb - 1) arow = a.nb - 1;
+        const _Float16* ap = xb + arow * a.ldb + (lane >> 5) * 8;  // + seg_c[seg] + jj * 16
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        // software pipeline: UNROLL fragments in flight
+        half8 abuf[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            const int j = u < nj ? u : nj - 1;
+            const int seg = j / jper, jj = j - seg * jper;
+            abuf[u] = *(const half8*)(ap + a.seg_c[seg] + jj * 16);
+        }
+        for (int j0 = 0; j0 < nj; j0 += UNROLL) {
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) {
+                const int j = j0 + u;
+                const half8 av = abuf[u];
+                // refill this slot with the fragment UNROLL steps ahead (clamped; surplus loads are harmless)
+                int jn = j + UNROLL;
+                jn = jn < nj ? jn : nj - 1;
+                const int segn = jn / jper, jjn = jn - segn * jper;
+                abuf[u] = *(const half8*)(ap + a.seg_c[segn] + jjn * 16);
+                if (j < nj) {
+                    const int sg = j / jper;
+                    const half8 bv = bfrag[(a.seg_b[sg] + j - sg * jper) * 64 + lane];
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bv, acc, 0, 0, 0);
+                }
+            }
+        }
+        // ---- block epilogue: 32 rows x 32 queries; lane holds query q, rows row0 + (r&3) + 8*(r>>2) + 4*(lane>>5)
+        const long long rbase = row0 + 4 * (lane >> 5);
+        if (a.metric == LVS_METRIC_L2) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const long long row = rbase + (r & 3) + 8 * (r >> 2);
+                const float bnv = row < a.nb ? a.bn[row] : 0.f;
+                acc[r] = -fmaxf((qnv + bnv) - 2.0f * acc[r], 0.f);
+            }
+        }
+        {
+            const uint32_t lo = (uint32_t)(lists[q * KCAP + k - 1] >> 32);
+            tauf = fmaxf(tauf, tau_float(lo));
+        }
+        const bool th = qvalid && (max16(acc) >= tauf);
+        if (__any(th)) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float s = acc[r];
+                bool pending = false;
+                u64 key = 0;
+                if (th && s >= tauf) {
+                    const long long row = rbase + (r & 3) + 8 * (r >> 2);
+                    if (row < a.nb) {
+                        const uint32_t id = a.row_ids ? a.row_ids[row] : (uint32_t)(row + a.id_offset);
+                        key = lvs_pack_key(s, id);
+                        pending = (uint32_t)(key >> 32) >= gord;
+                    }
+                }
+                unsigned long long pm = __ballot(pending);
+                while (pm) {  // wave-cooperative sorted insertion (see lvs_tile2.hip)
+                    const int src = __ffsll((long long)pm) - 1;
+                    pm &= pm - 1;
+                    const uint32_t klo = __builtin_amdgcn_readlane((uint32_t)key, src);
+                    const uint32_t khi = __builtin_amdgcn_readlane((uint32_t)(key >> 32), src);
+                    const u64 ukey = ((u64)khi << 32) | klo;
+                    const int uq = __builtin_amdgcn_readlane(q, src);
+                    u64* UL = lists + uq * KCAP;
+                    u64 mine = 0, prev = ~0ull;
+                    for (;;) {
+                        uint32_t seen = 0;
+                        if (lane == 0)
+                            __hip_atomic_compare_exchange_strong(&locks[uq], &seen, 1u, __ATOMIC_RELAXED,
+                                                                 __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        asm volatile("" ::: "memory");
+                        if (lane < k) {
+                            mine = UL[lane];
+                            if (lane > 0) prev = UL[lane - 1];
+                        }
+                        if (__builtin_amdgcn_readfirstlane(seen) == 0) break;
+                    }
+                    u64 newv = 0;
+                    if (lane < k) newv = mine > ukey ? mine : (prev > ukey ? ukey : prev);
+                    __builtin_amdgcn_wave_barrier();
+                    if (lane < k) UL[lane] = newv;
+                    const uint32_t ntau = __builtin_amdgcn_readlane((uint32_t)(newv >> 32), k - 1);
+                    if (lane == 0) __hip_atomic_store(&locks[uq], 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (q == uq) tauf = fmaxf(tauf, tau_float(ntau));
+                }
+            }
+        }
+        // exchange thresholds with the other workgroups every 32 blocks of this wave (the global load drains the
+        // in-flight fragment loads - vmcnt is in-order - so this must stay rare)
+        if ((((blk - b0) / WAVES) & 31) == 31 && qvalid && lane < 32) {
+            const uint32_t lo = (uint32_t)(lists[q * KCAP + k - 1] >> 32);
+            if (lo > gord) atomicMax(&a.gtau[q], lo);
+            const uint32_t g = a.gtau[q];
+            gord = g > gord ? g : gord;
+        }
+        {
+            const uint32_t gl = __shfl(gord, lane & 31, 64);  // lanes l and l+32 share the query
+            gord = gl > gord ? gl : gord;
+        }
+        tauf = fmaxf(tauf, tau_float(gord));
+    }
+    __syncthreads();
+    for (int i = tid; i < a.nq * k; i += WAVES * 64) {
+        const int qq = i / k, j = i - qq * k;
+        a.out[((long long)blockIdx.x * a.nq + qq) * k + j] = lists[qq * KCAP + j];
+    }
+    if (tid < a.nq) {
+        const uint32_t lo = (uint32_t)(lists[tid * KCAP + k - 1] >> 32);
+        if (lo) atomicMax(&a.gtau[tid], lo);
+    }
+}
+
+// host side -----------------------------------------------------------------------------------------------------
+int lvs_stream_blocks(int64_t nb) {
+    const int64_t nblocks = (nb + 31) / 32;
+    int64_t wgs = 256;  // one per CU: fewest partial lists to merge, cold start amortised over ~120 row blocks
+    if (const char* e = getenv("LVS_STREAM_WGS")) wgs = atoll(e) > 0 ? atoll(e) : wgs;  // tuning override
+    if (wgs > (nblocks + 3) / 4) wgs = (nblocks + 3) / 4;
+    if (wgs < 1) wgs = 1;
+    return (int)wgs;
+}
+
+size_t lvs_stream_lds_bytes(int nbfrag) { return (size_t)nbfrag * 1024 + SQ * KCAP * 8 + SQ * 4; }
+
+hipError_t lvs_stream_launch(LvsStreamArgs& a, hipStream_t stream) {
+    const int64_t nblocks = (a.nb + 31) / 32;
+    const int wgs = lvs_stream_blocks(a.nb);
+    a.blocks_per_wg = (int)((nblocks + wgs - 1) / wgs);
+    const int grid = (int)((nblocks + a.blocks_per_wg - 1) / a.blocks_per_wg);
+    const size_t lds = (size_t)a.nbfrag * 1024 + SQ * KCAP * 8 + SQ * 4;
+    static size_t attr_bytes = 0;
+    if (lds > attr_bytes) {
+        hipError_t e = hipFuncSetAttribute((const void*)lvs_stream_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)lds);
+        if (e != hipSuccess) return e;
+        attr_bytes = lds;
+    }
+    hipLaunchKernelGGL(lvs_stream_kernel, dim3(grid), dim3(WAVES * 64), lds, stream, a);
+    return hipGetLastError();
+}

@@ -56,3 +56,28 @@ struct LvsTileArgs {
 int lvs_tile_grid_blocks(int nqt, int nslab, int gq);
 hipError_t lvs_tile_launch(int mode, const LvsTileArgs& a, hipStream_t stream);
 hipError_t lvs_tile2_launch(int mode, const LvsTileArgs& a, hipStream_t stream);
+
+// ---- small-batch streaming kernel (lvs_stream.hip): nq <= 32, k <= 15 ----
+#define LVS_STREAM_MAXQ 32
+struct LvsStreamArgs {
+    const void* xb;
+    const void* xq;
+    const float* bn;
+    const float* qn;
+    const uint32_t* row_ids;
+    uint32_t* gtau;  // [nq] zero-initialised
+    u64* out;        // [nblocks][nq][k]
+    long long nb, ldb, ldq, id_offset;
+    int nq, k, metric;
+    int nj;                  // MFMAs per 32-row block = nseg * dpad / 16
+    int jper;                // dpad / 16
+    int nseg;
+    int seg_q[3], seg_c[3];  // column offsets (halfs) of each K segment
+    int seg_b[3];            // first B-fragment index of each K segment (segments sharing query columns share fragments)
+    int nbfrag;              // B fragments held in LDS
+    int blocks_per_wg;       // 32-row blocks per workgroup (contiguous)
+};
+
+int lvs_stream_blocks(int64_t nb);
+size_t lvs_stream_lds_bytes(int nbfrag);
+hipError_t lvs_stream_launch(LvsStreamArgs& a, hipStream_t stream);

@@ -81,6 +81,31 @@ def test_mixed_precision_operands(hip_backend, cmode, qmode, k):
         assert err <= 3e-5 and hard == 0 and recall >= 0.9999
 
 
+@pytest.mark.parametrize("nq,nb,d,k,mode,metric", [
+    (1, 100_000, 768, 10, F16, IP),    # the literal sem_search call
+    (7, 50_001, 384, 5, SPLIT, IP),    # fp32-accurate path, ragged row count
+    (32, 30_000, 100, 15, F16, IP),    # full query block, padded d, largest k
+    (3, 20_000, 768, 1, F16, L2),
+    (20, 40_000, 256, 10, SPLIT, L2),
+])
+def test_small_batch_streaming_kernel(hip_backend, nq, nb, d, k, mode, metric):
+    """nq <= 32 takes the HBM-streaming kernel (lvs_stream.hip): same results as the tile kernels / the oracle."""
+    xb = synth.corpus(nb, d, seed=nb % 89)
+    xq, _ = synth.queries(xb, nq, seed=13)
+    if metric == L2:
+        xb = xb * 1.4
+    D, I, _ = _run(hip_backend, xb, xq, k, mode, metric)
+    Dr, Ir = oracle.flat_search(_stored(xb, mode), _stored(xq, mode), k, metric)
+    atol = 1e-5 if metric == IP else 4e-5
+    err, hard, recall = synth.compare_topk(Dr, Ir, D, I, atol=atol)
+    assert err <= atol and hard == 0 and recall == 1.0
+    # duplicates: exact ties keep the oracle's id order on this path too
+    xd = np.concatenate([xb[:5000], xb[:5000]])
+    D, I, _ = _run(hip_backend, xd, xq, min(k, 8), mode, metric)
+    Dr, Ir = oracle.flat_search(_stored(xd, mode), _stored(xq, mode), min(k, 8), metric)
+    assert np.array_equal(I, Ir)
+
+
 def test_duplicates_follow_the_total_order(hip_backend):
     """Exact duplicate rows give exactly equal scores; ids must come back ascending inside each tie group."""
     base = synth.corpus(50, 128, seed=5)
