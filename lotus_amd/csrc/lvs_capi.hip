@@ -338,7 +338,8 @@ int make_plan(int64_t nq, int64_t nb, int32_t d, int32_t xb_pack, int32_t xq_pac
     const int gs = 32 / p.gq;
     // enough (query tile, slab) items to load-balance 256 CUs, slabs kept >= 32 tiles, a multiple of gs slabs
     int64_t want = lvs_ceil_div(4096, p.nqt);
-    int64_t max_slabs = lvs_ceil_div(p.ntiles, 32);
+    // few query tiles: allow slabs down to 8 tiles so that every CU gets work (cold starts are cheap)
+    int64_t max_slabs = lvs_ceil_div(p.ntiles, p.nqt >= 8 ? 32 : (p.nqt >= 2 ? 16 : 8));
     int64_t s = want < 1 ? 1 : want;
     if (s > max_slabs) s = max_slabs;
     s = lvs_round_up(s, gs);
