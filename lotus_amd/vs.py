@@ -105,7 +105,17 @@ class HipVS(VS):
         return _capi.PACK_F16 if np.dtype(dtype) == np.float16 else _capi.PACK_SPLIT
 
     @staticmethod
-    def _as_matrix(x, what: str) -> np.ndarray:
+    def _is_device_tensor(x) -> bool:
+        return hasattr(x, "is_cuda") and hasattr(x, "data_ptr") and bool(x.is_cuda)
+
+    @staticmethod
+    def _as_matrix(x, what: str):
+        if HipVS._is_device_tensor(x):  # embeddings that never left the GPU
+            if x.dim() == 1:
+                x = x[None, :]
+            if x.dim() != 2:
+                raise ValueError(f"{what} must be a 2-D tensor, got shape {tuple(x.shape)}")
+            return x
         x = np.asarray(x)
         if x.ndim == 1:
             x = x[None, :]
@@ -120,8 +130,10 @@ class HipVS(VS):
         rank, world = self._dist()
         per = -(-n // world) if n else 0
         lo, hi = min(n, rank * per), min(n, (rank + 1) * per)
-        packed = self.backend.pack(vecs[lo:hi], self._pack_mode(vecs.dtype))
-        ent = _Resident(vecs=vecs, packed=packed, n=n, d=d, lo=lo, hi=hi)
+        is_dev = self._is_device_tensor(vecs)
+        dtype = np.float16 if (is_dev and str(vecs.dtype) == "torch.float16") else (np.float32 if is_dev else vecs.dtype)
+        packed = self.backend.pack(vecs[lo:hi], self._pack_mode(dtype))
+        ent = _Resident(vecs=None if is_dev else vecs, packed=packed, n=n, d=d, lo=lo, hi=hi)
         self._resident[index_dir] = ent
         self._resident.move_to_end(index_dir)
         while len(self._resident) > self._max_resident:
@@ -136,14 +148,16 @@ class HipVS(VS):
     # ---------------------------------------------------------------------------------------- plugin methods
     def index(self, docs, embeddings, index_dir: str, **kwargs: dict[str, Any]) -> None:
         """Build the index from ``embeddings`` and persist it (``faiss_vs.py:22-30``).  ``docs`` is unused, as in
-        ``FaissVS``."""
+        ``FaissVS``.  ``embeddings`` may also be a CUDA tensor straight from an encoder (no host round trip for the
+        device image); ``persist=False`` skips writing ``vecs`` / ``index`` to disk."""
         emb = self._as_matrix(embeddings, "embeddings")
         os.makedirs(index_dir, exist_ok=True)
         rank, _ = self._dist()
-        if rank == 0:
+        if rank == 0 and kwargs.get("persist", True):
+            host = emb.cpu().numpy() if self._is_device_tensor(emb) else emb
             with open(os.path.join(index_dir, "vecs"), "wb") as fp:
-                pickle.dump(embeddings if isinstance(embeddings, np.ndarray) else emb, fp)
-            faiss_io.write_index_flat(os.path.join(index_dir, "index"), emb, self.metric)
+                pickle.dump(embeddings if isinstance(embeddings, np.ndarray) else host, fp)
+            faiss_io.write_index_flat(os.path.join(index_dir, "index"), host, self.metric)
         self._install(index_dir, emb)
         self.index_dir = index_dir
 
@@ -182,7 +196,8 @@ class HipVS(VS):
         K = int(K)
         if K < 0:
             raise ValueError("K must be >= 0")
-        nq = q.shape[0]
+        nq = int(q.shape[0])
+        return_device = bool(kwargs.get("return_device", False))
         pad_d = -FLT_MAX if self.metric == METRIC_INNER_PRODUCT else FLT_MAX
         if K == 0 or nq == 0:
             return RMOutput(distances=np.full((nq, K), pad_d, np.float32), indices=np.full((nq, K), -1, np.int64))
@@ -229,9 +244,27 @@ class HipVS(VS):
         if world > 1:
             keys = self._allgather_merge(keys, world)
         Dd, Id = be.keys_to_result(keys, self.metric, id_map)
+        if return_device and k_eff == K:  # results stay in HBM (torch tensors) for a GPU-side consumer
+            return RMOutput(distances=Dd, indices=Id)
         D[:, :k_eff] = Dd.cpu().numpy()
         I[:, :k_eff] = Id.cpu().numpy()
         return RMOutput(distances=D, indices=I)
+
+    def scores(self, query_vectors, ids: list[int] | None = None):
+        """Similarity of every query to every indexed row (or to rows ``ids``) as one float32 matrix [Q, N] - what
+        the K = N callers actually want (``sem_filter.py:491-497`` takes ``vec_scores`` of ALL rows,
+        ``sem_join.py:343-373`` clips them to [0, 1]) without ranking anything.  Inner product:
+        the product; L2: minus the squared distance."""
+        ent = self._current()
+        if ent.lo != 0 or ent.hi != ent.n:
+            raise ValueError("scores() needs an unsharded index")
+        q = self._as_matrix(query_vectors, "query_vectors")
+        if q.shape[1] != ent.d:
+            raise ValueError(f"query dimension {q.shape[1]} does not match index dimension {ent.d}")
+        be = self.backend
+        corpus = self.packed_rows(ids)
+        queries = be.pack(q, ent.packed.mode)
+        return be.scores(corpus, queries, self.metric).cpu().numpy()
 
     def packed_rows(self, ids=None):
         """Device image (backend ``PackedRows``) of the current index restricted to positional ``ids`` (all rows

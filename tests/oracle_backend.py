@@ -85,6 +85,13 @@ class OracleBackend:
         D, I = _finish(k, metric, None if id_map is None else id_map.numpy())
         return torch.from_numpy(D), torch.from_numpy(I)
 
+    def scores(self, corpus, queries, metric):
+        xb, xq = corpus.rows.numpy(), queries.rows.numpy()
+        s = xq @ xb.T
+        if metric == 1:
+            s = -np.maximum((queries.norms.numpy()[:, None] + corpus.norms.numpy()[None, :]) - 2 * s, 0)
+        return torch.from_numpy(s.astype(np.float32))
+
     def rank_all(self, corpus, queries, metric, id_offset=0):
         return self.search_keys(corpus, queries, corpus.n, metric, id_offset=id_offset)
 

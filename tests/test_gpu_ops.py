@@ -126,3 +126,31 @@ def test_dedup_at_scale_finds_planted_duplicate_chains(hip_backend):
     vals = [f"row{r}" for r in range(len(x))]
     keep = keep_mask(vals, i, j)
     assert int((~keep).sum()) == 15_000 and keep[:n0].all()  # every chain collapses onto its base row
+
+
+def test_device_resident_embeddings_in_and_out(hip_backend, tmp_path):
+    """Embeddings produced on the GPU are indexed and searched without a host round trip."""
+    import torch
+
+    xb = synth.corpus(5000, 128, seed=3)
+    xq, planted = synth.queries(xb, 64, seed=4)
+    xb_d = torch.from_numpy(xb.astype(np.float16)).to(hip_backend.device)
+    xq_d = torch.from_numpy(xq.astype(np.float16)).to(hip_backend.device)
+    vs = HipVS(backend=hip_backend)
+    vs.index(None, xb_d, str(tmp_path / "dev"), persist=False)
+    assert not os.path.exists(str(tmp_path / "dev" / "vecs"))
+    out = vs(xq_d, 5, return_device=True)
+    assert torch.is_tensor(out.indices) and out.indices.is_cuda
+    Dr, Ir = oracle.flat_search(xb.astype(np.float16).astype(np.float32), xq.astype(np.float16).astype(np.float32), 5)
+    err, hard, recall = synth.compare_topk(Dr, Ir, out.distances.cpu().numpy(), out.indices.cpu().numpy())
+    assert err <= 1e-5 and hard == 0 and recall == 1.0
+    host = vs(xq, 5)  # host queries against the same device-born index
+    assert np.array_equal(host.indices, out.indices.cpu().numpy())
+    S = vs.scores(xq_d[:4])
+    assert np.allclose(S, (xq.astype(np.float16).astype(np.float32)[:4] @ xb.astype(np.float16).astype(np.float32).T),
+                       atol=2e-6)
+    vs2 = HipVS(backend=hip_backend)
+    vs2.index(None, xb_d, str(tmp_path / "dev2"))  # persisted: loads back like any other index
+    fresh = HipVS(backend=hip_backend)
+    fresh.load_index(str(tmp_path / "dev2"))
+    assert np.array_equal(fresh(xq, 5).indices, host.indices)

@@ -175,3 +175,13 @@ def test_k_equal_n_and_beyond_max_k(indexed, tmp_path):
     assert np.array_equal(out.indices, I) and any(c[0] == "search" and c[3] == 2600 for c in v2.backend.calls)
     sub = list(range(0, 2600, 1))[5:]
     assert v2(big[:2], 2595, ids=sub).indices.shape == (2, 2595)
+
+
+def test_scores_matrix_for_cascade_callers(indexed):
+    vs, xb, _ = indexed
+    xq, _ = synth.queries(xb, 5)
+    S = vs.scores(xq)
+    ref = _emulate_storage(xq, 1) @ _emulate_storage(xb, 1).T
+    assert S.shape == (5, 400) and S.dtype == np.float32 and np.allclose(S, ref, atol=1e-6)
+    sub = [3, 7, 399]
+    assert np.allclose(vs.scores(xq, ids=sub), ref[:, sub], atol=1e-6)
