@@ -187,6 +187,9 @@ __global__ __launch_bounds__(512, 2) void lvs_tile2_kernel(const LvsTileArgs a) 
     const int T = (tile1 - tile0) * nk;
     stage(0, 0);
     int ks_in_tile = 0, ti = 0;
+    // the second-dispatched half of the waves loses VALU/MFMA arbitration to the older half on every segment: one
+    // static priority raise evens it out (+2 % on the bare loop, tools/probe_gemm.hip)
+    if (wave >= 4) __builtin_amdgcn_s_setprio(1);
     uint32_t gpre[2] = {0u, 0u};  // cross-workgroup thresholds, prefetched one K-step before the tile epilogue
     for (int t = 0; t < T; ++t) {
         const int buf = t & 1;
@@ -232,7 +235,7 @@ __global__ __launch_bounds__(512, 2) void lvs_tile2_kernel(const LvsTileArgs a) 
                 const int f2 = f + 2;
                 Af[f2 % 3] = *(const half8*)(sb + a_base + (f2 & 3) * 32 * ROWB + foff[f2 >> 2]);
             }
-            if (mi == 1 && kk + 1 < 4) {
+            if (mi == 2 && kk + 1 < 4) {  // measured best position (tools/probe_gemm.hip)
                 Bf[(kk + 1) & 1][0] = *(const half8*)(sb + b_base + foff[kk + 1]);
                 Bf[(kk + 1) & 1][1] = *(const half8*)(sb + b_base + 32 * ROWB + foff[kk + 1]);
             }

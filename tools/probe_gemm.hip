@@ -20,7 +20,7 @@ __device__ inline void glds16(const void* g, void* l) {
 }
 
 // WM x WN waves, each wave MI x NI accumulator blocks of 32x32:  WM*MI*32 == 256, WN*NI*32 == 256
-template <int WM, int WN, int MI, int NI, int WPE>
+template <int WM, int WN, int MI, int NI, int WPE, int DEPTH, int BPOS, int PRIO, int SPREAD>
 __global__ __launch_bounds__(WM * WN * 64, WPE) void gemm_probe(const _Float16* __restrict__ xb, const _Float16* __restrict__ xq,
                                                                  float* __restrict__ out, int ntiles, int nk, long long ld) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -79,33 +79,36 @@ __global__ __launch_bounds__(WM * WN * 64, WPE) void gemm_probe(const _Float16* 
         const char* sb = smem + buf * STAGE;
         const int tn = t + 1 < T ? t + 1 : T - 1;
         const int nti = tn / nk, nks = tn - nti * nk;
-        half8 Bf[2][NI], Af[3];
+        half8 Bf[2][NI], Af[DEPTH + 1];
+        if (PRIO == 1) { if (wave >= NW / 2) __builtin_amdgcn_s_setprio(1); }  // static priority for the younger half
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) Bf[0][ni] = *(const half8*)(sb + b_base + ni * 32 * ROWB + foff[0]);
-        Af[0] = *(const half8*)(sb + a_base + foff[0]);
-        if (MI > 1) Af[1] = *(const half8*)(sb + a_base + 32 * ROWB + foff[0]);
         constexpr int NF = 4 * MI;
+#pragma unroll
+        for (int f = 0; f < DEPTH; ++f) Af[f] = *(const half8*)(sb + a_base + (f % MI) * 32 * ROWB + foff[f / MI]);
 #pragma unroll
         for (int f = 0; f < NF; ++f) {
             const int kk = f / MI, mi = f % MI;
-            if (f + 2 < NF) {
-                const int f2 = f + 2;
-                Af[f2 % 3] = *(const half8*)(sb + a_base + (f2 % MI) * 32 * ROWB + foff[f2 / MI]);
-            } else if (MI == 1 && f + 1 < NF) {
+            if (f + DEPTH < NF) {
+                const int f2 = f + DEPTH;
+                Af[f2 % (DEPTH + 1)] = *(const half8*)(sb + a_base + (f2 % MI) * 32 * ROWB + foff[f2 / MI]);
             }
-            if (mi == (MI > 1 ? 1 : 0) && kk + 1 < 4) {
+            if (mi == BPOS && kk + 1 < 4) {
 #pragma unroll
                 for (int ni = 0; ni < NI; ++ni) Bf[(kk + 1) & 1][ni] = *(const half8*)(sb + b_base + ni * 32 * ROWB + foff[kk + 1]);
             }
-            if (f < GL) {
-                int row = wave * RPW + f * 8;
+            if ((SPREAD ? ((f & 1) == 0 && (f >> 1) < GL) : (f < GL))) {
+                const int gi = SPREAD ? (f >> 1) : f;
+                int row = wave * RPW + gi * 8;
                 bool isq = row >= BC;
                 long long tile_off = isq ? 0 : (long long)nti * BC * ld * 2;
-                glds16(sbase[f] + tile_off + loff[f] + nks * BK * 2, smem + (buf ^ 1) * STAGE + row * ROWB);
+                glds16(sbase[gi] + tile_off + loff[gi] + nks * BK * 2, smem + (buf ^ 1) * STAGE + row * ROWB);
             }
+            if (PRIO == 2) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni)
-                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Af[f % 3], Bf[kk & 1][ni], acc[mi][ni], 0, 0, 0);
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Af[f % (DEPTH + 1)], Bf[kk & 1][ni], acc[mi][ni], 0, 0, 0);
+            if (PRIO == 2) __builtin_amdgcn_s_setprio(0);
         }
         if (++ksin < nk) continue;
         ksin = 0;
@@ -123,9 +126,9 @@ __global__ __launch_bounds__(WM * WN * 64, WPE) void gemm_probe(const _Float16* 
     for (int ni = 0; ni < NI; ++ni) out[((long long)blockIdx.x * NW + wave) * 64 * NI + ni * 64 + lane] = best[ni];
 }
 
-template <int WM, int WN, int MI, int NI, int WPE>
+template <int WM, int WN, int MI, int NI, int WPE, int DEPTH, int BPOS, int PRIO, int SPREAD>
 void run(const char* name, const _Float16* xb, const _Float16* xq, float* out, int nqt, int ntiles, int nk, long long ld) {
-    auto k = gemm_probe<WM, WN, MI, NI, WPE>;
+    auto k = gemm_probe<WM, WN, MI, NI, WPE, DEPTH, BPOS, PRIO, SPREAD>;
     CHECK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE));
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0));
@@ -160,10 +163,11 @@ int main() {
     CHECK(hipMalloc(&out, (size_t)nqt * 16 * 64 * 4 * 4));
     CHECK(hipMemcpy(xb, h.data(), nb * d * 2, hipMemcpyHostToDevice));
     CHECK(hipMemcpy(xq, h.data(), nq * d * 2, hipMemcpyHostToDevice));
-    run<2, 4, 4, 2, 2>("8 waves 2x4, 128x64/wave", xb, xq, out, nqt, ntiles, nk, d);
-    run<4, 2, 2, 4, 2>("8 waves 4x2, 64x128/wave", xb, xq, out, nqt, ntiles, nk, d);
-    run<2, 2, 4, 4, 1>("4 waves 2x2, 128x128/wave", xb, xq, out, nqt, ntiles, nk, d);
-    run<4, 4, 2, 2, 4>("16 waves 4x4, 64x64/wave", xb, xq, out, nqt, ntiles, nk, d);
-    run<1, 8, 8, 1, 2>("8 waves 1x8, 256x32/wave", xb, xq, out, nqt, ntiles, nk, d);
+    for (int rep = 0; rep < 2; ++rep) {
+        run<2, 4, 4, 2, 2, 2, 2, 0, 0>("base (B at mi=2)", xb, xq, out, nqt, ntiles, nk, d);
+        run<2, 4, 4, 2, 2, 2, 2, 1, 0>("static prio younger half", xb, xq, out, nqt, ntiles, nk, d);
+        run<2, 4, 4, 2, 2, 2, 2, 2, 0>("setprio around MFMA pairs", xb, xq, out, nqt, ntiles, nk, d);
+        run<2, 4, 4, 2, 2, 2, 2, 0, 1>("staging loads spread over 16 steps", xb, xq, out, nqt, ntiles, nk, d);
+    }
     return 0;
 }
