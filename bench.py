@@ -61,6 +61,7 @@ def make_data(torch, device, n, d, nq):
 
 def main():
     args = parse()
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on this driver; before any HIP call
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -78,7 +79,6 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=device)  # RCCL
 
     from lotus_amd import _capi
