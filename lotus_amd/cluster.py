@@ -134,6 +134,9 @@ def cluster(col_name: str, ncentroids: int):
                 f"Number of centroids must be less than number of documents. {ncentroids} > {len(df)}")
         rm = lotus.settings.rm
         vs = lotus.settings.vs
+        if vs is not None and not hasattr(vs, "packed_rows") and _ORIGINAL is not None:
+            # another vector store is configured (e.g. FaissVS): leave its k-means to the reference implementation
+            return _ORIGINAL(col_name, ncentroids)(df, niter, verbose, method)
         if rm is None or vs is None:
             raise ValueError(
                 "The retrieval model must be an instance of RM, and the vector store must be an instance of VS. "

@@ -116,3 +116,38 @@ def sem_dedup(df: pd.DataFrame, col_name: str, threshold: float, rm=None, vs=Non
     i, j, _ = _dedup.threshold_pairs(vs.backend, packed, threshold, vs.metric, shard=shard)
     mask = _dedup.keep_mask(df[col_name].tolist(), i, j)
     return df[mask]
+
+
+def sem_cluster_by(df: pd.DataFrame, col_name: str, ncentroids: int, niter: int = 20, verbose: bool = False,
+                   rm=None, vs=None) -> pd.DataFrame:
+    """``df.sem_cluster_by`` (``sem_cluster_by.py:57-86``): adds the ``cluster_id`` column computed by the GPU k-means
+    (same checks as ``lotus.utils.cluster``)."""
+    from .cluster import kmeans
+
+    rm, vs = _settings(rm, vs)
+    if col_name not in df.columns:
+        raise ValueError(f"Column {col_name} not found in DataFrame")
+    if ncentroids > len(df):
+        raise ValueError(f"Number of centroids must be less than number of documents. {ncentroids} > {len(df)}")
+    try:
+        col_index_dir = df.attrs["index_dirs"][col_name]
+    except KeyError:
+        raise ValueError(f"Index directory for column {col_name} not found in DataFrame")
+    if vs.index_dir != col_index_dir:
+        vs.load_index(col_index_dir)
+    ids = df.index.tolist()
+    vec_set = vs.get_vectors_from_index(col_index_dir, ids)
+    packed = None
+    if hasattr(vs, "packed_rows"):
+        try:
+            packed = vs.packed_rows(ids)
+        except ValueError:
+            packed = None
+    res = kmeans(vec_set, ncentroids, niter=niter, backend=getattr(vs, "backend", None), packed=packed,
+                 pack_mode=None if packed is None else packed.mode)
+    if verbose:
+        for it, o in enumerate(res.obj):
+            print(f"  Iteration {it} objective={o:.6g}")
+    out = df.copy()
+    out["cluster_id"] = pd.Series(res.assign, index=df.index)
+    return out

@@ -118,3 +118,63 @@ def test_ops_work_without_lotus_settings(tmp_path):
     assert out["_scores"].dtype == np.float32 and len(out) == 40
     hit = ops.sem_search(right, "R", xq[:1], 3, vs=vs, return_scores=True)
     assert hit["R"].iloc[0] == f"r{planted[0]}"
+
+
+@pytest.mark.skipif(not ref_harness.available(), reason="reference checkout not present")
+def test_install_routes_the_accessors_and_falls_back_for_other_stores(tmp_path):
+    lotus = ref_harness.import_lotus()
+    from lotus.models.rm import RM
+    from lotus.vector_store.faiss_vs import FaissVS
+
+    import fake_rm
+    import lotus_amd
+    from lotus_amd import HipVS
+
+    words = sum(fake_rm.TOPICS.values(), [])
+    rng = np.random.default_rng(8)
+    left = [" ".join(rng.choice(words, 3)) for _ in range(30)]
+    right = [" ".join(rng.choice(words, 2)) + f" {i}" for i in range(90)]
+
+    def run(d):
+        df2 = pd.DataFrame({"R": right}).sem_index("R", d + "r")
+        j = pd.DataFrame({"L": left}).sem_sim_join(df2, left_on="L", right_on="R", K=3)
+        s = df2[df2.index % 2 == 0].sem_search("R", "history cooking", K=4, return_scores=True)
+        c = df2.sem_cluster_by("R", 3, niter=5)
+        dd = pd.DataFrame({"T": right + [t + " extra" for t in right[:10]]}).sem_index("T", d + "d").sem_dedup("T", 0.9)
+        return j, s, c, dd
+
+    lotus.settings.configure(rm=fake_rm.make_rm(RM), vs=FaissVS())
+    ref = run(str(tmp_path / "f"))
+    lotus_amd.install(accessors=True)
+    try:
+        from lotus.sem_ops.sem_sim_join import SemSimJoinDataframe
+
+        assert SemSimJoinDataframe.__call__.__name__ == "sim_join"
+        still_ref = run(str(tmp_path / "f2"))  # FaissVS configured: patched accessors fall through to the originals
+        lotus.settings.configure(rm=fake_rm.make_rm(RM), vs=HipVS(backend=OracleBackend()))
+        got = run(str(tmp_path / "h"))
+    finally:
+        lotus_amd.uninstall()
+    assert SemSimJoinDataframe.__call__.__name__ != "sim_join"
+    for a, b in ((ref, still_ref), (ref, got)):
+        pd.testing.assert_frame_equal(a[0], b[0])
+        pd.testing.assert_frame_equal(a[1], b[1], check_dtype=False)
+        assert a[2]["cluster_id"].tolist() == b[2]["cluster_id"].tolist()
+        assert len(a[3]) == len(b[3]) and 90 <= len(a[3]) <= 100
+
+
+def test_ops_sem_cluster_by_standalone(tmp_path):
+    from lotus_amd import HipVS, ops
+
+    rng = np.random.default_rng(2)
+    c = rng.standard_normal((3, 16)).astype(np.float32) * 5
+    lab = rng.integers(0, 3, 200)
+    x = (c[lab] + 0.2 * rng.standard_normal((200, 16))).astype(np.float32)
+    vs = HipVS(backend=OracleBackend())
+    df = ops.sem_index(pd.DataFrame({"t": [f"t{i}" for i in range(200)]}), "t", str(tmp_path / "i"), vs=vs, embeddings=x)
+    out = ops.sem_cluster_by(df, "t", 3, niter=6, vs=vs)
+    assert "cluster_id" in out.columns and "cluster_id" not in df.columns
+    for b in range(3):
+        assert len(set(out["cluster_id"][lab == b])) == 1  # every true blob maps to one cluster
+    with pytest.raises(ValueError):
+        ops.sem_cluster_by(df, "t", 500, vs=vs)
