@@ -1,0 +1,87 @@
+"""Property-based tests (hypothesis) of the oracle and of HipVS's host logic with the oracle-backed double:
+size-independent invariants the domain offers - k-monotonicity, subset consistency, shard-merge equivalence,
+permutation invariance, key round trips."""
+import numpy as np
+import pytest
+from hypothesis import HealthCheck, given, settings, strategies as st
+
+import oracle
+from oracle_backend import OracleBackend
+
+hyp = settings(max_examples=25, deadline=None, suppress_health_check=[HealthCheck.too_slow])
+
+
+def _data(seed, nb, nq, d, dup):
+    rng = np.random.default_rng(seed)
+    xb = rng.standard_normal((nb, d)).astype(np.float16).astype(np.float32)
+    if dup and nb > 4:
+        xb[nb // 2:] = xb[: nb - nb // 2]  # exact duplicates -> exact ties
+    xq = rng.standard_normal((nq, d)).astype(np.float16).astype(np.float32)
+    return xb, xq
+
+
+@hyp
+@given(seed=st.integers(0, 10**6), nb=st.integers(1, 300), nq=st.integers(1, 12), d=st.integers(1, 40),
+       k=st.integers(1, 40), metric=st.sampled_from([0, 1]), dup=st.booleans())
+def test_oracle_invariants(seed, nb, nq, d, k, metric, dup):
+    xb, xq = _data(seed, nb, nq, d, dup)
+    D, I = oracle.flat_search(xb, xq, k, metric)
+    kk = min(k, nb)
+    assert (I[:, :kk] >= 0).all() and (I[:, kk:] == -1).all()
+    for q in range(nq):
+        assert len(set(I[q, :kk].tolist())) == kk  # no id twice
+    order = D[:, :kk] if metric == 1 else -D[:, :kk]
+    assert (np.diff(order, axis=1) >= 0).all()  # best first
+    # ties are id-ascending
+    same = np.diff(order, axis=1) == 0
+    assert (np.diff(I[:, :kk], axis=1)[same] > 0).all()
+    # prefix property: top-k is a prefix of top-(k+3)
+    D2, I2 = oracle.flat_search(xb, xq, k + 3, metric)
+    assert np.array_equal(I2[:, :k], I) and np.array_equal(D2[:, :k], D)
+    # shard-merge equivalence: searching two row shards and merging keys equals the unsharded search
+    if nb >= 2:
+        cut = nb // 2
+        be = OracleBackend()
+        pb1, pb2, pq = be.pack(xb[:cut], 0), be.pack(xb[cut:], 0), be.pack(xq, 0)
+        k1 = be.search_keys(pb1, pq, k, metric, id_offset=0)
+        k2 = be.search_keys(pb2, pq, k, metric, id_offset=cut)
+        import torch
+
+        Dm, Im = be.keys_to_result(be.merge_keys(torch.stack([k1, k2])), metric)
+        assert np.array_equal(Im.numpy(), I)
+        assert np.allclose(Dm.numpy(), D, atol=1e-6)
+
+
+@hyp
+@given(seed=st.integers(0, 10**6), nb=st.integers(2, 200), nq=st.integers(1, 8), k=st.integers(1, 12),
+       frac=st.floats(0.1, 1.0))
+def test_hipvs_subset_equals_search_on_the_subset(seed, nb, nq, k, frac, tmp_path_factory):
+    from lotus_amd import HipVS
+
+    xb, xq = _data(seed, nb, nq, 12, False)
+    rng = np.random.default_rng(seed + 1)
+    ids = np.sort(rng.choice(nb, max(1, int(nb * frac)), replace=False)).tolist()
+    d = str(tmp_path_factory.mktemp("p"))
+    vs = HipVS(backend=OracleBackend(), storage="fp16")
+    vs.index(None, xb, d)
+    out = vs(xq, k, ids=ids)
+    Dr, Ir = oracle.flat_search(xb, xq, k, 0, ids=ids)
+    assert np.array_equal(out.indices, Ir) and np.allclose(out.distances, Dr, atol=1e-6)
+    perm = rng.permutation(len(ids))
+    out2 = vs(xq, k, ids=[ids[i] for i in perm])  # id order only matters inside exact ties
+    assert np.array_equal(np.sort(out2.indices, 1), np.sort(out.indices, 1))
+
+
+@hyp
+@given(vals=st.lists(st.floats(allow_nan=False, width=32), min_size=1, max_size=50),
+       ids=st.lists(st.integers(0, 2**32 - 2), min_size=50, max_size=50))
+def test_key_round_trip_and_order(vals, ids):
+    v = np.array(vals, np.float32)
+    i = np.array(ids[: len(v)], np.int64)
+    keys = oracle.pack_keys(v, i)
+    b, ii, empty = oracle.unpack_keys(keys)
+    assert not empty.any() and np.array_equal(ii, i)
+    assert np.array_equal(b, v + np.float32(0))  # -0.0 folds onto +0.0
+    o = np.argsort(keys)[::-1]
+    ref = np.lexsort((i, -(v + np.float32(0)).astype(np.float64)))
+    assert np.array_equal(v[o] + 0, v[ref] + 0) and np.array_equal(i[o][v[o] == v[o]], i[ref][v[ref] == v[ref]])
