@@ -131,7 +131,7 @@ __device__ inline float wave_sum(float v) {
     return v;
 }
 
-// one wave per row
+// one wave per row, one element per lane and step: the fallback for d % 8 != 0 (rows not 16-byte aligned)
 template <typename SrcT>
 __global__ __launch_bounds__(256) void pack_rows_kernel(const SrcT* __restrict__ src, long long n, int d, int dpad,
                                                         int split, int normalize, _Float16* __restrict__ dst,
@@ -171,6 +171,75 @@ __global__ __launch_bounds__(256) void pack_rows_kernel(const SrcT* __restrict__
     }
 }
 
+typedef _Float16 pk_half8 __attribute__((ext_vector_type(8)));
+typedef float pk_float4 __attribute__((ext_vector_type(4)));
+
+__device__ inline void pack_load8(const float* s, float (&v)[8]) {
+    pk_float4 a = *(const pk_float4*)s, b = *(const pk_float4*)(s + 4);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        v[t] = a[t];
+        v[4 + t] = b[t];
+    }
+}
+__device__ inline void pack_load8(const _Float16* s, float (&v)[8]) {
+    pk_half8 a = *(const pk_half8*)s;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) v[t] = (float)a[t];
+}
+
+// one wave per row, 8 consecutive elements per lane and step (16-byte stores, 16/32-byte loads): d % 8 == 0
+template <typename SrcT, int SPLIT>
+__global__ __launch_bounds__(256) void pack_rows_vec_kernel(const SrcT* __restrict__ src, long long n, int d, int dpad,
+                                                            int normalize, _Float16* __restrict__ dst,
+                                                            float* __restrict__ norms) {
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= n) return;
+    const SrcT* s = src + row * (long long)d;
+    _Float16* o = dst + row * (long long)(SPLIT ? 2 * dpad : dpad);
+    float scale = 1.0f;
+    if (normalize) {
+        float ss = 0.f;
+        for (int j = lane * 8; j < d; j += 512) {
+            float v[8];
+            pack_load8(s + j, v);
+#pragma unroll
+            for (int t = 0; t < 8; ++t) ss += v[t] * v[t];
+        }
+        ss = wave_sum(ss);
+        scale = ss > 0.f ? 1.0f / sqrtf(ss) : 0.f;
+    }
+    float nn = 0.f;
+    for (int j = lane * 8; j < dpad; j += 512) {
+        float v[8];
+        if (j < d) {
+            pack_load8(s + j, v);
+        } else {
+#pragma unroll
+            for (int t = 0; t < 8; ++t) v[t] = 0.f;
+        }
+        pk_half8 hi, lo;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            float x = v[t] * scale;
+            hi[t] = (_Float16)x;
+            float stored = (float)hi[t];
+            if (SPLIT) {
+                lo[t] = (_Float16)(x - (float)hi[t]);
+                stored += (float)lo[t];
+            }
+            nn += stored * stored;
+        }
+        *(pk_half8*)(o + j) = hi;
+        if (SPLIT) *(pk_half8*)(o + dpad + j) = lo;
+    }
+    if (norms) {
+        nn = wave_sum(nn);
+        if (lane == 0) norms[row] = nn;
+    }
+}
+
 __global__ __launch_bounds__(256) void gather_rows_kernel(const uint4* __restrict__ src, long long ld16,
                                                           const long long* __restrict__ ids, long long n_ids,
                                                           uint4* __restrict__ dst) {
@@ -186,6 +255,19 @@ __global__ __launch_bounds__(256) void gather_f32_kernel(const float* __restrict
                                                          long long n_ids, float* __restrict__ dst) {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n_ids) dst[i] = src[ids[i]];
+}
+
+// k == 1: one thread per query, the best key over the parts (k-means assignment: 10 M queries, a handful of parts)
+__global__ __launch_bounds__(256) void merge_top1_kernel(const u64* __restrict__ parts, int nparts, long long nq,
+                                                         u64* __restrict__ out, long long out_ld) {
+    const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nq) return;
+    u64 best = 0;
+    for (int p = 0; p < nparts; ++p) {
+        u64 v = parts[(long long)p * nq + q];
+        best = v > best ? v : best;
+    }
+    out[q * out_ld] = best;
 }
 
 // one wave per query: merge nparts sorted-or-not candidate lists of k keys into the best k (k <= 64)
@@ -245,12 +327,27 @@ extern "C" int32_t lvs_pack_rows(const void* src, int32_t src_dtype, int64_t n, 
     const int dpad = (int)lvs_round_up(d, LVS_BK);
     dim3 block(256), grid((unsigned)lvs_ceil_div(n, 4));
     hipStream_t st = (hipStream_t)stream;
-    if (src_dtype == LVS_DTYPE_F32)
+    const bool split = pack_mode == LVS_PACK_SPLIT;
+    const bool vec = d % 8 == 0 && ((uintptr_t)src & 15) == 0;  // every source row 16-byte aligned
+    _Float16* o = (_Float16*)dst;
+    if (vec && src_dtype == LVS_DTYPE_F32 && split)
+        hipLaunchKernelGGL((pack_rows_vec_kernel<float, 1>), grid, block, 0, st, (const float*)src, (long long)n, d,
+                           dpad, normalize, o, out_norms_sq);
+    else if (vec && src_dtype == LVS_DTYPE_F32)
+        hipLaunchKernelGGL((pack_rows_vec_kernel<float, 0>), grid, block, 0, st, (const float*)src, (long long)n, d,
+                           dpad, normalize, o, out_norms_sq);
+    else if (vec && split)
+        hipLaunchKernelGGL((pack_rows_vec_kernel<_Float16, 1>), grid, block, 0, st, (const _Float16*)src, (long long)n,
+                           d, dpad, normalize, o, out_norms_sq);
+    else if (vec)
+        hipLaunchKernelGGL((pack_rows_vec_kernel<_Float16, 0>), grid, block, 0, st, (const _Float16*)src, (long long)n,
+                           d, dpad, normalize, o, out_norms_sq);
+    else if (src_dtype == LVS_DTYPE_F32)
         hipLaunchKernelGGL(pack_rows_kernel<float>, grid, block, 0, st, (const float*)src, (long long)n, d, dpad,
-                           pack_mode == LVS_PACK_SPLIT, normalize, (_Float16*)dst, out_norms_sq);
+                           split, normalize, o, out_norms_sq);
     else
         hipLaunchKernelGGL(pack_rows_kernel<_Float16>, grid, block, 0, st, (const _Float16*)src, (long long)n, d,
-                           dpad, pack_mode == LVS_PACK_SPLIT, normalize, (_Float16*)dst, out_norms_sq);
+                           dpad, split, normalize, o, out_norms_sq);
     LVS_HIP_CHECK(hipGetLastError());
     return LVS_OK;
 }
@@ -501,7 +598,10 @@ extern "C" int32_t lvs_flat_search_keys(const void* xb, int32_t xb_pack, int64_t
                 LVS_HIP_CHECK(lvs_tile_launch(LVS_MODE_TOPK, a, st));
         }
         dim3 mgrid((unsigned)lvs_ceil_div(nq, 4)), mblock(256);
-        if (p.npass == 1) {
+        if (p.npass == 1 && kp == 1) {
+            hipLaunchKernelGGL(merge_top1_kernel, dim3((unsigned)lvs_ceil_div(nq, 256)), mblock, 0, st, partial,
+                               p.nslab, (long long)nq, (u64*)out_keys, (long long)k);
+        } else if (p.npass == 1) {
             hipLaunchKernelGGL(merge_keys_kernel, mgrid, mblock, 0, st, partial, p.nslab, (long long)nq, kp,
                                (u64*)out_keys, (long long)k);
         } else {

@@ -3,7 +3,7 @@
 // Assignment is the tile kernel in top-1 / squared-L2 mode (lvs_flat_search_keys with k = 1).  This file holds the
 // centroid update and the host-side pieces of faiss's Clustering::train that must match bit for bit:
 //   * lvs_kmeans_accumulate: rows are bucketed by centroid with a STABLE radix sort on the assignment bits
-//     (rocPRIM), then every (centroid, 256-dim chunk) is reduced by one workgroup that walks its bucket in row
+//     (rocPRIM), then every (centroid, 512-dim chunk) is reduced by one wave that walks its bucket in row
 //     order - the accumulation order of faiss compute_centroids, so results are reproducible run to run;
 //   * lvs_rand_perm_host / lvs_kmeans_split_clusters_host: std::mt19937-driven subsample/init permutation and
 //     empty-cluster re-seeding exactly as faiss.
@@ -18,61 +18,69 @@
 namespace {
 
 __global__ __launch_bounds__(256) void km_keys_kernel(const long long* __restrict__ assign, long long n, int k,
-                                                      uint32_t* __restrict__ keys, uint32_t* __restrict__ vals,
-                                                      uint32_t* __restrict__ counts) {
+                                                      uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     long long c = assign[i];
-    uint32_t cc = (c < 0 || c >= k) ? (uint32_t)k : (uint32_t)c;  // out-of-range assignments are ignored
-    keys[i] = cc;
+    keys[i] = (c < 0 || c >= k) ? (uint32_t)k : (uint32_t)c;  // out-of-range assignments go to an ignored bucket
     vals[i] = (uint32_t)i;
-    if (cc < (uint32_t)k) atomicAdd(&counts[cc], 1u);  // integer atomics: order-independent
 }
 
-// exclusive scan of counts[0..k] (k + 1 entries incl. the "ignored" bucket) by one workgroup
-__global__ __launch_bounds__(1024) void km_scan_kernel(const uint32_t* __restrict__ counts, int k,
-                                                       uint32_t* __restrict__ offsets) {
-    __shared__ uint32_t carry;
-    __shared__ uint32_t buf[1024];
-    if (threadIdx.x == 0) carry = 0;
-    __syncthreads();
-    for (int base = 0; base < k; base += 1024) {
-        int i = base + threadIdx.x;
-        uint32_t v = i < k ? counts[i] : 0;
-        buf[threadIdx.x] = v;
-        __syncthreads();
-        for (int off = 1; off < 1024; off <<= 1) {
-            uint32_t t = threadIdx.x >= off ? buf[threadIdx.x - off] : 0;
-            __syncthreads();
-            buf[threadIdx.x] += t;
-            __syncthreads();
-        }
-        if (i < k) offsets[i] = carry + buf[threadIdx.x] - v;
-        __syncthreads();
-        if (threadIdx.x == 1023) carry += buf[1023];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) offsets[k] = carry;
+// bucket boundaries from the SORTED keys: offsets[c] = first position whose key is >= c, c = 0..k
+// (no atomics: position i writes the offsets of every centroid whose bucket starts there; k + 1 writes in total)
+__global__ __launch_bounds__(256) void km_bounds_kernel(const uint32_t* __restrict__ sorted_keys, long long n, int k,
+                                                        uint32_t* __restrict__ offsets) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > n) return;
+    const long long lo = i == 0 ? 0 : (long long)sorted_keys[i - 1] + 1;
+    const long long hi = i == n ? (long long)k : (long long)sorted_keys[i];
+    for (long long c = lo; c <= hi && c <= k; ++c) offsets[c] = (uint32_t)i;
 }
 
-// grid = (k, ceil(d / 256)); thread t owns dimension chunk*256 + t of centroid blockIdx.x
-__global__ __launch_bounds__(256) void km_reduce_kernel(const _Float16* __restrict__ x, long long ld, int d, int dpad,
-                                                        int split, const uint32_t* __restrict__ rows,
-                                                        const uint32_t* __restrict__ offsets,
-                                                        float* __restrict__ sums, float* __restrict__ cnt_out) {
-    const int c = blockIdx.x;
-    const int j = blockIdx.y * 256 + threadIdx.x;
+typedef _Float16 km_half8 __attribute__((ext_vector_type(8)));
+
+// grid = (k, ceil(dpad / 512)), one wave per workgroup: lane owns 8 consecutive dimensions of centroid blockIdx.x
+// and walks the bucket in row order, U rows (16-byte loads) in flight at a time.  Per dimension the additions
+// happen in exactly the bucket (= ascending row) order, so the sums do not depend on U or on the launch shape.
+template <int SPLIT>
+__global__ __launch_bounds__(64) void km_reduce_kernel(const _Float16* __restrict__ x, long long ld, int d, int dpad,
+                                                       const uint32_t* __restrict__ rows,
+                                                       const uint32_t* __restrict__ offsets,
+                                                       float* __restrict__ sums, float* __restrict__ cnt_out) {
+    const int c = blockIdx.x, lane = threadIdx.x;
+    const int j0 = (blockIdx.y * 64 + lane) * 8;
     const uint32_t b = offsets[c], e = offsets[c + 1];
-    if (blockIdx.y == 0 && threadIdx.x == 0) cnt_out[c] += (float)(e - b);
-    if (j >= d) return;
-    float acc = 0.f;
-    for (uint32_t p = b; p < e; ++p) {
-        const _Float16* row = x + (long long)rows[p] * ld;
-        float v = (float)row[j];
-        if (split) v += (float)row[dpad + j];
-        acc += v;  // sequential, in row order
+    if (blockIdx.y == 0 && lane == 0) cnt_out[c] += (float)(e - b);
+    if (j0 >= dpad) return;
+    constexpr int U = SPLIT ? 8 : 16;
+    float acc[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) acc[t] = 0.f;
+    const _Float16* xc = x + j0;
+    uint32_t p = b;
+    for (; p + U <= e; p += U) {
+        km_half8 hi[U], lo[U];
+#pragma unroll
+        for (int i = 0; i < U; ++i) {
+            const _Float16* row = xc + (long long)rows[p + i] * ld;
+            hi[i] = *(const km_half8*)row;
+            if (SPLIT) lo[i] = *(const km_half8*)(row + dpad);
+        }
+#pragma unroll
+        for (int i = 0; i < U; ++i)
+#pragma unroll
+            for (int t = 0; t < 8; ++t) acc[t] += SPLIT ? (float)hi[i][t] + (float)lo[i][t] : (float)hi[i][t];
     }
-    sums[(long long)c * d + j] += acc;
+    for (; p < e; ++p) {
+        const _Float16* row = xc + (long long)rows[p] * ld;
+        km_half8 h = *(const km_half8*)row, l;
+        if (SPLIT) l = *(const km_half8*)(row + dpad);
+#pragma unroll
+        for (int t = 0; t < 8; ++t) acc[t] += SPLIT ? (float)h[t] + (float)l[t] : (float)h[t];
+    }
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+        if (j0 + t < d) sums[(long long)c * d + j0 + t] += acc[t];
 }
 
 }  // namespace
@@ -84,7 +92,7 @@ extern "C" int64_t lvs_kmeans_accumulate_workspace_bytes(int64_t n, int32_t k) {
     (void)rocprim::radix_sort_pairs(nullptr, tmp, nil, nil, nil, nil, (size_t)(n > 0 ? n : 1), 0u, 32u);
     int64_t bytes = lvs_round_up((int64_t)tmp, 256);
     bytes += 4 * lvs_round_up(n * 4, 256);             // keys in/out, vals in/out
-    bytes += 2 * lvs_round_up((int64_t)(k + 2) * 4, 256);  // counts, offsets
+    bytes += 2 * lvs_round_up((int64_t)(k + 2) * 4, 256);  // bucket offsets (+ spare)
     return bytes;
 }
 
@@ -116,22 +124,24 @@ extern "C" int32_t lvs_kmeans_accumulate(const void* x, int64_t n, int32_t d, in
     w += lvs_round_up(n * 4, 256);
     uint32_t* vals_out = (uint32_t*)w;
     w += lvs_round_up(n * 4, 256);
-    uint32_t* cnt = (uint32_t*)w;
-    w += lvs_round_up((int64_t)(k + 2) * 4, 256);
     uint32_t* offs = (uint32_t*)w;
 
-    LVS_HIP_CHECK(hipMemsetAsync(cnt, 0, (size_t)(k + 2) * 4, st));
     hipLaunchKernelGGL(km_keys_kernel, dim3((unsigned)lvs_ceil_div(n, 256)), dim3(256), 0, st, (const long long*)assign,
-                       (long long)n, k, keys_in, vals_in, cnt);
+                       (long long)n, k, keys_in, vals_in);
     unsigned bits = 1;
     while ((1u << bits) < (unsigned)(k + 1)) ++bits;
     LVS_HIP_CHECK(rocprim::radix_sort_pairs(d_tmp, tmp, keys_in, keys_out, vals_in, vals_out, (size_t)n, 0u, bits, st));
-    hipLaunchKernelGGL(km_scan_kernel, dim3(1), dim3(1024), 0, st, cnt, k, offs);
+    hipLaunchKernelGGL(km_bounds_kernel, dim3((unsigned)lvs_ceil_div(n + 1, 256)), dim3(256), 0, st, keys_out,
+                       (long long)n, k, offs);
     const int dpad = (int)lvs_round_up(d, LVS_BK);
     const long long ld = pack_mode == LVS_PACK_SPLIT ? 2 * dpad : dpad;
-    hipLaunchKernelGGL(km_reduce_kernel, dim3((unsigned)k, (unsigned)lvs_ceil_div(d, 256)), dim3(256), 0, st,
-                       (const _Float16*)x, ld, d, dpad, pack_mode == LVS_PACK_SPLIT ? 1 : 0, vals_out, offs, sums,
-                       counts);
+    const dim3 grid((unsigned)k, (unsigned)lvs_ceil_div(dpad, 512));
+    if (pack_mode == LVS_PACK_SPLIT)
+        hipLaunchKernelGGL(km_reduce_kernel<1>, grid, dim3(64), 0, st, (const _Float16*)x, ld, d, dpad, vals_out, offs,
+                           sums, counts);
+    else
+        hipLaunchKernelGGL(km_reduce_kernel<0>, grid, dim3(64), 0, st, (const _Float16*)x, ld, d, dpad, vals_out, offs,
+                           sums, counts);
     LVS_HIP_CHECK(hipGetLastError());
     return LVS_OK;
 }

@@ -202,6 +202,36 @@ def test_pack_rows_values_and_norms(hip_backend):
     assert np.abs(nrm - 1).max() < 2e-3
 
 
+@pytest.mark.parametrize("d", [96, 200, 768, 1000])
+@pytest.mark.parametrize("src_dtype", [np.float32, np.float16])
+def test_pack_rows_vector_path_equals_scalar_semantics(hip_backend, d, src_dtype):
+    """d % 8 == 0 takes the 16-byte-per-lane kernel: same stored values as the element-wise definition, also for a
+    source that starts at an odd row of a bigger buffer (every row still 16-byte aligned)."""
+    import torch
+
+    be = hip_backend
+    big = (synth.corpus(131, d, seed=d) * 2).astype(src_dtype)
+    dev = torch.from_numpy(big).to(be.device)
+    for x_dev, x in ((dev, big), (dev[3:], big[3:])):
+        xf = x.astype(np.float32)
+        hi = xf.astype(np.float16)
+        dpad = -(-d // 64) * 64
+        p = be.pack(x_dev, F16)
+        rows = p.rows.cpu().numpy()
+        assert rows.shape == (len(x), dpad)
+        assert np.array_equal(rows[:, :d], hi) and not rows[:, d:].any()
+        assert np.allclose(p.norms.cpu().numpy(), (hi.astype(np.float32) ** 2).sum(1), rtol=2e-6)
+        p2 = be.pack(x_dev, SPLIT)
+        r2 = p2.rows.cpu().numpy()
+        lo = (xf - hi.astype(np.float32)).astype(np.float16)
+        assert np.array_equal(r2[:, :d], hi) and np.array_equal(r2[:, dpad:dpad + d], lo)
+        assert not r2[:, d:dpad].any() and not r2[:, dpad + d:].any()
+        pn = be.pack(x_dev, SPLIT, normalize=True)
+        rn = pn.rows.cpu().numpy().astype(np.float32)
+        want = xf / np.linalg.norm(xf, axis=1, keepdims=True)
+        assert np.abs(rn[:, :d] + rn[:, dpad:dpad + d] - want).max() <= 3e-7
+
+
 def test_rank_all_rows_for_k_equal_n(hip_backend, tmp_path):
     """K = N beyond LVS_MAX_K through HipVS: full score rows + segmented sort."""
     from lotus_amd import HipVS

@@ -22,13 +22,19 @@ __device__ inline void glds16(const void* g, void* l) {
 // WM x WN waves, each wave MI x NI accumulator blocks of 32x32:  WM*MI*32 == 256, WN*NI*32 == 256
 template <int WM, int WN, int MI, int NI, int WPE, int DEPTH, int BPOS, int PRIO, int SPREAD>
 __global__ __launch_bounds__(WM * WN * 64, WPE) void gemm_probe(const _Float16* __restrict__ xb, const _Float16* __restrict__ xq,
-                                                                 float* __restrict__ out, int ntiles, int nk, long long ld) {
+                                                                 float* __restrict__ out, int ntiles, int nk, long long ld, unsigned long long* __restrict__ stamps, int qmod) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NW = WM * WN;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
-    const long long q0 = (long long)blockIdx.x * BQ;
+        // XCD x = b % 8 runs 32 blocks at a time (one per CU): local index i = (b / 8) % 32, generation g = b / 256
+    const int xcd = blockIdx.x & 7, li = (blockIdx.x >> 3) & 31, gen = blockIdx.x >> 8;
+    const int gq = qmod;                       // query tiles per XCD group; 32 / gq corpus phases
+    const int qt = (gen * 8 + xcd) * gq + (li % gq);
+    const int slab = li / gq, nsl = 32 / gq;
+    const int tile0 = slab * (ntiles / nsl);
+    const long long q0 = (long long)qt * BQ;
     constexpr int RPW = 512 / NW;        // staged rows per wave per K-step (corpus + queries)
     constexpr int GL = RPW / 8;          // glds per wave per K-step
     // wave stages rows [wave*RPW, +RPW) of the 512-row (corpus | query) stack
@@ -61,7 +67,7 @@ __global__ __launch_bounds__(WM * WN * 64, WPE) void gemm_probe(const _Float16* 
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
     const int T = ntiles * nk;
     auto issue = [&](int t, int buf) {
-        int ti = t / nk, ks = t - ti * nk;
+        int ti = t / nk, ks = t - ti * nk; ti = (ti + tile0) % ntiles;
 #pragma unroll
         for (int i = 0; i < GL; ++i) {
             int row = wave * RPW + i * 8;
@@ -74,11 +80,15 @@ __global__ __launch_bounds__(WM * WN * 64, WPE) void gemm_probe(const _Float16* 
     int ksin = 0;
     for (int t = 0; t < T; ++t) {
         const int buf = t & 1;
+        unsigned long long ta = 0, tb = 0;
+        const bool st = stamps && t >= 200 && t < 264 && (blockIdx.x == 0 || blockIdx.x == 1001);
+        if (st) ta = __builtin_amdgcn_s_memtime();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        if (st) tb = __builtin_amdgcn_s_memtime();
         const char* sb = smem + buf * STAGE;
         const int tn = t + 1 < T ? t + 1 : T - 1;
-        const int nti = tn / nk, nks = tn - nti * nk;
+        const int nti0 = tn / nk, nks = tn - nti0 * nk; const int nti = (nti0 + tile0) % ntiles;
         half8 Bf[2][NI], Af[DEPTH + 1];
         if (PRIO == 1) { if (wave >= NW / 2) __builtin_amdgcn_s_setprio(1); }  // static priority for the younger half
 #pragma unroll
@@ -110,6 +120,13 @@ __global__ __launch_bounds__(WM * WN * 64, WPE) void gemm_probe(const _Float16* 
                 acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Af[f % (DEPTH + 1)], Bf[kk & 1][ni], acc[mi][ni], 0, 0, 0);
             if (PRIO == 2) __builtin_amdgcn_s_setprio(0);
         }
+        if (st) {
+            unsigned long long tc = __builtin_amdgcn_s_memtime();
+            if (lane == 0) {
+                unsigned long long* o = stamps + (((blockIdx.x ? 1 : 0) * NW + wave) * 64 + (t - 200)) * 3;
+                o[0] = ta; o[1] = tb; o[2] = tc;
+            }
+        }
         if (++ksin < nk) continue;
         ksin = 0;
 #pragma unroll
@@ -127,7 +144,7 @@ __global__ __launch_bounds__(WM * WN * 64, WPE) void gemm_probe(const _Float16* 
 }
 
 template <int WM, int WN, int MI, int NI, int WPE, int DEPTH, int BPOS, int PRIO, int SPREAD>
-void run(const char* name, const _Float16* xb, const _Float16* xq, float* out, int nqt, int ntiles, int nk, long long ld) {
+void run(const char* name, const _Float16* xb, const _Float16* xq, float* out, int nqt, int ntiles, int nk, long long ld, unsigned long long* stamps = nullptr, int qmod = 32) {
     auto k = gemm_probe<WM, WN, MI, NI, WPE, DEPTH, BPOS, PRIO, SPREAD>;
     CHECK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE));
     hipEvent_t e0, e1;
@@ -136,7 +153,7 @@ void run(const char* name, const _Float16* xb, const _Float16* xq, float* out, i
     float best = 1e30f;
     for (int it = 0; it < 4; ++it) {
         CHECK(hipEventRecord(e0));
-        hipLaunchKernelGGL(k, dim3(nqt), dim3(WM * WN * 64), 2 * STAGE, 0, xb, xq, out, ntiles, nk, ld);
+        hipLaunchKernelGGL(k, dim3(nqt), dim3(WM * WN * 64), 2 * STAGE, 0, xb, xq, out, ntiles, nk, ld, stamps, qmod);
         CHECK(hipEventRecord(e1));
         CHECK(hipEventSynchronize(e1));
         float ms;
@@ -163,11 +180,37 @@ int main() {
     CHECK(hipMalloc(&out, (size_t)nqt * 16 * 64 * 4 * 4));
     CHECK(hipMemcpy(xb, h.data(), nb * d * 2, hipMemcpyHostToDevice));
     CHECK(hipMemcpy(xq, h.data(), nq * d * 2, hipMemcpyHostToDevice));
-    for (int rep = 0; rep < 2; ++rep) {
-        run<2, 4, 4, 2, 2, 2, 2, 0, 0>("base (B at mi=2)", xb, xq, out, nqt, ntiles, nk, d);
-        run<2, 4, 4, 2, 2, 2, 2, 1, 0>("static prio younger half", xb, xq, out, nqt, ntiles, nk, d);
-        run<2, 4, 4, 2, 2, 2, 2, 2, 0>("setprio around MFMA pairs", xb, xq, out, nqt, ntiles, nk, d);
-        run<2, 4, 4, 2, 2, 2, 2, 0, 1>("staging loads spread over 16 steps", xb, xq, out, nqt, ntiles, nk, d);
-    }
+    unsigned long long* stamps;
+    const size_t nst = 2 * 8 * 64 * 3;
+    CHECK(hipMalloc(&stamps, nst * 8));
+    auto clock_of = [&](const char* name, int qmod) {
+        CHECK(hipMemset(stamps, 0, nst * 8));
+        hipEvent_t e0, e1;
+        CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+        auto k = gemm_probe<2, 4, 4, 2, 2, 2, 2, 1, 0>;
+        CHECK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE));
+        float best = 1e30f;
+        for (int it = 0; it < 4; ++it) {
+            CHECK(hipEventRecord(e0));
+            hipLaunchKernelGGL(k, dim3(nqt), dim3(512), 2 * STAGE, 0, xb, xq, out, ntiles, nk, (long long)d, stamps, qmod);
+            CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
+            float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+            if (ms < best) best = ms;
+        }
+        std::vector<unsigned long long> hs(nst);
+        CHECK(hipMemcpy(hs.data(), stamps, nst * 8, hipMemcpyDeviceToHost));
+        double per = (double)(hs[63 * 3] - hs[0]) / 63.0;
+        double fl = 2.0 * nqt * 256.0 * ntiles * 256.0 * nk * 64.0;
+        double us_per_kstep = best * 1e3 / ((double)ntiles * nk * (nqt / 256.0));
+        printf("%-34s %8.2f ms %7.1f TFLOP/s  cycles/K-step %.0f  -> clock %.2f GHz, MFMA util %.1f %%\n", name, best,
+               fl / (best * 1e-3) / 1e12, per, per / us_per_kstep / 1e3, 2048.0 / per * 100);
+        fflush(stdout);
+    };
+    clock_of("32 query tiles x 1 slab / XCD", 32);
+    clock_of("16 x 2", 16);
+    clock_of("8 x 4", 8);
+    clock_of("4 x 8", 4);
+    clock_of("2 x 16", 2);
+    clock_of("32 x 1 again", 32);
     return 0;
 }
