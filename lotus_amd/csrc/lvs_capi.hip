@@ -534,6 +534,15 @@ extern "C" int32_t lvs_flat_search_keys(const void* xb, int32_t xb_pack, int64_t
     a.nqt = p.nqt;
     a.gq = p.gq;
     a.debug_hot = getenv("LVS_DEBUG_HOT") ? atoi(getenv("LVS_DEBUG_HOT")) : 0;
+    a.dbg = nullptr;
+    unsigned long long* dbg_counters = nullptr;
+#ifdef LVS_COUNT_EVENTS
+    if (getenv("LVS_COUNT") && atoi(getenv("LVS_COUNT"))) {  // tuning aid: count slow-path events of this call
+        LVS_HIP_CHECK(hipMalloc((void**)&dbg_counters, 3 * sizeof(unsigned long long)));
+        LVS_HIP_CHECK(hipMemsetAsync(dbg_counters, 0, 3 * sizeof(unsigned long long), st));
+        a.dbg = dbg_counters;
+    }
+#endif
 
     // HBM-bound regime (the literal sem_search: one query per call): stream the corpus once, queries resident in LDS
     {
@@ -612,6 +621,14 @@ extern "C" int32_t lvs_flat_search_keys(const void* xb, int32_t xb_pack, int64_t
                                (long long)nq, kp, (u64*)out_keys, k, col0);
         }
         LVS_HIP_CHECK(hipGetLastError());
+    }
+    if (dbg_counters) {
+        unsigned long long h[3] = {0, 0, 0};
+        LVS_HIP_CHECK(hipStreamSynchronize(st));
+        LVS_HIP_CHECK(hipMemcpy(h, dbg_counters, sizeof(h), hipMemcpyDeviceToHost));
+        (void)hipFree(dbg_counters);
+        fprintf(stderr, "[lvs] nq=%lld nb=%lld k=%d nslab=%d: wave-tiles %llu, block visits %llu, insertions %llu (%.1f per query)\n",
+                (long long)nq, (long long)nb, k, p.nslab, h[2], h[0], h[1], (double)h[1] / (double)(nq > 0 ? nq : 1));
     }
     return LVS_OK;
 }

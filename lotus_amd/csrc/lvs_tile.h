@@ -51,6 +51,7 @@ struct LvsTileArgs {
     int ntiles, tiles_per_slab, nslab, nqt;
     int debug_hot;            // tuning aid: every workgroup re-reads tile 0 / query tile 0 (all loads L2-hot)
     int gq;                   // query tiles per XCD group (1,2,4,8,16,32); slabs per group = 32 / gq
+    unsigned long long* dbg;  // tuning aid (build with -DLVS_COUNT_EVENTS, run with LVS_COUNT=1): [0] block visits, [1] insertions, [2] wave-tiles
 };
 
 int lvs_tile_grid_blocks(int nqt, int nslab, int gq);

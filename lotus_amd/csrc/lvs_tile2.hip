@@ -9,6 +9,9 @@
 //                query (256 x KCAP x 8 B) plus a lock word per query.  A score that beats its query's current k-th
 //                best is inserted at once under the query's LDS spin lock (hits are rare: ~k ln(N/k) per query per
 //                pass), so thresholds tighten immediately and the epilogue needs no workgroup barrier.
+#include <type_traits>
+#include <utility>
+
 #include "lvs_common.h"
 #include "lvs_tile.h"
 
@@ -29,6 +32,46 @@ typedef const __attribute__((address_space(1))) void gbl_void_t;
 __device__ inline void glds16(const void* gsrc, void* ldst) {
     __builtin_amdgcn_global_load_lds((gbl_void_t*)gsrc, (lds_void_t*)ldst, 16, 0, 0);
 }
+
+// ---- asm-scheduled K-step ------------------------------------------------------------------------------------
+// hipcc sinks every LDS fragment read to just before its first use and waits with lgkmcnt(0), which undoes the
+// software pipelining written in the source.  The fragment reads and their waits are therefore inline asm: reads are
+// issued in source order (pinned by sched_barrier), waits are COUNTED (LDS returns a wave's reads in issue order).
+template <int... Is, class F>
+__device__ inline void static_for_impl(std::integer_sequence<int, Is...>, F&& f) {
+    (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, class F>
+__device__ inline void static_for(F&& f) {
+    static_for_impl(std::make_integer_sequence<int, N>{}, f);
+}
+__device__ inline void lds_read16(half8& dst, unsigned addr) {
+    asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(addr));
+}
+template <int N>
+__device__ inline void lds_wait(half8& a, half8& b0, half8& b1) {
+    asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(a), "+v"(b0), "+v"(b1) : "n"(N));
+}
+// Issue order of one K-step (16 steps f = kk * 4 + mi): prologue B(0)[0], B(0)[1], A(0) .. A(DEPTH-1); step f issues
+// A(f + DEPTH) (if any), then B(kk+1)[0..1] when mi == BPOS.  wait(f) = reads that may still be outstanding when step
+// f's MFMAs start = (reads issued so far) - 1 - (issue index of the last read step f needs).
+template <int DEPTH, int BPOS>
+struct KStepOrder {
+    static constexpr int issued(int f) {
+        int c = 2 + DEPTH;
+        for (int g = 0; g <= f; ++g) {
+            if (g + DEPTH < 16) ++c;
+            if (g % 4 == BPOS && g / 4 + 1 < 4) c += 2;
+        }
+        return c;
+    }
+    static constexpr int pos_A(int f) { return f < DEPTH ? 2 + f : issued(f - DEPTH - 1); }
+    static constexpr int pos_B(int kk) { return kk == 0 ? 1 : issued((kk - 1) * 4 + BPOS) - 1; }
+    static constexpr int wait(int f) {
+        const int a = pos_A(f), b = pos_B(f / 4);
+        return issued(f) - 1 - (a > b ? a : b);
+    }
+};
 
 __device__ inline float max16(const f32x16& v) {
     float a = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
@@ -191,6 +234,10 @@ __global__ __launch_bounds__(512, 2) void lvs_tile2_kernel(const LvsTileArgs a) 
     // static priority raise evens it out (+2 % on the bare loop, tools/probe_gemm.hip)
     if (wave >= 4) __builtin_amdgcn_s_setprio(1);
     uint32_t gpre[2] = {0u, 0u};  // cross-workgroup thresholds, prefetched one K-step before the tile epilogue
+#ifdef LVS_COUNT_EVENTS
+    unsigned n_visit = 0, n_ins = 0, n_wt = 0;  // tuning aid, see a.dbg
+#endif
+    const int pubmask = a.debug_hot == 5 ? 0 : (a.debug_hot == 6 ? 1 : (a.debug_hot == 7 ? 3 : 7));  // tuning aid
     for (int t = 0; t < T; ++t) {
         const int buf = t & 1;
         if (a.debug_hot == 4) {  // tuning aid: no wait for the staging loads (results are garbage, timing only)
@@ -223,21 +270,24 @@ __global__ __launch_bounds__(512, 2) void lvs_tile2_kernel(const LvsTileArgs a) 
         }
         const char* c_sbase = (const char*)xb + ((long long)(tile0 + n_tile) * BC * ldb + a.seg_c[n_seg] + n_r * BK) * 2;
         const char* q_sbase = (const char*)xq + (q0 * ldq + a.seg_q[n_seg] + n_r * BK) * 2;
-        half8 Bf[2][2], Af[3];
-        Bf[0][0] = *(const half8*)(sb + b_base + foff[0]);
-        Bf[0][1] = *(const half8*)(sb + b_base + 32 * ROWB + foff[0]);
-        Af[0] = *(const half8*)(sb + a_base + foff[0]);
-        Af[1] = *(const half8*)(sb + a_base + 32 * ROWB + foff[0]);
+        constexpr int KDEPTH = 2, KBPOS = 2;  // A fragments two steps ahead, B fragments of the next kk read at mi == 2
+        using Ord = KStepOrder<KDEPTH, KBPOS>;
+        half8 Bf[2][2], Af[KDEPTH + 1];
+        const unsigned sbu = (unsigned)(unsigned long long)sb;
+        lds_read16(Bf[0][0], sbu + b_base + foff[0]);
+        lds_read16(Bf[0][1], sbu + b_base + 32 * ROWB + foff[0]);
 #pragma unroll
-        for (int f = 0; f < 16; ++f) {
-            const int kk = f >> 2, mi = f & 3;
-            if (f + 2 < 16) {
-                const int f2 = f + 2;
-                Af[f2 % 3] = *(const half8*)(sb + a_base + (f2 & 3) * 32 * ROWB + foff[f2 >> 2]);
+        for (int f = 0; f < KDEPTH; ++f) lds_read16(Af[f], sbu + a_base + (f & 3) * 32 * ROWB + foff[f >> 2]);
+        static_for<16>([&](auto fc) {
+            constexpr int f = decltype(fc)::value;
+            constexpr int kk = f >> 2, mi = f & 3;
+            if (f + KDEPTH < 16) {
+                constexpr int f2 = f + KDEPTH;
+                lds_read16(Af[f2 % (KDEPTH + 1)], sbu + a_base + (f2 & 3) * 32 * ROWB + foff[f2 >> 2]);
             }
-            if (mi == 2 && kk + 1 < 4) {  // measured best position (tools/probe_gemm.hip)
-                Bf[(kk + 1) & 1][0] = *(const half8*)(sb + b_base + foff[kk + 1]);
-                Bf[(kk + 1) & 1][1] = *(const half8*)(sb + b_base + 32 * ROWB + foff[kk + 1]);
+            if (mi == KBPOS && kk + 1 < 4) {
+                lds_read16(Bf[(kk + 1) & 1][0], sbu + b_base + foff[kk + 1]);
+                lds_read16(Bf[(kk + 1) & 1][1], sbu + b_base + 32 * ROWB + foff[kk + 1]);
             }
             if (f < 8) {
                 if (f < 4)
@@ -245,9 +295,12 @@ __global__ __launch_bounds__(512, 2) void lvs_tile2_kernel(const LvsTileArgs a) 
                 else
                     glds16(q_sbase + q_loff[f - 4], n_base + BC * ROWB + (wave * 32 + (f - 4) * 8) * ROWB);
             }
-            acc[mi][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Af[f % 3], Bf[kk & 1][0], acc[mi][0], 0, 0, 0);
-            acc[mi][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Af[f % 3], Bf[kk & 1][1], acc[mi][1], 0, 0, 0);
-        }
+            __builtin_amdgcn_sched_barrier(0);
+            lds_wait<Ord::wait(f)>(Af[f % (KDEPTH + 1)], Bf[kk & 1][0], Bf[kk & 1][1]);
+            acc[mi][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Af[f % (KDEPTH + 1)], Bf[kk & 1][0], acc[mi][0], 0, 0, 0);
+            acc[mi][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Af[f % (KDEPTH + 1)], Bf[kk & 1][1], acc[mi][1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        });
 
         if (++ks_in_tile < nk) continue;
         ks_in_tile = 0;
@@ -377,6 +430,9 @@ __global__ __launch_bounds__(512, 2) void lvs_tile2_kernel(const LvsTileArgs a) 
         }
         // fast filter: which of the eight 32x32 blocks hold a score that may enter some query's list?
         uint32_t hitmask = 0;  // wave-uniform, bit tsel = mi * 2 + ni
+#ifdef LVS_COUNT_EVENTS
+        ++n_wt;
+#endif
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
@@ -403,6 +459,9 @@ __global__ __launch_bounds__(512, 2) void lvs_tile2_kernel(const LvsTileArgs a) 
                 const bool qv = ni ? qvalid[1] : qvalid[0];
                 const bool th = qv && (max16(tv) >= tf);
                 if (!__any(th)) continue;
+#ifdef LVS_COUNT_EVENTS
+                ++n_visit;
+#endif
                 const int q = ni ? qloc[1] : qloc[0];
                 const u64 ubq = ni ? ubk[1] : ubk[0];
                 const uint32_t go = ni ? gord[1] : gord[0];
@@ -427,6 +486,9 @@ __global__ __launch_bounds__(512, 2) void lvs_tile2_kernel(const LvsTileArgs a) 
                     unsigned long long pm = __ballot(pending);
                     if (a.debug_hot == 3) pm = 0;  // tuning aid: scan for hits but skip the insertions
                     while (pm) {
+#ifdef LVS_COUNT_EVENTS
+                        ++n_ins;
+#endif
                         const int src = __ffsll((long long)pm) - 1;
                         pm &= pm - 1;
                         const uint32_t klo = __builtin_amdgcn_readlane((uint32_t)key, src);
@@ -465,7 +527,7 @@ __global__ __launch_bounds__(512, 2) void lvs_tile2_kernel(const LvsTileArgs a) 
             }
         }
         // publish thresholds for the other slabs of these queries every 8 tiles and at the end of the item
-        if (((ti & 7) == 0) || t + 1 == T) {
+        if (((ti & pubmask) == 0) || t + 1 == T) {
 #pragma unroll
             for (int ni = 0; ni < 2; ++ni) {
                 const uint32_t lo = (uint32_t)(lists[qloc[ni] * KCAP + k - 1] >> 32);
@@ -481,6 +543,13 @@ __global__ __launch_bounds__(512, 2) void lvs_tile2_kernel(const LvsTileArgs a) 
                 for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
     }
 
+#ifdef LVS_COUNT_EVENTS
+    if (MODE == LVS_MODE_TOPK && a.dbg && lane == 0) {
+        atomicAdd(&a.dbg[0], (unsigned long long)n_visit);
+        atomicAdd(&a.dbg[1], (unsigned long long)n_ins);
+        atomicAdd(&a.dbg[2], (unsigned long long)n_wt);
+    }
+#endif
     if (MODE == LVS_MODE_RANGE || MODE == LVS_MODE_SCORES) return;
     if (MODE == LVS_MODE_TOP1) {
         // four lanes (l, l+32 of waves wm = 0, 1) hold partial winners of each query: combine by key

@@ -5,6 +5,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
+#include <utility>
+#include <type_traits>
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -13,6 +15,55 @@ typedef const __attribute__((address_space(1))) void gbl_void_t;
 
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
 
+
+template <int... Is, class F>
+__device__ inline void static_for_impl(std::integer_sequence<int, Is...>, F&& f) {
+    (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, class F>
+__device__ inline void static_for(F&& f) {
+    static_for_impl(std::make_integer_sequence<int, N>{}, f);
+}
+
+__device__ inline void lds_read16(half8& dst, unsigned addr) {
+    asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(addr));
+}
+template <int N>
+__device__ inline void lds_wait(half8& a, half8& b0, half8& b1) {
+    asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(a), "+v"(b0), "+v"(b1) : "n"(N));
+}
+// issue-order bookkeeping for the asm-scheduled K-step (NI == 2): reads are issued in this order -
+//   prologue: B(0)[0], B(0)[1], A(0) .. A(DEPTH-1);  step f: A(f+DEPTH) (if any), then B(kk+1)[0..1] when mi == BPOS.
+// pos_A(f) / pos_B(kk): 0-based issue index of the LAST read that MFMA step f needs; issued(f): reads issued up to and
+// including step f's own issues.  The counted wait before step f's MFMAs is lgkmcnt(issued(f) - 1 - needed).
+template <int MI, int DEPTH, int BPOS>
+struct KStepOrder {
+    static constexpr int NF = 4 * MI;
+    static constexpr int issued(int f) {
+        int c = 2 + DEPTH;
+        for (int g = 0; g <= f; ++g) {
+            if (g + DEPTH < NF) ++c;
+            if (g % MI == BPOS && g / MI + 1 < 4) c += 2;
+        }
+        return c;
+    }
+    static constexpr int pos_A(int f) {
+        if (f < DEPTH) return 2 + f;
+        // issued at step g = f - DEPTH as the first read of that step
+        return issued(f - DEPTH - 1 < 0 ? -1 : f - DEPTH - 1);
+    }
+    static constexpr int pos_B(int kk) {
+        if (kk == 0) return 1;
+        const int g = (kk - 1) * MI + BPOS;  // step that issued B(kk): after that step's A read (if any)
+        return issued(g) - 1;
+    }
+    static constexpr int wait(int f) {
+        const int a = pos_A(f), b = pos_B(f / MI);
+        const int need = a > b ? a : b;
+        return issued(f) - 1 - need;
+    }
+};
+
 constexpr int BC = 256, BQ = 256, BK = 64, ROWB = 128, STAGE = (BC + BQ) * ROWB;
 
 __device__ inline void glds16(const void* g, void* l) {
@@ -20,7 +71,7 @@ __device__ inline void glds16(const void* g, void* l) {
 }
 
 // WM x WN waves, each wave MI x NI accumulator blocks of 32x32:  WM*MI*32 == 256, WN*NI*32 == 256
-template <int WM, int WN, int MI, int NI, int WPE, int DEPTH, int BPOS, int PRIO, int SPREAD>
+template <int WM, int WN, int MI, int NI, int WPE, int DEPTH, int BPOS, int PRIO, int SPREAD, int STAMP = 0, int ABL = 0>
 __global__ __launch_bounds__(WM * WN * 64, WPE) void gemm_probe(const _Float16* __restrict__ xb, const _Float16* __restrict__ xq,
                                                                  float* __restrict__ out, int ntiles, int nk, long long ld, unsigned long long* __restrict__ stamps, int qmod) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -81,7 +132,7 @@ __global__ __launch_bounds__(WM * WN * 64, WPE) void gemm_probe(const _Float16* 
     for (int t = 0; t < T; ++t) {
         const int buf = t & 1;
         unsigned long long ta = 0, tb = 0;
-        const bool st = stamps && t >= 200 && t < 264 && (blockIdx.x == 0 || blockIdx.x == 1001);
+        const bool st = STAMP && stamps && t >= 200 && t < 264 && (blockIdx.x == 0 || blockIdx.x == 1001);
         if (st) ta = __builtin_amdgcn_s_memtime();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -89,6 +140,42 @@ __global__ __launch_bounds__(WM * WN * 64, WPE) void gemm_probe(const _Float16* 
         const char* sb = smem + buf * STAGE;
         const int tn = t + 1 < T ? t + 1 : T - 1;
         const int nti0 = tn / nk, nks = tn - nti0 * nk; const int nti = (nti0 + tile0) % ntiles;
+        if constexpr (SPREAD == 3) {
+            // asm-scheduled K-step: LDS reads and their counted waits are inline asm, order pinned by sched_barrier
+            static_assert(NI == 2, "asm K-step is written for NI == 2");
+            using Ord = KStepOrder<MI, DEPTH, BPOS>;
+            half8 Bf[2][2], Af[DEPTH + 1];
+            if (PRIO == 1) { if (wave >= NW / 2) __builtin_amdgcn_s_setprio(1); }
+            const unsigned sbu = (unsigned)(unsigned long long)sb;
+            lds_read16(Bf[0][0], sbu + b_base + foff[0]);
+            lds_read16(Bf[0][1], sbu + b_base + 32 * ROWB + foff[0]);
+            constexpr int NF = 4 * MI;
+#pragma unroll
+            for (int f = 0; f < DEPTH; ++f) lds_read16(Af[f], sbu + a_base + (f % MI) * 32 * ROWB + foff[f / MI]);
+            static_for<NF>([&](auto fc) {
+                constexpr int f = decltype(fc)::value;
+                constexpr int kk = f / MI, mi = f % MI;
+                if (f + DEPTH < NF && !(ABL & 1)) {
+                    constexpr int f2 = f + DEPTH;
+                    lds_read16(Af[f2 % (DEPTH + 1)], sbu + a_base + (f2 % MI) * 32 * ROWB + foff[f2 / MI]);
+                }
+                if (mi == BPOS && kk + 1 < 4 && !(ABL & 1)) {
+                    lds_read16(Bf[(kk + 1) & 1][0], sbu + b_base + foff[kk + 1]);
+                    lds_read16(Bf[(kk + 1) & 1][1], sbu + b_base + 32 * ROWB + foff[kk + 1]);
+                }
+                if (f < GL && !(ABL & 2)) {
+                    int row = wave * RPW + f * 8;
+                    bool isq = row >= BC;
+                    long long tile_off = isq ? 0 : (long long)nti * BC * ld * 2;
+                    glds16(sbase[f] + tile_off + loff[f] + nks * BK * 2, smem + (buf ^ 1) * STAGE + row * ROWB);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (!(ABL & 1)) lds_wait<Ord::wait(f)>(Af[f % (DEPTH + 1)], Bf[kk & 1][0], Bf[kk & 1][1]);
+                acc[mi][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Af[f % (DEPTH + 1)], Bf[kk & 1][0], acc[mi][0], 0, 0, 0);
+                acc[mi][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Af[f % (DEPTH + 1)], Bf[kk & 1][1], acc[mi][1], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        } else {
         half8 Bf[2][NI], Af[DEPTH + 1];
         if (PRIO == 1) { if (wave >= NW / 2) __builtin_amdgcn_s_setprio(1); }  // static priority for the younger half
 #pragma unroll
@@ -107,18 +194,21 @@ __global__ __launch_bounds__(WM * WN * 64, WPE) void gemm_probe(const _Float16* 
 #pragma unroll
                 for (int ni = 0; ni < NI; ++ni) Bf[(kk + 1) & 1][ni] = *(const half8*)(sb + b_base + ni * 32 * ROWB + foff[kk + 1]);
             }
-            if ((SPREAD ? ((f & 1) == 0 && (f >> 1) < GL) : (f < GL))) {
-                const int gi = SPREAD ? (f >> 1) : f;
+            if ((SPREAD == 1 ? ((f & 1) == 0 && (f >> 1) < GL) : (f < GL))) {
+                const int gi = SPREAD == 1 ? (f >> 1) : f;
                 int row = wave * RPW + gi * 8;
                 bool isq = row >= BC;
                 long long tile_off = isq ? 0 : (long long)nti * BC * ld * 2;
                 glds16(sbase[gi] + tile_off + loff[gi] + nks * BK * 2, smem + (buf ^ 1) * STAGE + row * ROWB);
             }
+            if (SPREAD == 2) __builtin_amdgcn_sched_barrier(0);  // pin: this step's reads are issued BEFORE its MFMAs
             if (PRIO == 2) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni)
                 acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Af[f % (DEPTH + 1)], Bf[kk & 1][ni], acc[mi][ni], 0, 0, 0);
             if (PRIO == 2) __builtin_amdgcn_s_setprio(0);
+            if (SPREAD == 2) __builtin_amdgcn_sched_barrier(0);
+        }
         }
         if (st) {
             unsigned long long tc = __builtin_amdgcn_s_memtime();
@@ -143,9 +233,9 @@ __global__ __launch_bounds__(WM * WN * 64, WPE) void gemm_probe(const _Float16* 
     for (int ni = 0; ni < NI; ++ni) out[((long long)blockIdx.x * NW + wave) * 64 * NI + ni * 64 + lane] = best[ni];
 }
 
-template <int WM, int WN, int MI, int NI, int WPE, int DEPTH, int BPOS, int PRIO, int SPREAD>
+template <int WM, int WN, int MI, int NI, int WPE, int DEPTH, int BPOS, int PRIO, int SPREAD, int ABL = 0>
 void run(const char* name, const _Float16* xb, const _Float16* xq, float* out, int nqt, int ntiles, int nk, long long ld, unsigned long long* stamps = nullptr, int qmod = 32) {
-    auto k = gemm_probe<WM, WN, MI, NI, WPE, DEPTH, BPOS, PRIO, SPREAD>;
+    auto k = gemm_probe<WM, WN, MI, NI, WPE, DEPTH, BPOS, PRIO, SPREAD, 0, ABL>;
     CHECK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE));
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0));
@@ -165,6 +255,38 @@ void run(const char* name, const _Float16* xb, const _Float16* xq, float* out, i
     fflush(stdout);
 }
 
+template <int SPREAD, int ABL>
+void clock_of(const char* name, const _Float16* xb, const _Float16* xq, float* out, int nqt, int ntiles, int nk, long long d,
+              unsigned long long* stamps) {
+    const size_t nst = 2 * 8 * 64 * 3;
+    CHECK(hipMemset(stamps, 0, nst * 8));
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    auto k = gemm_probe<2, 4, 4, 2, 2, 2, 2, 1, SPREAD, 1, ABL>;
+    CHECK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE));
+    float best = 1e30f;
+    for (int it = 0; it < 4; ++it) {
+        CHECK(hipEventRecord(e0));
+        hipLaunchKernelGGL(k, dim3(nqt), dim3(512), 2 * STAGE, 0, xb, xq, out, ntiles, nk, d, stamps, 32);
+        CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
+        float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+        if (ms < best) best = ms;
+    }
+    std::vector<unsigned long long> hs(nst);
+    CHECK(hipMemcpy(hs.data(), stamps, nst * 8, hipMemcpyDeviceToHost));
+    double per = (double)(hs[63 * 3] - hs[0]) / 63.0;
+    double wt = 0, mf = 0;
+    for (int i = 0; i < 64; ++i) { wt += (double)(hs[i * 3 + 1] - hs[i * 3]); mf += (double)(hs[i * 3 + 2] - hs[i * 3 + 1]); }
+    const unsigned long long* o4 = hs.data() + (size_t)4 * 64 * 3;
+    double wt4 = 0, mf4 = 0;
+    for (int i = 0; i < 64; ++i) { wt4 += (double)(o4[i * 3 + 1] - o4[i * 3]); mf4 += (double)(o4[i * 3 + 2] - o4[i * 3 + 1]); }
+    double fl = 2.0 * nqt * 256.0 * ntiles * 256.0 * nk * 64.0;
+    double us_per_kstep = best * 1e3 / ((double)ntiles * nk * (nqt / 256.0));
+    printf("%-32s %7.2f ms %7.1f TF  cyc/K-step %.0f  clock %.2f GHz  util %.1f %%  wave0 wait %.0f mfma %.0f | wave4 wait %.0f mfma %.0f\n",
+           name, best, fl / (best * 1e-3) / 1e12, per, per / us_per_kstep / 1e3, 2048.0 / per * 100, wt / 64, mf / 64, wt4 / 64, mf4 / 64);
+    fflush(stdout);
+}
+
 int main() {
     const int d = 768, nk = d / 64;
     const int nqt = 2048 * 2;             // 4096 query tiles of 256 = 1M queries (16 blocks per CU)
@@ -181,36 +303,13 @@ int main() {
     CHECK(hipMemcpy(xb, h.data(), nb * d * 2, hipMemcpyHostToDevice));
     CHECK(hipMemcpy(xq, h.data(), nq * d * 2, hipMemcpyHostToDevice));
     unsigned long long* stamps;
-    const size_t nst = 2 * 8 * 64 * 3;
-    CHECK(hipMalloc(&stamps, nst * 8));
-    auto clock_of = [&](const char* name, int qmod) {
-        CHECK(hipMemset(stamps, 0, nst * 8));
-        hipEvent_t e0, e1;
-        CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
-        auto k = gemm_probe<2, 4, 4, 2, 2, 2, 2, 1, 0>;
-        CHECK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE));
-        float best = 1e30f;
-        for (int it = 0; it < 4; ++it) {
-            CHECK(hipEventRecord(e0));
-            hipLaunchKernelGGL(k, dim3(nqt), dim3(512), 2 * STAGE, 0, xb, xq, out, ntiles, nk, (long long)d, stamps, qmod);
-            CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
-            float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
-            if (ms < best) best = ms;
-        }
-        std::vector<unsigned long long> hs(nst);
-        CHECK(hipMemcpy(hs.data(), stamps, nst * 8, hipMemcpyDeviceToHost));
-        double per = (double)(hs[63 * 3] - hs[0]) / 63.0;
-        double fl = 2.0 * nqt * 256.0 * ntiles * 256.0 * nk * 64.0;
-        double us_per_kstep = best * 1e3 / ((double)ntiles * nk * (nqt / 256.0));
-        printf("%-34s %8.2f ms %7.1f TFLOP/s  cycles/K-step %.0f  -> clock %.2f GHz, MFMA util %.1f %%\n", name, best,
-               fl / (best * 1e-3) / 1e12, per, per / us_per_kstep / 1e3, 2048.0 / per * 100);
-        fflush(stdout);
-    };
-    clock_of("32 query tiles x 1 slab / XCD", 32);
-    clock_of("16 x 2", 16);
-    clock_of("8 x 4", 8);
-    clock_of("4 x 8", 4);
-    clock_of("2 x 16", 2);
-    clock_of("32 x 1 again", 32);
+    CHECK(hipMalloc(&stamps, 2 * 8 * 64 * 3 * 8));
+    for (int rep = 0; rep < 2; ++rep) {
+        clock_of<0, 0>("compiler order", xb, xq, out, nqt, ntiles, nk, d, stamps);
+        clock_of<3, 0>("asm waits (full)", xb, xq, out, nqt, ntiles, nk, d, stamps);
+        clock_of<3, 1>("  no LDS reads", xb, xq, out, nqt, ntiles, nk, d, stamps);
+        clock_of<3, 2>("  no staging loads", xb, xq, out, nqt, ntiles, nk, d, stamps);
+        clock_of<3, 3>("  MFMA + barrier only", xb, xq, out, nqt, ntiles, nk, d, stamps);
+    }
     return 0;
 }
