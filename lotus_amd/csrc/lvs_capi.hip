@@ -428,13 +428,27 @@ int make_plan(int64_t nq, int64_t nb, int32_t d, int32_t xb_pack, int32_t xq_pac
             break;
         }
     }
-    if (const char* e = getenv("LVS_GQ")) {
-        int v = atoi(e);
-        if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16 || v == 32) p.gq = v;
-    }
-    const int gs = 32 / p.gq;
     // enough (query tile, slab) items to load-balance 256 CUs, slabs kept >= 32 tiles, a multiple of gs slabs
     int64_t want = lvs_ceil_div(4096, p.nqt);
+    // Long corpus streams: 8 query tiles x 4 slabs per XCD share BOTH operands through the 4 MB L2 (hit rate 37 % -> 70 %,
+    // half the fabric traffic, +3 % clock) and win 1-5 % once each of >= 20 slabs still has >= 160 tiles
+    // (profiles/r01_tuning.md); shorter slabs lose more to the extra cold starts than the locality returns.
+    int64_t slabs_l2 = 0;
+    if (p.v2 && p.gq > 8 && p.nqt >= 64) {
+        const int64_t n8 = lvs_round_up(want > 20 ? want : 20, 4);
+        if (p.ntiles / n8 >= 160) {
+            p.gq = 8;
+            slabs_l2 = n8;
+        }
+    }
+    if (const char* e = getenv("LVS_GQ")) {
+        int v = atoi(e);
+        if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16 || v == 32) {
+            p.gq = v;
+            slabs_l2 = 0;
+        }
+    }
+    const int gs = 32 / p.gq;
     // few query tiles: allow slabs down to 8 tiles so that every CU gets work (cold starts are cheap)
     int64_t max_slabs = lvs_ceil_div(p.ntiles, p.nqt >= 8 ? 32 : (p.nqt >= 2 ? 16 : 8));
     int64_t s = want < 1 ? 1 : want;
@@ -442,6 +456,7 @@ int make_plan(int64_t nq, int64_t nb, int32_t d, int32_t xb_pack, int32_t xq_pac
     s = lvs_round_up(s, gs);
     if (s > p.ntiles) s = p.ntiles;
     if (s < 1) s = 1;
+    if (slabs_l2 > 0) s = slabs_l2;
     if (const char* e = getenv("LVS_NSLAB")) {  // tuning override
         int64_t v = atoll(e);
         if (v >= 1 && v <= p.ntiles) s = v;
@@ -591,6 +606,12 @@ extern "C" int32_t lvs_flat_search_keys(const void* xb, int32_t xb_pack, int64_t
             return LVS_OK;
         }
     }
+    // k == 1: the list-free per-lane running best (TOP1) wins on short streams (k-means assignment: a few corpus tiles
+    // per query, nearly every block improves some lane's best); on long streams the threshold filter of the list
+    // kernel skips almost every block, so k = 1 goes through it like any other k.  Same winner either way
+    // (best score, lowest row among equals).
+    bool use_top1 = k == 1 && !row_ids && p.tiles_per_slab <= 64;
+    if (const char* e = getenv("LVS_TOP1")) use_top1 = k == 1 && !row_ids && atoi(e) != 0;  // tuning override
     for (int pass = 0; pass < p.npass; ++pass) {
         const int col0 = pass * p.kpass;
         const int kp = (k - col0) < p.kpass ? (k - col0) : p.kpass;
@@ -602,7 +623,7 @@ extern "C" int32_t lvs_flat_search_keys(const void* xb, int32_t xb_pack, int64_t
         {
             ScopedKernelTimer timer(st);
             if (p.v2)
-                LVS_HIP_CHECK(lvs_tile2_launch(k == 1 && !row_ids ? LVS_MODE_TOP1 : LVS_MODE_TOPK, a, st));
+                LVS_HIP_CHECK(lvs_tile2_launch(use_top1 ? LVS_MODE_TOP1 : LVS_MODE_TOPK, a, st));
             else
                 LVS_HIP_CHECK(lvs_tile_launch(LVS_MODE_TOPK, a, st));
         }

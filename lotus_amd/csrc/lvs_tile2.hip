@@ -45,8 +45,10 @@ template <int N, class F>
 __device__ inline void static_for(F&& f) {
     static_for_impl(std::make_integer_sequence<int, N>{}, f);
 }
+template <int OFFSET>  // OFFSET: compile-time byte offset (16-bit immediate field of the instruction)
 __device__ inline void lds_read16(half8& dst, unsigned addr) {
-    asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(addr));
+    static_assert(OFFSET >= 0 && OFFSET < 65536, "ds_read offset field is 16 bits");
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFFSET));
 }
 template <int N>
 __device__ inline void lds_wait(half8& a, half8& b0, half8& b1) {
@@ -273,21 +275,30 @@ __global__ __launch_bounds__(512, 2) void lvs_tile2_kernel(const LvsTileArgs a) 
         constexpr int KDEPTH = 2, KBPOS = 2;  // A fragments two steps ahead, B fragments of the next kk read at mi == 2
         using Ord = KStepOrder<KDEPTH, KBPOS>;
         half8 Bf[2][2], Af[KDEPTH + 1];
+        // one address VGPR per (operand, kk); the 32-row block (mi / second query block) goes into the offset field
         const unsigned sbu = (unsigned)(unsigned long long)sb;
-        lds_read16(Bf[0][0], sbu + b_base + foff[0]);
-        lds_read16(Bf[0][1], sbu + b_base + 32 * ROWB + foff[0]);
+        unsigned a_addr[4], b_addr[4];
 #pragma unroll
-        for (int f = 0; f < KDEPTH; ++f) lds_read16(Af[f], sbu + a_base + (f & 3) * 32 * ROWB + foff[f >> 2]);
+        for (int kk = 0; kk < 4; ++kk) {
+            a_addr[kk] = (sbu + a_base) + foff[kk];
+            b_addr[kk] = (sbu + b_base) + foff[kk];
+        }
+        lds_read16<0>(Bf[0][0], b_addr[0]);
+        lds_read16<32 * ROWB>(Bf[0][1], b_addr[0]);
+        static_for<KDEPTH>([&](auto fc) {
+            constexpr int f = decltype(fc)::value;
+            lds_read16<(f & 3) * 32 * ROWB>(Af[f], a_addr[f >> 2]);
+        });
         static_for<16>([&](auto fc) {
             constexpr int f = decltype(fc)::value;
             constexpr int kk = f >> 2, mi = f & 3;
-            if (f + KDEPTH < 16) {
+            if constexpr (f + KDEPTH < 16) {
                 constexpr int f2 = f + KDEPTH;
-                lds_read16(Af[f2 % (KDEPTH + 1)], sbu + a_base + (f2 & 3) * 32 * ROWB + foff[f2 >> 2]);
+                lds_read16<(f2 & 3) * 32 * ROWB>(Af[f2 % (KDEPTH + 1)], a_addr[f2 >> 2]);
             }
-            if (mi == KBPOS && kk + 1 < 4) {
-                lds_read16(Bf[(kk + 1) & 1][0], sbu + b_base + foff[kk + 1]);
-                lds_read16(Bf[(kk + 1) & 1][1], sbu + b_base + 32 * ROWB + foff[kk + 1]);
+            if constexpr (mi == KBPOS && kk + 1 < 4) {
+                lds_read16<0>(Bf[(kk + 1) & 1][0], b_addr[kk + 1]);
+                lds_read16<32 * ROWB>(Bf[(kk + 1) & 1][1], b_addr[kk + 1]);
             }
             if (f < 8) {
                 if (f < 4)
