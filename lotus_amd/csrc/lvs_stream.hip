@@ -160,7 +160,8 @@ __global__ __launch_bounds__(WAVES * 64, 2) void lvs_stream_kernel(const LvsStre
                     __builtin_amdgcn_wave_barrier();
                     if (lane < k) UL[lane] = newv;
                     const uint32_t ntau = __builtin_amdgcn_readlane((uint32_t)(newv >> 32), k - 1);
-                    if (lane == 0) __hip_atomic_store(&locks[uq], 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    asm volatile("" ::: "memory");  // slot writes stay ahead of the unlock (LDS is in-order per wave)
+                    if (lane == 0) __hip_atomic_store(&locks[uq], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     if (q == uq) tauf = fmaxf(tauf, tau_float(ntau));
                 }
             }

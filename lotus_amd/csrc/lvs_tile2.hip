@@ -529,8 +529,11 @@ __global__ __launch_bounds__(512, 2) void lvs_tile2_kernel(const LvsTileArgs a) 
                         __builtin_amdgcn_wave_barrier();
                         if (lane < k) UL[lane] = newv;
                         const uint32_t ntau = __builtin_amdgcn_readlane((uint32_t)(newv >> 32), k - 1);
+                        // unlock: the LDS executes one wave's DS instructions in issue order, so a plain (relaxed)
+                        // store issued after the slot writes is observed after them - no wait for the writes needed
+                        asm volatile("" ::: "memory");
                         if (lane == 0)
-                            __hip_atomic_store(&locks[uq], 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            __hip_atomic_store(&locks[uq], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                         if (q == uq) tf = fmaxf(tf, tau_float(ntau));
                     }
                 }
