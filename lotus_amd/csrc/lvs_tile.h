@@ -49,7 +49,9 @@ struct LvsTileArgs {
     int metric;
     int k;                    // <= LVS_KPASS
     int ntiles, tiles_per_slab, nslab, nqt;
-    int debug_hot;            // tuning aid: every workgroup re-reads tile 0 / query tile 0 (all loads L2-hot)
+    int debug_hot;            // tuning aid (env LVS_DEBUG_HOT), timing only - results are wrong unless 0:
+                              // 2 skip the top-k slow path, 3 scan hits but skip insertions, 4 no wait for the
+                              // staging loads (256x256 kernel only)
     int gq;                   // query tiles per XCD group (1,2,4,8,16,32); slabs per group = 32 / gq
     unsigned long long* dbg;  // tuning aid (build with -DLVS_COUNT_EVENTS, run with LVS_COUNT=1): [0] block visits, [1] insertions, [2] wave-tiles
 };

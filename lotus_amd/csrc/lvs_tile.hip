@@ -113,7 +113,7 @@ __global__ __launch_bounds__(LVS_TILE_THREADS, 2) void lvs_tile_kernel(const Lvs
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         int row = wave * 16 + i * 8 + srow;
-        long long grow = a.debug_hot ? row : q0 + row;
+        long long grow = q0 + row;
         if (grow > a.nq - 1) grow = a.nq - 1;
         q_src[i] = xq + grow * ldq + (sp ^ ((row >> 1) & 7)) * 8;
     }
@@ -123,7 +123,7 @@ __global__ __launch_bounds__(LVS_TILE_THREADS, 2) void lvs_tile_kernel(const Lvs
         int seg = ks / nkd, r = ks - seg * nkd;
         int qcol = a.seg_q[seg] + r * LVS_BK;
         int ccol = a.seg_c[seg] + r * LVS_BK;
-        long long trow0 = a.debug_hot ? 0 : (long long)(tile0 + ti) * LVS_BC;
+        long long trow0 = (long long)(tile0 + ti) * LVS_BC;
         char* base = smem + buf * STAGE_BYTES;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {

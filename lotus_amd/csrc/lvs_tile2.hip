@@ -1,14 +1,19 @@
-// Second-generation tile kernel: 256 corpus rows x 256 queries per workgroup, top-k only, k <= LVS2_KCAP.
+// The dominant kernel: 256 corpus rows x 256 queries per workgroup on the matrix cores with the selection fused in.
 //
-// Same role as lvs_tile.hip (faiss IndexFlat::search behind lotus/vector_store/faiss_vs.py:67,75) and the same
-// result keys / thresholds; what changes is the geometry, chosen for L2 traffic and MFMA occupancy:
-//   score tile   256 corpus rows (MFMA M) x 256 queries (MFMA N): 128 flop per byte staged from L2 (v1: 85)
+// Replaces faiss IndexFlat::search as reached from lotus/vector_store/faiss_vs.py:67,75 (top-k, k <= LVS2_KCAP per
+// pass), the k = 1 L2 search of lotus/utils.py:62,65 (k-means assignment), the K = N score rows of the cascade callers
+// (SCORES) and the all-pairs search of lotus/sem_ops/sem_dedup.py:45-46 (RANGE: threshold self-join).  Geometry:
+//   score tile   256 corpus rows (MFMA M) x 256 queries (MFMA N): 128 flop per byte staged from L2
 //   wave layout  2 (corpus) x 4 (queries); each wave 128 x 64 = 4 x 2 accumulators of v_mfma_f32_32x32x16_f16
-//                (128 accumulator VGPRs), 32 MFMAs per wave between barriers
-//   LDS          2 x 512 rows x 128 B staging = 128 KB, which leaves 32 KB for candidates: one sorted k-list per
-//                query (256 x KCAP x 8 B) plus a lock word per query.  A score that beats its query's current k-th
-//                best is inserted at once under the query's LDS spin lock (hits are rare: ~k ln(N/k) per query per
-//                pass), so thresholds tighten immediately and the epilogue needs no workgroup barrier.
+//                (128 accumulator VGPRs), 32 MFMAs per wave between barriers; operands swapped (corpus = A, queries = B)
+//                so that a lane owns a query column and its running threshold is a register
+//   LDS          2 x 512 rows x 128 B staging (global_load_lds, source-side XOR swizzle) = 128 KB, which leaves 31 KB
+//                for candidates: one sorted k-list per query (256 x KCAP x 8 B) plus a lock word per query.  A score
+//                that beats its query's current k-th best is inserted at once by 16 cooperating lanes under the
+//                query's LDS lock (hits are rare: ~k (1 + ln(N/k)) per query), so thresholds tighten immediately
+//                and the epilogue needs no workgroup barrier.
+//   K-step       inline-asm fragment reads with counted lgkmcnt waits, see below.
+// Measurements and the tuning history: profiles/r01_tuning.md, DESIGN.md section 3.1.
 #include <type_traits>
 #include <utility>
 
@@ -20,7 +25,7 @@ namespace {
 constexpr int BC = 256, BQ = 256, BK = 64;
 constexpr int ROWB = BK * 2;
 constexpr int STAGE_BYTES = (BC + BQ) * ROWB;  // 65536
-constexpr int KCAP = LVS2_KCAP;                // 12
+constexpr int KCAP = LVS2_KCAP;                // 15 list slots per query
 constexpr int OFF_LIST = 2 * STAGE_BYTES;      // u64 [BQ][KCAP] sorted descending, first k used
 constexpr int OFF_LOCK = OFF_LIST + BQ * KCAP * 8;  // u32 [BQ] spin locks
 constexpr int LDS_TOTAL = OFF_LOCK + BQ * 4;
@@ -145,7 +150,7 @@ __global__ __launch_bounds__(512, 2) void lvs_tile2_kernel(const LvsTileArgs a) 
     const _Float16* q_src[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        long long grow = a.debug_hot ? s_row[i] : q0 + s_row[i];
+        long long grow = q0 + s_row[i];
         if (grow > a.nq - 1) grow = a.nq - 1;
         q_src[i] = xq + grow * ldq + s_col[i];
     }
@@ -155,7 +160,7 @@ __global__ __launch_bounds__(512, 2) void lvs_tile2_kernel(const LvsTileArgs a) 
         int seg = ks / nkd, r = ks - seg * nkd;
         int qcol = a.seg_q[seg] + r * BK;
         int ccol = a.seg_c[seg] + r * BK;
-        long long trow0 = a.debug_hot ? 0 : (long long)(tile0 + ti) * BC;
+        long long trow0 = (long long)(tile0 + ti) * BC;
         char* base = smem + buf * STAGE_BYTES;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -213,9 +218,9 @@ __global__ __launch_bounds__(512, 2) void lvs_tile2_kernel(const LvsTileArgs a) 
     unsigned c_loff[4], q_loff[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        long long qrow = a.debug_hot ? s_row[i] : q0 + s_row[i];
+        long long qrow = q0 + s_row[i];
         if (qrow > a.nq - 1) qrow = a.nq - 1;
-        q_loff[i] = (unsigned)(((qrow - (a.debug_hot ? 0 : q0)) * ldq + s_col[i]) * 2);
+        q_loff[i] = (unsigned)(((qrow - q0) * ldq + s_col[i]) * 2);
     }
     auto set_tile_offsets = [&](int tile_rel) {  // rows past the end of the shard re-read the last valid row
         const long long trow0 = (long long)(tile0 + tile_rel) * BC;
@@ -239,7 +244,6 @@ __global__ __launch_bounds__(512, 2) void lvs_tile2_kernel(const LvsTileArgs a) 
 #ifdef LVS_COUNT_EVENTS
     unsigned n_visit = 0, n_ins = 0, n_wt = 0;  // tuning aid, see a.dbg
 #endif
-    const int pubmask = a.debug_hot == 5 ? 0 : (a.debug_hot == 6 ? 1 : (a.debug_hot == 7 ? 3 : 7));  // tuning aid
     for (int t = 0; t < T; ++t) {
         const int buf = t & 1;
         if (a.debug_hot == 4) {  // tuning aid: no wait for the staging loads (results are garbage, timing only)
@@ -300,12 +304,10 @@ __global__ __launch_bounds__(512, 2) void lvs_tile2_kernel(const LvsTileArgs a) 
                 lds_read16<0>(Bf[(kk + 1) & 1][0], b_addr[kk + 1]);
                 lds_read16<32 * ROWB>(Bf[(kk + 1) & 1][1], b_addr[kk + 1]);
             }
-            if (f < 8) {
-                if (f < 4)
-                    glds16(c_sbase + c_loff[f], n_base + (wave * 32 + f * 8) * ROWB);
-                else
-                    glds16(q_sbase + q_loff[f - 4], n_base + BC * ROWB + (wave * 32 + (f - 4) * 8) * ROWB);
-            }
+            if constexpr (f < 4)
+                glds16(c_sbase + c_loff[f], n_base + (wave * 32 + f * 8) * ROWB);
+            else if constexpr (f < 8)
+                glds16(q_sbase + q_loff[f - 4], n_base + BC * ROWB + (wave * 32 + (f - 4) * 8) * ROWB);
             __builtin_amdgcn_sched_barrier(0);
             lds_wait<Ord::wait(f)>(Af[f % (KDEPTH + 1)], Bf[kk & 1][0], Bf[kk & 1][1]);
             acc[mi][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Af[f % (KDEPTH + 1)], Bf[kk & 1][0], acc[mi][0], 0, 0, 0);
@@ -477,9 +479,18 @@ __global__ __launch_bounds__(512, 2) void lvs_tile2_kernel(const LvsTileArgs a) 
                 const u64 ubq = ni ? ubk[1] : ubk[0];
                 const uint32_t go = ni ? gord[1] : gord[0];
                 const long long rbase = trow0 + lrow_base + mi * 32;
+                // the visiting wave is on the workgroup's critical path (the next barrier waits for it): let its
+                // instructions win the issue arbitration against the other wave's MFMAs
+                __builtin_amdgcn_s_setprio(3);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
+                for (int g4 = 0; g4 < 4; ++g4) {  // rows 8g .. 8g+3: skip the group when none of its four scores can enter
+                    const float m4 = fmaxf(fmaxf(tv[4 * g4], tv[4 * g4 + 1]), fmaxf(tv[4 * g4 + 2], tv[4 * g4 + 3]));
+                    if (!__any(th && m4 >= tf)) continue;
+#pragma unroll
+                for (int e4 = 0; e4 < 4; ++e4) {
+                    const int r = 4 * g4 + e4;
                     const float s = tv[r];
+                    if (!__any(th && s >= tf)) continue;  // wave-uniform skip before any per-lane work
                     bool pending = false;
                     u64 key = 0;
                     if (th && s >= tf) {
@@ -537,11 +548,13 @@ __global__ __launch_bounds__(512, 2) void lvs_tile2_kernel(const LvsTileArgs a) 
                         if (q == uq) tf = fmaxf(tf, tau_float(ntau));
                     }
                 }
+                }  // g4
+                if (wave >= 4) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
                 if (ni) tauf[1] = fmaxf(tauf[1], tf); else tauf[0] = fmaxf(tauf[0], tf);
             }
         }
         // publish thresholds for the other slabs of these queries every 8 tiles and at the end of the item
-        if (((ti & pubmask) == 0) || t + 1 == T) {
+        if (((ti & 7) == 0) || t + 1 == T) {
 #pragma unroll
             for (int ni = 0; ni < 2; ++ni) {
                 const uint32_t lo = (uint32_t)(lists[qloc[ni] * KCAP + k - 1] >> 32);

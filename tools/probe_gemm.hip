@@ -29,6 +29,10 @@ __device__ inline void lds_read16(half8& dst, unsigned addr) {
     asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(addr));
 }
 template <int N>
+__device__ inline void lds_wait5(half8& a, half8& b0, half8& b1, half8& b2, half8& b3) {
+    asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(a), "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3) : "n"(N));
+}
+template <int N>
 __device__ inline void lds_wait(half8& a, half8& b0, half8& b1) {
     asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(a), "+v"(b0), "+v"(b1) : "n"(N));
 }
@@ -36,24 +40,24 @@ __device__ inline void lds_wait(half8& a, half8& b0, half8& b1) {
 //   prologue: B(0)[0], B(0)[1], A(0) .. A(DEPTH-1);  step f: A(f+DEPTH) (if any), then B(kk+1)[0..1] when mi == BPOS.
 // pos_A(f) / pos_B(kk): 0-based issue index of the LAST read that MFMA step f needs; issued(f): reads issued up to and
 // including step f's own issues.  The counted wait before step f's MFMAs is lgkmcnt(issued(f) - 1 - needed).
-template <int MI, int DEPTH, int BPOS>
+template <int MI, int DEPTH, int BPOS, int NB = 2>
 struct KStepOrder {
     static constexpr int NF = 4 * MI;
     static constexpr int issued(int f) {
-        int c = 2 + DEPTH;
+        int c = NB + DEPTH;
         for (int g = 0; g <= f; ++g) {
             if (g + DEPTH < NF) ++c;
-            if (g % MI == BPOS && g / MI + 1 < 4) c += 2;
+            if (g % MI == BPOS && g / MI + 1 < 4) c += NB;
         }
         return c;
     }
     static constexpr int pos_A(int f) {
-        if (f < DEPTH) return 2 + f;
+        if (f < DEPTH) return NB + f;
         // issued at step g = f - DEPTH as the first read of that step
         return issued(f - DEPTH - 1 < 0 ? -1 : f - DEPTH - 1);
     }
     static constexpr int pos_B(int kk) {
-        if (kk == 0) return 1;
+        if (kk == 0) return NB - 1;
         const int g = (kk - 1) * MI + BPOS;  // step that issued B(kk): after that step's A read (if any)
         return issued(g) - 1;
     }
@@ -140,7 +144,41 @@ __global__ __launch_bounds__(WM * WN * 64, WPE) void gemm_probe(const _Float16* 
         const char* sb = smem + buf * STAGE;
         const int tn = t + 1 < T ? t + 1 : T - 1;
         const int nti0 = tn / nk, nks = tn - nti0 * nk; const int nti = (nti0 + tile0) % ntiles;
-        if constexpr (SPREAD == 3) {
+        if constexpr (SPREAD == 4) {
+            // one wave per SIMD: 4 waves of 128 x 128 (MI = NI = 4), asm-scheduled, 16 staging loads per wave and K-step
+            static_assert(NI == 4 && MI == 4, "written for 4 x 4 accumulator blocks");
+            using Ord = KStepOrder<MI, DEPTH, BPOS, 4>;
+            half8 Bf[2][4], Af[DEPTH + 1];
+            const unsigned sbu = (unsigned)(unsigned long long)sb;
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) lds_read16(Bf[0][ni], sbu + b_base + ni * 32 * ROWB + foff[0]);
+#pragma unroll
+            for (int f = 0; f < DEPTH; ++f) lds_read16(Af[f], sbu + a_base + (f % MI) * 32 * ROWB + foff[f / MI]);
+            static_for<16>([&](auto fc) {
+                constexpr int f = decltype(fc)::value;
+                constexpr int kk = f / 4, mi = f % 4;
+                if constexpr (f + DEPTH < 16) {
+                    constexpr int f2 = f + DEPTH;
+                    lds_read16(Af[f2 % (DEPTH + 1)], sbu + a_base + (f2 % 4) * 32 * ROWB + foff[f2 / 4]);
+                }
+                if constexpr (mi == BPOS && kk + 1 < 4) {
+#pragma unroll
+                    for (int ni = 0; ni < 4; ++ni) lds_read16(Bf[(kk + 1) & 1][ni], sbu + b_base + ni * 32 * ROWB + foff[kk + 1]);
+                }
+                if (f < GL) {
+                    int row = wave * RPW + f * 8;
+                    bool isq = row >= BC;
+                    long long tile_off = isq ? 0 : (long long)nti * BC * ld * 2;
+                    glds16(sbase[f] + tile_off + loff[f] + nks * BK * 2, smem + (buf ^ 1) * STAGE + row * ROWB);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                lds_wait5<Ord::wait(f)>(Af[f % (DEPTH + 1)], Bf[kk & 1][0], Bf[kk & 1][1], Bf[kk & 1][2], Bf[kk & 1][3]);
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Af[f % (DEPTH + 1)], Bf[kk & 1][ni], acc[mi][ni], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        } else if constexpr (SPREAD == 3) {
             // asm-scheduled K-step: LDS reads and their counted waits are inline asm, order pinned by sched_barrier
             static_assert(NI == 2, "asm K-step is written for NI == 2");
             using Ord = KStepOrder<MI, DEPTH, BPOS>;
@@ -302,14 +340,11 @@ int main() {
     CHECK(hipMalloc(&out, (size_t)nqt * 16 * 64 * 4 * 4));
     CHECK(hipMemcpy(xb, h.data(), nb * d * 2, hipMemcpyHostToDevice));
     CHECK(hipMemcpy(xq, h.data(), nq * d * 2, hipMemcpyHostToDevice));
-    unsigned long long* stamps;
-    CHECK(hipMalloc(&stamps, 2 * 8 * 64 * 3 * 8));
     for (int rep = 0; rep < 2; ++rep) {
-        clock_of<0, 0>("compiler order", xb, xq, out, nqt, ntiles, nk, d, stamps);
-        clock_of<3, 0>("asm waits (full)", xb, xq, out, nqt, ntiles, nk, d, stamps);
-        clock_of<3, 1>("  no LDS reads", xb, xq, out, nqt, ntiles, nk, d, stamps);
-        clock_of<3, 2>("  no staging loads", xb, xq, out, nqt, ntiles, nk, d, stamps);
-        clock_of<3, 3>("  MFMA + barrier only", xb, xq, out, nqt, ntiles, nk, d, stamps);
+        run<2, 4, 4, 2, 2, 2, 2, 1, 3>("8 waves 128x64, asm waits", xb, xq, out, nqt, ntiles, nk, d);
+        run<2, 2, 4, 4, 1, 2, 2, 0, 4>("4 waves 128x128, asm, depth 2, B at 2", xb, xq, out, nqt, ntiles, nk, d);
+        run<2, 2, 4, 4, 1, 3, 1, 0, 4>("4 waves 128x128, asm, depth 3, B at 1", xb, xq, out, nqt, ntiles, nk, d);
+        run<2, 2, 4, 4, 1, 2, 0, 0, 4>("4 waves 128x128, asm, depth 2, B at 0", xb, xq, out, nqt, ntiles, nk, d);
     }
     return 0;
 }
