@@ -151,7 +151,7 @@ def main():
             "planted_neighbour_at_rank1": planted_at_1,
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP16_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP16_MFMA_TFLOPS, "traffic": pmc_traffic(n, nq, world),
-                         "kernel": "lvs_tile2_kernel<TOPK>", "kernel_ms": kernel_ms, "launches": klaunches,
+                         "kernel": "lvs_tile_kernel<TOPK, 256x256>", "kernel_ms": kernel_ms, "launches": klaunches,
                          "algorithmic_flops_per_launch": flops_per_launch,
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "hbm_frac_secondary": alg_bytes / (kernel_ms * 1e-3) / 1e9 / PEAK_HBM_GBS},

@@ -385,12 +385,12 @@ struct Plan {
     int ntiles, nqt, nslab, tiles_per_slab;
     int kpass, npass;
     int gq;
-    int v2;  // 1: 256x256 kernel (lvs_tile2.hip), top-k with k <= LVS2_KCAP
+    int v2;  // 1: 256 x 256 geometry (k <= LVS2_KCAP, TOP1 / SCORES / RANGE); 0: 256 x 128 geometry (k > LVS2_KCAP)
     int64_t off_gtau, off_partial, off_pass, total;
 };
 
 int make_plan(int64_t nq, int64_t nb, int32_t d, int32_t xb_pack, int32_t xq_pack, int32_t k, Plan& p,
-              bool allow_v2 = true, bool force_v2 = false) {
+              bool force_v2 = false) {
     if (nq < 0 || nb < 0 || d <= 0 || k < 0) return LVS_EINVAL;
     if (xb_pack != LVS_PACK_F16 && xb_pack != LVS_PACK_SPLIT) return LVS_EINVAL;
     if (xq_pack != LVS_PACK_F16 && xq_pack != LVS_PACK_SPLIT) return LVS_EINVAL;
@@ -411,16 +411,14 @@ int make_plan(int64_t nq, int64_t nb, int32_t d, int32_t xb_pack, int32_t xq_pac
     if (xq_pack == LVS_PACK_SPLIT) seg(p.dpad, 0);
     p.nk = p.nseg * p.nkd;
     p.ntiles = (int)lvs_ceil_div(nb > 0 ? nb : 1, LVS_BC);
-    p.v2 = force_v2 || (allow_v2 && k >= 1 && k <= LVS2_KCAP);
-    if (const char* e = getenv("LVS_KERNEL")) {  // tuning override: 1 = 256x128 kernel, 2 = 256x256 kernel
-        if (atoi(e) == 1) p.v2 = 0;
-    }
-    p.nqt = (int)lvs_ceil_div(nq > 0 ? nq : 1, p.v2 ? LVS2_BQ : LVS_BQ);
+    // geometry: 256 queries per tile with 15 list slots (k <= 15 and every non-top-k mode), else 128 queries / 56 slots
+    p.v2 = force_v2 || k <= LVS2_KCAP;
+    p.nqt = (int)lvs_ceil_div(nq > 0 ? nq : 1, p.v2 ? LVS2_BQ : LVS3_BQ);
     // XCD group = gq query tiles x (32 / gq) slabs resident on one XCD at a time.  Wide groups (one corpus stream per
     // XCD) are fastest (profiles/r01_tuning.md) but must be full: groups are dealt round-robin to the 8 XCDs, so a
     // half-empty group idles half an XCD.  Take the widest gq that wastes < 15 % of its query-tile slots.
     p.gq = 1;
-    const int gq_max = p.v2 ? 32 : 8;
+    const int gq_max = 32;
     for (int g = gq_max; g >= 1; g >>= 1) {
         const double fill = (double)p.nqt / (double)(lvs_ceil_div(p.nqt, g) * g);
         if (fill >= 0.85) {
@@ -463,7 +461,7 @@ int make_plan(int64_t nq, int64_t nb, int32_t d, int32_t xb_pack, int32_t xq_pac
     }
     p.tiles_per_slab = (int)lvs_ceil_div(p.ntiles, s);
     p.nslab = (int)lvs_ceil_div(p.ntiles, p.tiles_per_slab);
-    p.kpass = k < LVS_KPASS ? (k > 0 ? k : 1) : LVS_KPASS;
+    p.kpass = k < LVS_KPASS ? (k > 0 ? k : 1) : LVS_KPASS;  // k <= 15 -> one pass on the 256-query geometry
     p.npass = k > 0 ? (int)lvs_ceil_div(k, p.kpass) : 0;
     int64_t off = 0;
     p.off_gtau = off;
@@ -547,6 +545,7 @@ extern "C" int32_t lvs_flat_search_keys(const void* xb, int32_t xb_pack, int64_t
     a.tiles_per_slab = p.tiles_per_slab;
     a.nslab = p.nslab;
     a.nqt = p.nqt;
+    a.bq = p.v2 ? LVS2_BQ : LVS3_BQ;
     a.gq = p.gq;
     a.debug_hot = getenv("LVS_DEBUG_HOT") ? atoi(getenv("LVS_DEBUG_HOT")) : 0;
     a.dbg = nullptr;
@@ -622,10 +621,7 @@ extern "C" int32_t lvs_flat_search_keys(const void* xb, int32_t xb_pack, int64_t
         LVS_HIP_CHECK(hipMemsetAsync(gtau, 0, (size_t)nq * 4, st));
         {
             ScopedKernelTimer timer(st);
-            if (p.v2)
-                LVS_HIP_CHECK(lvs_tile2_launch(use_top1 ? LVS_MODE_TOP1 : LVS_MODE_TOPK, a, st));
-            else
-                LVS_HIP_CHECK(lvs_tile_launch(LVS_MODE_TOPK, a, st));
+            LVS_HIP_CHECK(lvs_tile_launch(use_top1 ? LVS_MODE_TOP1 : LVS_MODE_TOPK, a, st));
         }
         dim3 mgrid((unsigned)lvs_ceil_div(nq, 4)), mblock(256);
         if (p.npass == 1 && kp == 1) {
@@ -683,7 +679,7 @@ extern "C" int32_t lvs_scores(const void* xb, int32_t xb_pack, int64_t nb, const
                               int32_t d, int32_t metric, const float* xb_norms_sq, const float* xq_norms_sq, float* out,
                               int64_t ld_out, void* stream) {
     Plan p;
-    LVS_REQUIRE(make_plan(nq, nb, d, xb_pack, xq_pack, 1, p, true, true) == LVS_OK, "bad shape");
+    LVS_REQUIRE(make_plan(nq, nb, d, xb_pack, xq_pack, 1, p, true) == LVS_OK, "bad shape");
     LVS_REQUIRE(metric == LVS_METRIC_IP || metric == LVS_METRIC_L2, "bad metric %d", metric);
     if (nq == 0 || nb == 0) return LVS_OK;
     LVS_REQUIRE(xb && xq && out && ld_out >= nb, "bad buffers");
@@ -713,9 +709,9 @@ extern "C" int32_t lvs_scores(const void* xb, int32_t xb_pack, int64_t nb, const
     a.tiles_per_slab = p.tiles_per_slab;
     a.nslab = p.nslab;
     a.nqt = p.nqt;
+    a.bq = p.v2 ? LVS2_BQ : LVS3_BQ;
     a.gq = p.gq;
-    LVS_HIP_CHECK(p.v2 ? lvs_tile2_launch(LVS_MODE_SCORES, a, (hipStream_t)stream)
-                       : lvs_tile_launch(LVS_MODE_SCORES, a, (hipStream_t)stream));
+    LVS_HIP_CHECK(lvs_tile_launch(LVS_MODE_SCORES, a, (hipStream_t)stream));
     return LVS_OK;
 }
 
@@ -725,7 +721,7 @@ extern "C" int32_t lvs_range_join(const void* xb, int32_t xb_pack, int64_t nb, c
                                   int32_t qt_phase, int64_t capacity, int64_t* out_q, int64_t* out_j, float* out_s,
                                   uint64_t* out_count, void* stream) {
     Plan p;
-    LVS_REQUIRE(make_plan(nq, nb, d, xb_pack, xq_pack, 1, p, true, true) == LVS_OK, "bad shape");
+    LVS_REQUIRE(make_plan(nq, nb, d, xb_pack, xq_pack, 1, p, true) == LVS_OK, "bad shape");
     LVS_REQUIRE(metric == LVS_METRIC_IP || metric == LVS_METRIC_L2, "bad metric %d", metric);
     LVS_REQUIRE(capacity >= 0 && out_count, "bad output buffers");
     LVS_REQUIRE(qt_stride >= 1 && qt_phase >= 0 && qt_phase < qt_stride, "bad tile dealing %d/%d", qt_phase, qt_stride);
@@ -756,6 +752,7 @@ extern "C" int32_t lvs_range_join(const void* xb, int32_t xb_pack, int64_t nb, c
     a.tiles_per_slab = p.tiles_per_slab;
     a.nslab = p.nslab;
     a.nqt = p.nqt;
+    a.bq = p.v2 ? LVS2_BQ : LVS3_BQ;
     a.gq = p.gq;
     a.pair_q = (long long*)out_q;
     a.pair_j = (long long*)out_j;
@@ -766,7 +763,6 @@ extern "C" int32_t lvs_range_join(const void* xb, int32_t xb_pack, int64_t nb, c
     a.threshold = threshold;
     a.qt_stride = qt_stride;
     a.qt_phase = qt_phase;
-    LVS_HIP_CHECK(p.v2 ? lvs_tile2_launch(LVS_MODE_RANGE, a, (hipStream_t)stream)
-                       : lvs_tile_launch(LVS_MODE_RANGE, a, (hipStream_t)stream));
+    LVS_HIP_CHECK(lvs_tile_launch(LVS_MODE_RANGE, a, (hipStream_t)stream));
     return LVS_OK;
 }

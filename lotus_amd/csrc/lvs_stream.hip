@@ -134,7 +134,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void lvs_stream_kernel(const LvsStre
                     }
                 }
                 unsigned long long pm = __ballot(pending);
-                while (pm) {  // wave-cooperative sorted insertion (see lvs_tile2.hip)
+                while (pm) {  // wave-cooperative sorted insertion (see lvs_tile.hip)
                     const int src = __ffsll((long long)pm) - 1;
                     pm &= pm - 1;
                     const uint32_t klo = __builtin_amdgcn_readlane((uint32_t)key, src);

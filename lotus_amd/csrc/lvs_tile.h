@@ -1,17 +1,15 @@
-// Launch interface of the tiled distance / top-k kernel (lvs_tile.hip).
+// Launch interface of the tiled distance / top-k kernel (lvs_tile.hip) and the small-batch kernel (lvs_stream.hip).
 #pragma once
 #include "lvs_common.h"
 
 #define LVS_BC 256          // corpus rows per score tile (MFMA M)
-#define LVS_BQ 128          // queries per score tile (MFMA N)
 #define LVS_BK 64           // halfs per K-step
-#define LVS_LCAP 32         // candidate slots per query in LDS
-#define LVS_KPASS 24        // largest k one pass selects (LCAP minus head-room)
-#define LVS_TILE_THREADS 512
-#define LVS_TILE_LDS_BYTES (2 * (LVS_BC + LVS_BQ) * LVS_BK * 2 + LVS_BQ * LVS_LCAP * 8 + LVS_BQ * 8 + LVS_BQ * 4 + 16)
 
-#define LVS2_KCAP 15        // largest k of the 256x256 kernel (lvs_tile2.hip)
-#define LVS2_BQ 256
+#define LVS2_KCAP 15        // 256 x 256 geometry: list slots per query = largest k per pass
+#define LVS2_BQ 256         //                     queries per score tile (MFMA N)
+#define LVS3_KCAP 56        // 256 x 128 geometry (k > LVS2_KCAP): list slots per query = largest k per pass
+#define LVS3_BQ 128
+#define LVS_KPASS LVS3_KCAP // largest k any single pass selects; k up to LVS_MAX_K runs ceil(k / LVS_KPASS) passes
 
 #define LVS_MODE_TOPK 0
 #define LVS_MODE_SCORES 1
@@ -47,7 +45,8 @@ struct LvsTileArgs {
     int nseg;                 // K segments: product = sum over segments of q[seg_q..] . y[seg_c..]
     int seg_q[3], seg_c[3];   // column offsets (halfs) of each segment in the query / corpus rows
     int metric;
-    int k;                    // <= LVS_KPASS
+    int k;                    // <= the geometry's list capacity
+    int bq;                   // queries per tile the plan was made for: LVS2_BQ (256 x 256 geometry) or LVS3_BQ
     int ntiles, tiles_per_slab, nslab, nqt;
     int debug_hot;            // tuning aid (env LVS_DEBUG_HOT), timing only - results are wrong unless 0:
                               // 2 skip the top-k slow path, 3 scan hits but skip insertions, 4 no wait for the
@@ -58,7 +57,6 @@ struct LvsTileArgs {
 
 int lvs_tile_grid_blocks(int nqt, int nslab, int gq);
 hipError_t lvs_tile_launch(int mode, const LvsTileArgs& a, hipStream_t stream);
-hipError_t lvs_tile2_launch(int mode, const LvsTileArgs& a, hipStream_t stream);
 
 // ---- small-batch streaming kernel (lvs_stream.hip): nq <= 32, k <= 15 ----
 #define LVS_STREAM_MAXQ 32

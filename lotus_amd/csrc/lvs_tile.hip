@@ -1,43 +1,101 @@
-// Tiled brute-force distance kernel with fused per-query top-k for gfx950 (MI355X, wave64, MFMA).
+// The dominant kernel: 256 corpus rows x 256 queries per workgroup on the matrix cores with the selection fused in.
 //
-// Replaces faiss IndexFlat::search as reached from lotus/vector_store/faiss_vs.py:67,75 (and the k = 1 L2
-// search of lotus/utils.py:62,65).  Not a port: faiss computes sgemm blocks and heap-inserts every score on the
-// CPU; here one workgroup owns a 128-query tile, walks a slab of 256-row corpus tiles, accumulates the
-// 256 x 128 score tile over the whole embedding dimension on the matrix cores, and filters it against
-// per-query running thresholds so that almost no score ever leaves the registers.
-//
-// Geometry (one workgroup = 8 waves = 512 threads, 1 workgroup per CU):
-//   score tile   256 corpus rows (MFMA M) x 128 queries (MFMA N); K-step 64 halfs
-//   wave layout  4 (corpus) x 2 (queries); each wave 64 x 64 = 2 x 2 v_mfma_f32_32x32x16_f16 accumulators
-//   operands     corpus = A, queries = B  ->  D[i = corpus row][j = query]; lane l holds query j = l & 31 of a
-//                32-wide block, so a query's running threshold is a per-lane register ("swapped" product)
-//   LDS          2 x (256 + 128) rows x 128 B staging (global_load_lds, 16 B per lane, XOR-swizzled chunks)
-//                + 128 queries x 32 candidate slots x 8 B + thresholds/counters   = 132.6 KB
-//
-// fp32 embeddings (LVS_PACK_SPLIT): every value is carried as an fp16 pair hi + lo and the product is
-// hi*hi + hi*lo + lo*hi: the same kernel runs three K segments (3 x the MFMA work, ~2^-21 relative error).
+// Replaces faiss IndexFlat::search as reached from lotus/vector_store/faiss_vs.py:67,75 (top-k, k <= LVS2_KCAP per
+// pass), the k = 1 L2 search of lotus/utils.py:62,65 (k-means assignment), the K = N score rows of the cascade callers
+// (SCORES) and the all-pairs search of lotus/sem_ops/sem_dedup.py:45-46 (RANGE: threshold self-join).  Geometry:
+//   score tile   256 corpus rows (MFMA M) x 256 queries (MFMA N): 128 flop per byte staged from L2
+//   wave layout  2 (corpus) x 4 (queries); each wave 128 x 64 = 4 x 2 accumulators of v_mfma_f32_32x32x16_f16
+//                (128 accumulator VGPRs), 32 MFMAs per wave between barriers; operands swapped (corpus = A, queries = B)
+//                so that a lane owns a query column and its running threshold is a register
+//   LDS          2 x 512 rows x 128 B staging (global_load_lds, source-side XOR swizzle) = 128 KB, which leaves 31 KB
+//                for candidates: one sorted k-list per query (256 x KCAP x 8 B) plus a lock word per query.  A score
+//                that beats its query's current k-th best is inserted at once by 16 cooperating lanes under the
+//                query's LDS lock (hits are rare: ~k (1 + ln(N/k)) per query), so thresholds tighten immediately
+//                and the epilogue needs no workgroup barrier.
+//   K-step       inline-asm fragment reads with counted lgkmcnt waits, see below.
+// Measurements and the tuning history: profiles/r01_tuning.md, DESIGN.md section 3.1.
+#include <type_traits>
+#include <utility>
+
 #include "lvs_common.h"
 #include "lvs_tile.h"
 
 namespace {
 
-constexpr int ROWB = LVS_BK * 2;                          // bytes per staged row (128)
-constexpr int STAGE_BYTES = (LVS_BC + LVS_BQ) * ROWB;     // one staging buffer (49152)
-constexpr int OFF_LIST = 2 * STAGE_BYTES;                 // candidate lists u64 [BQ][LCAP]
-constexpr int OFF_TAU = OFF_LIST + LVS_BQ * LVS_LCAP * 8; // u64 [BQ] k-th best key at last compaction
-constexpr int OFF_CNT = OFF_TAU + LVS_BQ * 8;             // u32 [BQ] list fill
-constexpr int OFF_FLAG = OFF_CNT + LVS_BQ * 4;            // u32 [2] overflow flags (ping-pong) + pad
-constexpr int LDS_TOTAL = OFF_FLAG + 16;
-static_assert(LDS_TOTAL <= 160 * 1024, "LDS budget");
-static_assert(LDS_TOTAL == LVS_TILE_LDS_BYTES, "keep lvs_tile.h in sync");
+constexpr int BC = 256, BK = 64;
+constexpr int ROWB = BK * 2;
+
+// Two geometries of the same kernel, selected by MI = 32-row accumulator blocks per wave in the corpus direction:
+//   MI = 4: waves 2 (corpus) x 4 (queries), wave tile 128 x 64, 256 queries per workgroup, 15 list slots per query
+//           (k <= 15 per pass) - the fast one, everything above describes it;
+//   MI = 2: waves 4 x 2, wave tile 64 x 64, 128 queries per workgroup; the 32 KB of staging this frees hold 56 list
+//           slots per query (16 <= k <= 56 per pass).  Top-k mode only.
+template <int MI>
+struct Geo {
+    static_assert(MI == 4 || MI == 2, "two geometries");
+    static constexpr int WN = MI;                    // wave columns (queries); wave rows WM = 8 / WN
+    static constexpr int WM = 8 / WN;
+    static constexpr int BQ = WN * 64;               // queries per workgroup
+    static constexpr int QG = BQ / 64;               // staging loads (8 rows each) per wave for the query rows
+    static constexpr int NF = 4 * MI;                // steps (2 MFMAs each) per K-step
+    static constexpr int STAGE_BYTES = (BC + BQ) * ROWB;
+    static constexpr int KCAP = MI == 4 ? LVS2_KCAP : LVS3_KCAP;
+    static constexpr int OFF_LIST = 2 * STAGE_BYTES;             // u64 [BQ][KCAP] sorted descending, first k used
+    static constexpr int OFF_LOCK = OFF_LIST + BQ * KCAP * 8;    // u32 [BQ] list locks
+    static constexpr int LDS_TOTAL = OFF_LOCK + BQ * 4;
+    static_assert(LDS_TOTAL <= 160 * 1024, "LDS budget");
+    static_assert(KCAP <= 64, "one lane per list slot");
+};
 
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef const __attribute__((address_space(1))) void gbl_void_t;
 
 __device__ inline void glds16(const void* gsrc, void* ldst) {
-    // 16 B per lane, LDS destination = wave-uniform base + lane * 16
     __builtin_amdgcn_global_load_lds((gbl_void_t*)gsrc, (lds_void_t*)ldst, 16, 0, 0);
 }
+
+// ---- asm-scheduled K-step ------------------------------------------------------------------------------------
+// hipcc sinks every LDS fragment read to just before its first use and waits with lgkmcnt(0), which undoes the
+// software pipelining written in the source.  The fragment reads and their waits are therefore inline asm: reads are
+// issued in source order (pinned by sched_barrier), waits are COUNTED (LDS returns a wave's reads in issue order).
+template <int... Is, class F>
+__device__ inline void static_for_impl(std::integer_sequence<int, Is...>, F&& f) {
+    (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, class F>
+__device__ inline void static_for(F&& f) {
+    static_for_impl(std::make_integer_sequence<int, N>{}, f);
+}
+template <int OFFSET>  // OFFSET: compile-time byte offset (16-bit immediate field of the instruction)
+__device__ inline void lds_read16(half8& dst, unsigned addr) {
+    static_assert(OFFSET >= 0 && OFFSET < 65536, "ds_read offset field is 16 bits");
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFFSET));
+}
+template <int N>
+__device__ inline void lds_wait(half8& a, half8& b0, half8& b1) {
+    asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(a), "+v"(b0), "+v"(b1) : "n"(N));
+}
+// Issue order of one K-step (4 * MI steps f = kk * MI + mi): prologue B(0)[0], B(0)[1], A(0) .. A(DEPTH-1); step f issues
+// A(f + DEPTH) (if any), then B(kk+1)[0..1] when mi == BPOS.  wait(f) = reads that may still be outstanding when step
+// f's MFMAs start = (reads issued so far) - 1 - (issue index of the last read step f needs).
+template <int MI, int DEPTH, int BPOS>
+struct KStepOrder {
+    static constexpr int NF = 4 * MI;
+    static constexpr int issued(int f) {
+        int c = 2 + DEPTH;
+        for (int g = 0; g <= f; ++g) {
+            if (g + DEPTH < NF) ++c;
+            if (g % MI == BPOS && g / MI + 1 < 4) c += 2;
+        }
+        return c;
+    }
+    static constexpr int pos_A(int f) { return f < DEPTH ? 2 + f : issued(f - DEPTH - 1); }
+    static constexpr int pos_B(int kk) { return kk == 0 ? 1 : issued((kk - 1) * MI + BPOS) - 1; }
+    static constexpr int wait(int f) {
+        const int a = pos_A(f), b = pos_B(f / MI);
+        return issued(f) - 1 - (a > b ? a : b);
+    }
+};
 
 __device__ inline float max16(const f32x16& v) {
     float a = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
@@ -49,14 +107,11 @@ __device__ inline float max16(const f32x16& v) {
 
 __device__ inline float tau_float(uint32_t ord) { return ord == 0 ? -INFINITY : lvs_unord32(ord); }
 
-// blockIdx -> (query tile, slab).  Blocks are dealt round-robin to the 8 XCDs (block b runs on XCD b % 8,
-// observed; used for speed only).  Each XCD walks "groups" of 8 query tiles x 4 slabs = 32 blocks, i.e. what is
-// resident on its 32 CUs at a time shares 8 query tiles (1.5 MB, stays in the 4 MB L2) and 4 corpus streams.
 __device__ inline bool item_of_block(const LvsTileArgs& a, int b, int& qt, int& slab) {
     int x = b & 7, j = b >> 3;
     int gseq = j >> 5, r = j & 31;
     int g = gseq * 8 + x;
-    int gq = a.gq, gs = 32 / a.gq;  // group = gq query tiles x gs slabs = 32 blocks
+    int gq = a.gq, gs = 32 / a.gq;
     int nqg = (a.nqt + gq - 1) / gq;
     int qgroup = g % nqg, sgroup = g / nqg;
     qt = qgroup * gq + (r % gq);
@@ -66,84 +121,92 @@ __device__ inline bool item_of_block(const LvsTileArgs& a, int b, int& qt, int& 
 
 }  // namespace
 
-template <int MODE>
-__global__ __launch_bounds__(LVS_TILE_THREADS, 2) void lvs_tile_kernel(const LvsTileArgs a) {
+// MODE  TOPK: sorted lists (k <= KCAP); TOP1: k == 1, per-lane best; RANGE: threshold join; SCORES: matrix out
+template <int MODE, int MI>
+__global__ __launch_bounds__(512, 2) void lvs_tile_kernel(const LvsTileArgs a) {
+    using G = Geo<MI>;
+    constexpr int BQ = G::BQ, QG = G::QG, NF = G::NF, KCAP = G::KCAP, STAGE_BYTES = G::STAGE_BYTES;
+    constexpr int OFF_LIST = G::OFF_LIST, OFF_LOCK = G::OFF_LOCK;
+    static_assert(MODE == LVS_MODE_TOPK || MI == 4, "the other epilogues exist for the 256 x 256 geometry only");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / G::WN, wn = wave % G::WN;
 
     int qt, slab;
     if (!item_of_block(a, blockIdx.x, qt, slab)) return;
-    const long long q0 = (long long)qt * LVS_BQ;
-    int tile0 = slab * a.tiles_per_slab;
-    const int tile1 = min(a.ntiles, tile0 + a.tiles_per_slab);
+    const long long q0 = (long long)qt * BQ;
+    int tile0_ = slab * a.tiles_per_slab;
+    const int tile1 = min(a.ntiles, tile0_ + a.tiles_per_slab);
     if (MODE == LVS_MODE_RANGE) {
         if (a.qt_stride > 1 && (qt % a.qt_stride) != a.qt_phase) return;
         if (a.q_row0 >= 0) {  // self-join: tiles whose rows are all <= every query row of this tile hold no j > i
-            const long long first = (a.q_row0 + q0 - a.id_offset) / LVS_BC;
-            if (first > tile0) tile0 = (int)(first < tile1 ? first : tile1);
+            const long long first = (a.q_row0 + q0 - a.id_offset) / BC;
+            if (first > tile0_) tile0_ = (int)(first < tile1 ? first : tile1);
         }
     }
+    const int tile0 = tile0_;
     if (tile0 >= tile1) return;
 
     u64* lists = (u64*)(smem + OFF_LIST);
-    u64* taus = (u64*)(smem + OFF_TAU);
-    uint32_t* cnts = (uint32_t*)(smem + OFF_CNT);
-    uint32_t* flags = (uint32_t*)(smem + OFF_FLAG);
+    uint32_t* locks = (uint32_t*)(smem + OFF_LOCK);
+    float* bnl = (float*)(smem + OFF_LIST);           // TOP1: |y|^2 of the current corpus tile [BC]
+    u64* part = (u64*)(smem + OFF_LIST + BC * 4);     // TOP1: [BQ][4] per-lane partial best keys
 
     const _Float16* __restrict__ xb = (const _Float16*)a.xb;
     const _Float16* __restrict__ xq = (const _Float16*)a.xq;
     const long long ldb = a.ldb, ldq = a.ldq;
     const int nk = a.nk, nkd = a.nkd;
+    const int k = a.k;
 
-    // ---- per-lane staging addresses --------------------------------------------------------------------
-    // one glds covers 8 rows x 128 B: lane -> (row = R0 + lane/8, physical chunk p = lane%8) holds logical
-    // chunk c = p ^ ((row >> 1) & 7) of that row (source-side swizzle; LDS image stays lane-linear).
+    // ---- staging addresses: wave stages corpus rows [wave*32, +32) and query rows [wave*8*QG, +8*QG) ----------
     const int srow = lane >> 3, sp = lane & 7;
-    int c_row[4], c_col[4];
+    int s_row[4], s_col[4], qs_row[QG], qs_col[QG];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         int row = wave * 32 + i * 8 + srow;
-        c_row[i] = row;
-        c_col[i] = (sp ^ ((row >> 1) & 7)) * 8;
+        s_row[i] = row;
+        s_col[i] = (sp ^ ((row >> 1) & 7)) * 8;
     }
-    const _Float16* q_src[2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        int row = wave * 16 + i * 8 + srow;
-        long long grow = q0 + row;
+    for (int i = 0; i < QG; ++i) {
+        int row = wave * (8 * QG) + i * 8 + srow;
+        qs_row[i] = row;
+        qs_col[i] = (sp ^ ((row >> 1) & 7)) * 8;
+    }
+    const _Float16* q_src[QG];
+#pragma unroll
+    for (int i = 0; i < QG; ++i) {
+        long long grow = q0 + qs_row[i];
         if (grow > a.nq - 1) grow = a.nq - 1;
-        q_src[i] = xq + grow * ldq + (sp ^ ((row >> 1) & 7)) * 8;
+        q_src[i] = xq + grow * ldq + qs_col[i];
     }
 
     auto stage = [&](int t, int buf) {
         int ti = t / nk, ks = t - ti * nk;
         int seg = ks / nkd, r = ks - seg * nkd;
-        int qcol = a.seg_q[seg] + r * LVS_BK;
-        int ccol = a.seg_c[seg] + r * LVS_BK;
-        long long trow0 = (long long)(tile0 + ti) * LVS_BC;
+        int qcol = a.seg_q[seg] + r * BK;
+        int ccol = a.seg_c[seg] + r * BK;
+        long long trow0 = (long long)(tile0 + ti) * BC;
         char* base = smem + buf * STAGE_BYTES;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            long long grow = trow0 + c_row[i];
+            long long grow = trow0 + s_row[i];
             if (grow > a.nb - 1) grow = a.nb - 1;
-            glds16(xb + grow * ldb + ccol + c_col[i], base + (wave * 32 + i * 8) * ROWB);
+            glds16(xb + grow * ldb + ccol + s_col[i], base + (wave * 32 + i * 8) * ROWB);
         }
 #pragma unroll
-        for (int i = 0; i < 2; ++i) glds16(q_src[i] + qcol, base + LVS_BC * ROWB + (wave * 16 + i * 8) * ROWB);
+        for (int i = 0; i < QG; ++i) glds16(q_src[i] + qcol, base + BC * ROWB + (wave * (8 * QG) + i * 8) * ROWB);
     };
 
-    // ---- per-lane fragment read offsets (16 B per lane, chunk XOR-swizzled: conflict-free ds_read_b128) ----
     int foff[4];
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk)
         foff[kk] = (lane & 31) * ROWB + ((((kk * 2) + (lane >> 5)) ^ (((lane & 31) >> 1) & 7)) << 4);
-    const int a_base = (wm * 64) * ROWB;
-    const int b_base = LVS_BC * ROWB + (wn * 64) * ROWB;
+    const int a_base = (wm * MI * 32) * ROWB;
+    const int b_base = BC * ROWB + (wn * 64) * ROWB;
 
-    // ---- per-query state (lane owns queries qloc[0], qloc[1]; lanes l and l+32 share them) ----------------
     int qloc[2];
     bool qvalid[2];
     float tauf[2];
@@ -159,256 +222,443 @@ __global__ __launch_bounds__(LVS_TILE_THREADS, 2) void lvs_tile_kernel(const Lvs
         ubk[ni] = ~0ull;
         qnv[ni] = 0.f;
         if (qvalid[ni]) {
-            if (MODE == LVS_MODE_TOPK && a.ub) ubk[ni] = a.ub[(q0 + qloc[ni]) * a.ub_stride];
+            if (a.ub) ubk[ni] = a.ub[(q0 + qloc[ni]) * a.ub_stride];
             if (a.metric == LVS_METRIC_L2) qnv[ni] = a.qn[q0 + qloc[ni]];
         }
     }
 
     if (MODE == LVS_MODE_TOPK) {
-        for (int i = tid; i < LVS_BQ * LVS_LCAP; i += LVS_TILE_THREADS) lists[i] = 0;
-        for (int i = tid; i < LVS_BQ; i += LVS_TILE_THREADS) {
-            taus[i] = 0;
-            cnts[i] = a.k;
-        }
-        if (tid < 4) flags[tid] = 0;
+        for (int i = tid; i < BQ * KCAP; i += 512) lists[i] = 0;
+        for (int i = tid; i < BQ; i += 512) locks[i] = 0;
     }
+    float bestv[2] = {-INFINITY, -INFINITY};
+    uint32_t besti[2] = {0xFFFFFFFFu, 0xFFFFFFFFu};
 
-    f32x16 acc[2][2];
+    f32x16 acc[MI][2];
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
+    for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
-    int round = 0;  // overflow-round parity, persists across tiles (flag ping-pong)
+    // per-lane byte offsets of the staging loads relative to the tile's / query tile's first row
+    unsigned c_loff[4], q_loff[QG];
+#pragma unroll
+    for (int i = 0; i < QG; ++i) {
+        long long qrow = q0 + qs_row[i];
+        if (qrow > a.nq - 1) qrow = a.nq - 1;
+        q_loff[i] = (unsigned)(((qrow - q0) * ldq + qs_col[i]) * 2);
+    }
+    auto set_tile_offsets = [&](int tile_rel) {  // rows past the end of the shard re-read the last valid row
+        const long long trow0 = (long long)(tile0 + tile_rel) * BC;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            long long grow = trow0 + s_row[i];
+            if (grow > a.nb - 1) grow = a.nb - 1;
+            c_loff[i] = (unsigned)(((grow - trow0) * ldb + s_col[i]) * 2);
+        }
+    };
+    set_tile_offsets(0);
+    int n_tile = 0, n_seg = 0, n_r = 0;  // (tile, segment, k-block) of the K-step being prefetched
+
     const int T = (tile1 - tile0) * nk;
     stage(0, 0);
     int ks_in_tile = 0, ti = 0;
+    // the second-dispatched half of the waves loses VALU/MFMA arbitration to the older half on every segment: one
+    // static priority raise evens it out (+2 % on the bare loop, tools/probe_gemm.hip)
+    if (wave >= 4) __builtin_amdgcn_s_setprio(1);
+    uint32_t gpre[2] = {0u, 0u};  // cross-workgroup thresholds, prefetched one K-step before the tile epilogue
+#ifdef LVS_COUNT_EVENTS
+    unsigned n_visit = 0, n_ins = 0, n_wt = 0;  // tuning aid, see a.dbg
+#endif
     for (int t = 0; t < T; ++t) {
         const int buf = t & 1;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();  // buffer `buf` landed for every wave; everyone finished reading buffer buf^1
-        if (t + 1 < T) stage(t + 1, buf ^ 1);
-
+        if (a.debug_hot == 4) {  // tuning aid: no wait for the staging loads (results are garbage, timing only)
+            __builtin_amdgcn_s_barrier();
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+        if (MODE == LVS_MODE_TOPK && ks_in_tile == nk - 1) {
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+                if (qvalid[ni]) gpre[ni] = a.gtau[q0 + qloc[ni]];
+        }
+        // ---- one K-step, software-pipelined by hand: 4*MI steps f = kk*MI + mi of {A-fragment read two steps ahead,
+        // one staging load of the NEXT K-step (first 4 + QG steps), 2 MFMAs}; B fragments double-buffered per kk ----
         const char* sb = smem + buf * STAGE_BYTES;
+        // next K-step's source: uniform 64-bit bases (SGPRs) + constant per-lane 32-bit byte offsets, advanced
+        // incrementally (no divisions, no per-load 64-bit VALU).  The step after the last one re-loads the last
+        // K-step into the idle buffer (never read), so there is no branch around the loads.
+        char* n_base = smem + (buf ^ 1) * STAGE_BYTES;
+        if (t + 1 < T) {
+            if (++n_r == nkd) {
+                n_r = 0;
+                if (++n_seg == a.nseg) {
+                    n_seg = 0;
+                    ++n_tile;
+                    set_tile_offsets(n_tile);
+                }
+            }
+        }
+        const char* c_sbase = (const char*)xb + ((long long)(tile0 + n_tile) * BC * ldb + a.seg_c[n_seg] + n_r * BK) * 2;
+        const char* q_sbase = (const char*)xq + (q0 * ldq + a.seg_q[n_seg] + n_r * BK) * 2;
+        // A fragments two steps ahead; B fragments of the next kk read at mi == KBPOS
+        constexpr int KDEPTH = 2, KBPOS = MI == 4 ? 2 : 0;
+        using Ord = KStepOrder<MI, KDEPTH, KBPOS>;
+        half8 Bf[2][2], Af[KDEPTH + 1];
+        // one address VGPR per (operand, kk); the 32-row block (mi / second query block) goes into the offset field
+        const unsigned sbu = (unsigned)(unsigned long long)sb;
+        unsigned a_addr[4], b_addr[4];
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
-            half8 a0 = *(const half8*)(sb + a_base + foff[kk]);
-            half8 a1 = *(const half8*)(sb + a_base + 32 * ROWB + foff[kk]);
-            half8 b0 = *(const half8*)(sb + b_base + foff[kk]);
-            half8 b1 = *(const half8*)(sb + b_base + 32 * ROWB + foff[kk]);
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b1, acc[1][1], 0, 0, 0);
+            a_addr[kk] = (sbu + a_base) + foff[kk];
+            b_addr[kk] = (sbu + b_base) + foff[kk];
         }
+        lds_read16<0>(Bf[0][0], b_addr[0]);
+        lds_read16<32 * ROWB>(Bf[0][1], b_addr[0]);
+        static_for<KDEPTH>([&](auto fc) {
+            constexpr int f = decltype(fc)::value;
+            lds_read16<(f % MI) * 32 * ROWB>(Af[f], a_addr[f / MI]);
+        });
+        static_for<NF>([&](auto fc) {
+            constexpr int f = decltype(fc)::value;
+            constexpr int kk = f / MI, mi = f % MI;
+            if constexpr (f + KDEPTH < NF) {
+                constexpr int f2 = f + KDEPTH;
+                lds_read16<(f2 % MI) * 32 * ROWB>(Af[f2 % (KDEPTH + 1)], a_addr[f2 / MI]);
+            }
+            if constexpr (mi == KBPOS && kk + 1 < 4) {
+                lds_read16<0>(Bf[(kk + 1) & 1][0], b_addr[kk + 1]);
+                lds_read16<32 * ROWB>(Bf[(kk + 1) & 1][1], b_addr[kk + 1]);
+            }
+            if constexpr (f < 4)
+                glds16(c_sbase + c_loff[f], n_base + (wave * 32 + f * 8) * ROWB);
+            else if constexpr (f < 4 + QG)
+                glds16(q_sbase + q_loff[f - 4], n_base + BC * ROWB + (wave * (8 * QG) + (f - 4) * 8) * ROWB);
+            __builtin_amdgcn_sched_barrier(0);
+            lds_wait<Ord::wait(f)>(Af[f % (KDEPTH + 1)], Bf[kk & 1][0], Bf[kk & 1][1]);
+            acc[mi][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Af[f % (KDEPTH + 1)], Bf[kk & 1][0], acc[mi][0], 0, 0, 0);
+            acc[mi][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Af[f % (KDEPTH + 1)], Bf[kk & 1][1], acc[mi][1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        });
 
         if (++ks_in_tile < nk) continue;
         ks_in_tile = 0;
         // =============================== tile epilogue ===================================================
-        const long long trow0 = (long long)(tile0 + ti) * LVS_BC;
+        const long long trow0 = (long long)(tile0 + ti) * BC;
         ++ti;
-        const int lrow_base = wm * 64 + 4 * (lane >> 5);  // + mi*32 + (r&3) + 8*(r>>2)
+        const int lrow_base = wm * (MI * 32) + 4 * (lane >> 5);  // + mi*32 + (r&3) + 8*(r>>2)
 
-        if (a.metric == LVS_METRIC_L2) {
-            // better = -max((|q|^2 + |y|^2) - 2<q,y>, 0): same fp32 expression as the oracle / faiss BLAS path
+        if constexpr (MODE == LVS_MODE_RANGE || MODE == LVS_MODE_SCORES) {
+            if (a.metric == LVS_METRIC_L2) {
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    long long row = trow0 + lrow_base + mi * 32 + (r & 3) + 8 * (r >> 2);
-                    float bnv = row < a.nb ? a.bn[row] : 0.f;
-#pragma unroll
-                    for (int ni = 0; ni < 2; ++ni) {
-                        float dis = (qnv[ni] + bnv) - 2.0f * acc[mi][ni][r];
-                        acc[mi][ni][r] = -fmaxf(dis, 0.f);
-                    }
-                }
-        }
-
-        if (MODE == LVS_MODE_SCORES) {
-#pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < 2; ++ni) {
-                    if (!qvalid[ni]) continue;
-                    float* orow = a.scores + (q0 + qloc[ni]) * a.ld_scores;
-#pragma unroll
-                    for (int r4 = 0; r4 < 4; ++r4) {
-                        long long row = trow0 + lrow_base + mi * 32 + 8 * r4;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            if (row + e < a.nb) orow[row + e] = acc[mi][ni][r4 * 4 + e];
-                    }
-                }
-        } else if (MODE == LVS_MODE_RANGE) {
-#pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < 2; ++ni) {
-                    const bool th = qvalid[ni] && (max16(acc[mi][ni]) > a.threshold);
-                    if (!__any(th)) continue;
-                    if (!th) continue;
-                    const long long qg = q0 + qloc[ni];
+                for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        const float s = acc[mi][ni][r];
-                        if (!(s > a.threshold)) continue;  // strict, as sem_dedup.py:46
                         const long long row = trow0 + lrow_base + mi * 32 + (r & 3) + 8 * (r >> 2);
-                        if (row >= a.nb) continue;
-                        const long long jg = row + a.id_offset;
-                        if (a.q_row0 >= 0 && jg <= a.q_row0 + qg) continue;
-                        const unsigned long long pos = atomicAdd(a.pair_count, 1ull);
-                        if ((long long)pos < a.pair_capacity) {
-                            a.pair_q[pos] = qg;
-                            a.pair_j[pos] = jg;
-                            a.pair_s[pos] = s;
-                        }
+                        const float bnv = row < a.nb ? a.bn[row] : 0.f;
+#pragma unroll
+                        for (int ni = 0; ni < 2; ++ni)
+                            acc[mi][ni][r] = -fmaxf((qnv[ni] + bnv) - 2.0f * acc[mi][ni][r], 0.f);
                     }
-                }
-        } else if (MODE == LVS_MODE_TOPK) {
-            // refresh the cross-workgroup threshold (any slab's k-th best is a valid lower bound for the final
-            // k-th best; a stale value is only conservative)
+            }
 #pragma unroll
-            for (int ni = 0; ni < 2; ++ni)
-                if (qvalid[ni]) {
-                    uint32_t g = a.gtau[q0 + qloc[ni]];
-                    gord[ni] = g > gord[ni] ? g : gord[ni];
-                    tauf[ni] = fmaxf(tauf[ni], tau_float(gord[ni]));
-                }
-            u64 done = 0;
-            for (;;) {
-                bool anyhit = false;
+            for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-                for (int mi = 0; mi < 2; ++mi)
+                for (int ni = 0; ni < 2; ++ni) {
+                    const long long qg = q0 + qloc[ni];
+                    if (MODE == LVS_MODE_SCORES) {
+                        if (!qvalid[ni]) continue;
+                        float* orow = a.scores + qg * a.ld_scores;
 #pragma unroll
-                    for (int ni = 0; ni < 2; ++ni) anyhit |= qvalid[ni] && (max16(acc[mi][ni]) >= tauf[ni]);
-                if (__any(anyhit)) {
-                    // rare path: rolled over the four 32x32 accumulators to keep register pressure low
-#pragma unroll 1
-                    for (int tsel = 0; tsel < 4; ++tsel) {
-                        const int mi = tsel >> 1, ni = tsel & 1;
-                        const f32x16 tv = tsel == 0 ? acc[0][0] : tsel == 1 ? acc[0][1] : tsel == 2 ? acc[1][0] : acc[1][1];
-                        const float tf = ni ? tauf[1] : tauf[0];
-                        const bool qv = ni ? qvalid[1] : qvalid[0];
-                        const bool th = qv && (max16(tv) >= tf);
+                        for (int r = 0; r < 16; ++r) {
+                            const long long row = trow0 + lrow_base + mi * 32 + (r & 3) + 8 * (r >> 2);
+                            if (row < a.nb) orow[row] = acc[mi][ni][r];
+                        }
+                    } else {
+                        const bool th = qvalid[ni] && (max16(acc[mi][ni]) > a.threshold);
                         if (!__any(th)) continue;
-                        if (th) {
-                            const int q = ni ? qloc[1] : qloc[0];
-                            const u64 ubq = ni ? ubk[1] : ubk[0];
-                            const uint32_t go = ni ? gord[1] : gord[0];
-                            const u64 tk = taus[q];
-                            const long long rbase = trow0 + lrow_base + mi * 32;
+                        if (!th) continue;
 #pragma unroll
-                            for (int r = 0; r < 16; ++r) {
-                                const float s = tv[r];
-                                const u64 bit = 1ull << (tsel * 16 + r);
-                                if (s >= tf && !(done & bit)) {
-                                    const long long row = rbase + (r & 3) + 8 * (r >> 2);
-                                    done |= bit;  // cleared again only when the append has to be retried
-                                    if (row < a.nb) {
-                                        const uint32_t id = a.row_ids ? a.row_ids[row] : (uint32_t)(row + a.id_offset);
-                                        const u64 key = lvs_pack_key(s, id);
-                                        if (key > tk && key < ubq && (uint32_t)(key >> 32) >= go) {
-                                            const uint32_t pos = atomicAdd(&cnts[q], 1u);
-                                            if (pos < LVS_LCAP) {
-                                                lists[q * LVS_LCAP + pos] = key;
-                                            } else {
-                                                flags[round & 1] = 1u;  // retried after compaction
-                                                done &= ~bit;
-                                            }
-                                        }
-                                    }
-                                }
+                        for (int r = 0; r < 16; ++r) {
+                            const float s = acc[mi][ni][r];
+                            if (!(s > a.threshold)) continue;  // strict, as sem_dedup.py:46
+                            const long long row = trow0 + lrow_base + mi * 32 + (r & 3) + 8 * (r >> 2);
+                            if (row >= a.nb) continue;
+                            const long long jg = row + a.id_offset;
+                            if (a.q_row0 >= 0 && jg <= a.q_row0 + qg) continue;
+                            const unsigned long long pos = atomicAdd(a.pair_count, 1ull);
+                            if ((long long)pos < a.pair_capacity) {
+                                a.pair_q[pos] = qg;
+                                a.pair_j[pos] = jg;
+                                a.pair_s[pos] = s;
                             }
                         }
                     }
                 }
+        } else if constexpr (MODE == LVS_MODE_TOP1) {
+            // ---- k == 1: per-lane running best, no lists.  Rows are visited in increasing order, so a strict
+            // "greater" keeps the lowest row among equal scores (the oracle's tie rule). ----
+            if (a.metric == LVS_METRIC_L2) {
                 __syncthreads();
-                const uint32_t ovf = flags[round & 1];
-                if (!ovf) break;
-                if (tid == 0) flags[(round + 1) & 1] = 0;
-                // compaction: each wave owns 16 of the 128 queries
-                for (int i = 0; i < LVS_BQ / 8; ++i) {
-                    const int q = wave * (LVS_BQ / 8) + i;
-                    const uint32_t c = cnts[q];
-                    if (c < LVS_LCAP) continue;
-                    u64 v = lane < LVS_LCAP ? lists[q * LVS_LCAP + lane] : 0ull;
-                    v = lvs_wave_sort_desc(v, lane);
-                    if (lane < a.k) lists[q * LVS_LCAP + lane] = v;
-                    const u64 tk = lvs_shfl_u64(v, a.k - 1);
-                    if (lane == 0) {
-                        taus[q] = tk;
-                        cnts[q] = a.k;
-                        if (tk != 0 && (q0 + q) < a.nq) atomicMax(&a.gtau[q0 + q], (uint32_t)(tk >> 32));
+                if (tid < BC) {
+                    const long long row = trow0 + tid;
+                    bnl[tid] = row < a.nb ? a.bn[row] : INFINITY;  // rows past the end never win
+                }
+                __syncthreads();
+            }
+#pragma unroll 1
+            for (int mi = 0; mi < MI; ++mi) {  // rolled: keeps the epilogue's register footprint small
+                f32x16 t0, t1;
+                switch (mi) {
+                    case 0: t0 = acc[0][0]; t1 = acc[0][1]; break;
+                    case 1: t0 = acc[1][0]; t1 = acc[1][1]; break;
+                    case 2: t0 = acc[2][0]; t1 = acc[2][1]; break;
+                    default: t0 = acc[3][0]; t1 = acc[3][1]; break;
+                }
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    const int lrow = lrow_base + mi * 32 + 8 * r4;
+                    f32x4 bn4 = {0.f, 0.f, 0.f, 0.f};
+                    if (a.metric == LVS_METRIC_L2) bn4 = *(const f32x4*)(bnl + lrow);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const long long row = trow0 + lrow + e;
+#pragma unroll
+                        for (int ni = 0; ni < 2; ++ni) {
+                            float s = ni ? t1[r4 * 4 + e] : t0[r4 * 4 + e];
+                            if (a.metric == LVS_METRIC_L2)
+                                s = -fmaxf((qnv[ni] + bn4[e]) - 2.0f * s, 0.f);
+                            else
+                                s = row < a.nb ? s : -INFINITY;
+                            if (s > bestv[ni]) {
+                                bestv[ni] = s;
+                                besti[ni] = (uint32_t)row;
+                            }
+                        }
                     }
                 }
-                __syncthreads();
+            }
+        } else {
+        if (a.metric == LVS_METRIC_L2) {
 #pragma unroll
-                for (int ni = 0; ni < 2; ++ni) {
-                    uint32_t lo = (uint32_t)(taus[qloc[ni]] >> 32);
-                    tauf[ni] = fmaxf(tauf[ni], tau_float(lo));
+                for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        long long row = trow0 + lrow_base + mi * 32 + (r & 3) + 8 * (r >> 2);
+                        float bnv = row < a.nb ? a.bn[row] : 0.f;
+#pragma unroll
+                        for (int ni = 0; ni < 2; ++ni) {
+                            float dis = (qnv[ni] + bnv) - 2.0f * acc[mi][ni][r];
+                            acc[mi][ni][r] = -fmaxf(dis, 0.f);
+                        }
+                    }
+            }
+
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+            if (qvalid[ni]) {
+                const uint32_t g = gpre[ni];
+                gord[ni] = g > gord[ni] ? g : gord[ni];
+                tauf[ni] = fmaxf(tauf[ni], tau_float(gord[ni]));
+            }
+        // own lists' current thresholds (they may have risen since this lane last looked)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            uint32_t lo = (uint32_t)(lists[qloc[ni] * KCAP + k - 1] >> 32);
+            tauf[ni] = fmaxf(tauf[ni], tau_float(lo));
+        }
+        // fast filter: which of the wave's 2*MI 32x32 blocks hold a score that may enter some query's list?
+        uint32_t hitmask = 0;  // wave-uniform, bit tsel = mi * 2 + ni
+#ifdef LVS_COUNT_EVENTS
+        ++n_wt;
+#endif
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+                if (__any(qvalid[ni] && (max16(acc[mi][ni]) >= tauf[ni]))) hitmask |= 1u << (mi * 2 + ni);
+        if (a.debug_hot == 2) hitmask = 0;
+        {
+            while (hitmask) {  // rare path: only blocks with candidates are visited
+                const int tsel = __builtin_ctz(hitmask);
+                hitmask &= hitmask - 1;
+                const int mi = tsel >> 1, ni = tsel & 1;
+                f32x16 tv = acc[0][0];
+                static_for<2 * MI>([&](auto ic) {  // wave-uniform select of the hit block
+                    constexpr int i = decltype(ic)::value;
+                    if (i > 0 && tsel == i) tv = acc[i >> 1][i & 1];
+                });
+                float tf = ni ? tauf[1] : tauf[0];
+                const bool qv = ni ? qvalid[1] : qvalid[0];
+                const bool th = qv && (max16(tv) >= tf);
+                if (!__any(th)) continue;
+#ifdef LVS_COUNT_EVENTS
+                ++n_visit;
+#endif
+                const int q = ni ? qloc[1] : qloc[0];
+                const u64 ubq = ni ? ubk[1] : ubk[0];
+                const uint32_t go = ni ? gord[1] : gord[0];
+                const long long rbase = trow0 + lrow_base + mi * 32;
+                // the visiting wave is on the workgroup's critical path (the next barrier waits for it): let its
+                // instructions win the issue arbitration against the other wave's MFMAs
+                __builtin_amdgcn_s_setprio(3);
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {  // rows 8g .. 8g+3: skip the group when none of its four scores can enter
+                    const float m4 = fmaxf(fmaxf(tv[4 * g4], tv[4 * g4 + 1]), fmaxf(tv[4 * g4 + 2], tv[4 * g4 + 3]));
+                    if (!__any(th && m4 >= tf)) continue;
+#pragma unroll
+                for (int e4 = 0; e4 < 4; ++e4) {
+                    const int r = 4 * g4 + e4;
+                    const float s = tv[r];
+                    if (!__any(th && s >= tf)) continue;  // wave-uniform skip before any per-lane work
+                    bool pending = false;
+                    u64 key = 0;
+                    if (th && s >= tf) {
+                        const long long row = rbase + (r & 3) + 8 * (r >> 2);
+                        if (row < a.nb) {
+                            const uint32_t id = a.row_ids ? a.row_ids[row] : (uint32_t)(row + a.id_offset);
+                            key = lvs_pack_key(s, id);
+                            pending = key < ubq && (uint32_t)(key >> 32) >= go;  // re-checked under the lock
+                        }
+                    }
+                    // Wave-cooperative insertion, one pending hit at a time: the hit is broadcast, lane j < 16 owns
+                    // slot j of that query's sorted list and computes its new content in ONE step
+                    // (new[j] = L[j] if L[j] > key, else key if L[j-1] > key, else L[j-1]) - cost independent of k.
+                    // The list's lock is taken by lane 0 only (waves wm = 0, 1 share queries).
+                    unsigned long long pm = __ballot(pending);
+                    if (a.debug_hot == 3) pm = 0;  // tuning aid: scan for hits but skip the insertions
+                    while (pm) {
+#ifdef LVS_COUNT_EVENTS
+                        ++n_ins;
+#endif
+                        const int src = __ffsll((long long)pm) - 1;
+                        pm &= pm - 1;
+                        const uint32_t klo = __builtin_amdgcn_readlane((uint32_t)key, src);
+                        const uint32_t khi = __builtin_amdgcn_readlane((uint32_t)(key >> 32), src);
+                        const u64 ukey = ((u64)khi << 32) | klo;
+                        const int uq = __builtin_amdgcn_readlane(q, src);
+                        // Lock + slot reads under ONE wait: lane 0 issues the compare-and-swap, lanes < k issue their
+                        // slot reads right behind it.  LDS executes a wave's DS instructions in order, so when the
+                        // swap succeeded the reads saw the list under the lock; otherwise everything is retried.
+                        u64* UL = lists + uq * KCAP;
+                        u64 mine = 0, prev = ~0ull;
+                        for (;;) {
+                            uint32_t seen = 0;
+                            if (lane == 0) {
+                                __hip_atomic_compare_exchange_strong(&locks[uq], &seen, 1u, __ATOMIC_RELAXED,
+                                                                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            }
+                            asm volatile("" ::: "memory");  // keep the reads behind the swap in program order
+                            if (lane < k) {
+                                mine = UL[lane];
+                                if (lane > 0) prev = UL[lane - 1];
+                            }
+                            if (__builtin_amdgcn_readfirstlane(seen) == 0) break;  // lock word was 0: we own it
+                        }
+                        u64 newv = 0;
+                        if (lane < k) newv = mine > ukey ? mine : (prev > ukey ? ukey : prev);
+                        __builtin_amdgcn_wave_barrier();
+                        if (lane < k) UL[lane] = newv;
+                        const uint32_t ntau = __builtin_amdgcn_readlane((uint32_t)(newv >> 32), k - 1);
+                        // unlock: the LDS executes one wave's DS instructions in issue order, so a plain (relaxed)
+                        // store issued after the slot writes is observed after them - no wait for the writes needed
+                        asm volatile("" ::: "memory");
+                        if (lane == 0)
+                            __hip_atomic_store(&locks[uq], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        if (q == uq) tf = fmaxf(tf, tau_float(ntau));
+                    }
                 }
-                ++round;
+                }  // g4
+                if (wave >= 4) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+                if (ni) tauf[1] = fmaxf(tauf[1], tf); else tauf[0] = fmaxf(tauf[0], tf);
             }
         }
+        // publish thresholds for the other slabs of these queries every 8 tiles and at the end of the item
+        if (((ti & 7) == 0) || t + 1 == T) {
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
+            for (int ni = 0; ni < 2; ++ni) {
+                const uint32_t lo = (uint32_t)(lists[qloc[ni] * KCAP + k - 1] >> 32);
+                if (qvalid[ni] && lane < 32 && wm == 0 && lo > gord[ni]) atomicMax(&a.gtau[q0 + qloc[ni]], lo);
+            }
+        }
+        }  // MODE
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
             for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
     }
 
-    if (MODE == LVS_MODE_TOPK) {
+#ifdef LVS_COUNT_EVENTS
+    if (MODE == LVS_MODE_TOPK && a.dbg && lane == 0) {
+        atomicAdd(&a.dbg[0], (unsigned long long)n_visit);
+        atomicAdd(&a.dbg[1], (unsigned long long)n_ins);
+        atomicAdd(&a.dbg[2], (unsigned long long)n_wt);
+    }
+#endif
+    if constexpr (MODE == LVS_MODE_RANGE || MODE == LVS_MODE_SCORES) return;
+    if constexpr (MODE == LVS_MODE_TOP1) {
+        // four lanes (l, l+32 of waves wm = 0, 1) hold partial winners of each query: combine by key
         __syncthreads();
-        for (int i = 0; i < LVS_BQ / 8; ++i) {
-            const int q = wave * (LVS_BQ / 8) + i;
-            if (q0 + q >= a.nq) continue;
-            uint32_t c = cnts[q];
-            c = c < LVS_LCAP ? c : LVS_LCAP;
-            u64 v = lane < (int)c ? lists[q * LVS_LCAP + lane] : 0ull;
-            v = lvs_wave_sort_desc(v, lane);
-            if (lane < a.k) a.out[((long long)slab * a.nq + q0 + q) * a.k + lane] = v;
-            const u64 tk = lvs_shfl_u64(v, a.k - 1);
-            if (lane == 0 && tk != 0) atomicMax(&a.gtau[q0 + q], (uint32_t)(tk >> 32));
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            u64 key = 0;
+            if (besti[ni] != 0xFFFFFFFFu) key = lvs_pack_key(bestv[ni], (uint32_t)(besti[ni] + a.id_offset));
+            part[qloc[ni] * 4 + wm * 2 + (lane >> 5)] = key;
         }
+        __syncthreads();
+        if (tid < BQ && q0 + tid < a.nq) {
+            u64 b = part[tid * 4];
+#pragma unroll
+            for (int j = 1; j < 4; ++j) b = part[tid * 4 + j] > b ? part[tid * 4 + j] : b;
+            a.out[(long long)slab * a.nq + q0 + tid] = b;
+        }
+        return;
+    }
+    // lists are sorted and complete: write the slab's candidates
+    __syncthreads();
+    for (int i = tid; i < BQ * k; i += 512) {
+        int q = i / k, j = i - q * k;
+        if (q0 + q < a.nq) a.out[((long long)slab * a.nq + q0 + q) * k + j] = lists[q * KCAP + j];
     }
 }
 
-template __global__ void lvs_tile_kernel<LVS_MODE_TOPK>(const LvsTileArgs);
-template __global__ void lvs_tile_kernel<LVS_MODE_SCORES>(const LvsTileArgs);
-template __global__ void lvs_tile_kernel<LVS_MODE_RANGE>(const LvsTileArgs);
+template <int MODE, int MI>
+static hipError_t launch_one(const LvsTileArgs& a, hipStream_t stream) {
+    static bool attr_done = false;  // one flag per instantiation
+    constexpr int lds = Geo<MI>::LDS_TOTAL;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)lvs_tile_kernel<MODE, MI>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    dim3 grid(lvs_tile_grid_blocks(a.nqt, a.nslab, a.gq)), block(512);
+    hipLaunchKernelGGL((lvs_tile_kernel<MODE, MI>), grid, block, lds, stream, a);
+    return hipGetLastError();
+}
 
-// ---- launch helpers (called from lvs_capi.hip) -------------------------------------------------------------
+// a.bq names the geometry a.nqt was computed for: LVS2_BQ (k <= LVS2_KCAP and the TOP1 / RANGE / SCORES modes) or
+// LVS3_BQ (top-k with k <= LVS3_KCAP)
+hipError_t lvs_tile_launch(int mode, const LvsTileArgs& a, hipStream_t stream) {
+    if (a.bq == LVS3_BQ) {
+        if (mode != LVS_MODE_TOPK || a.k > LVS3_KCAP) return hipErrorInvalidValue;
+        return launch_one<LVS_MODE_TOPK, 2>(a, stream);
+    }
+    if (a.bq != LVS2_BQ || a.k > LVS2_KCAP) return hipErrorInvalidValue;
+    if (mode == LVS_MODE_TOP1) return launch_one<LVS_MODE_TOP1, 4>(a, stream);
+    if (mode == LVS_MODE_RANGE) return launch_one<LVS_MODE_RANGE, 4>(a, stream);
+    if (mode == LVS_MODE_SCORES) return launch_one<LVS_MODE_SCORES, 4>(a, stream);
+    return launch_one<LVS_MODE_TOPK, 4>(a, stream);
+}
+
 int lvs_tile_grid_blocks(int nqt, int nslab, int gq) {
     int gs = 32 / gq;
     long long nqg = (nqt + gq - 1) / gq, nsg = (nslab + gs - 1) / gs;
     long long groups = lvs_round_up(nqg * nsg, 8);
     return (int)(groups * 32);
-}
-
-hipError_t lvs_tile_launch(int mode, const LvsTileArgs& a, hipStream_t stream) {
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)lvs_tile_kernel<LVS_MODE_TOPK>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);
-        if (e != hipSuccess) return e;
-        e = hipFuncSetAttribute((const void*)lvs_tile_kernel<LVS_MODE_SCORES>,
-                                hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);
-        if (e != hipSuccess) return e;
-        e = hipFuncSetAttribute((const void*)lvs_tile_kernel<LVS_MODE_RANGE>,
-                                hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);
-        if (e != hipSuccess) return e;
-        attr_done = true;
-    }
-    dim3 grid(lvs_tile_grid_blocks(a.nqt, a.nslab, a.gq)), block(LVS_TILE_THREADS);
-    if (mode == LVS_MODE_TOPK)
-        hipLaunchKernelGGL(lvs_tile_kernel<LVS_MODE_TOPK>, grid, block, LDS_TOTAL, stream, a);
-    else if (mode == LVS_MODE_RANGE)
-        hipLaunchKernelGGL(lvs_tile_kernel<LVS_MODE_RANGE>, grid, block, LDS_TOTAL, stream, a);
-    else
-        hipLaunchKernelGGL(lvs_tile_kernel<LVS_MODE_SCORES>, grid, block, LDS_TOTAL, stream, a);
-    return hipGetLastError();
 }

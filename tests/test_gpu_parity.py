@@ -38,9 +38,15 @@ CASES = [
     (129, 257, 64, 1, F16, IP),
     (5, 3, 8, 5, F16, IP),              # k > nb -> padding
     (1, 1000, 768, 10, F16, IP),        # the literal single-query sem_search shape
-    (200, 3000, 384, 24, F16, IP),      # largest single-pass k
-    (200, 3000, 384, 25, F16, IP),      # two passes
-    (64, 3000, 128, 100, F16, IP),      # five passes
+    (300, 4000, 384, 15, F16, IP),      # largest k of the 256-query geometry
+    (300, 4000, 384, 16, F16, IP),      # smallest k of the 128-query / 56-slot geometry
+    (200, 3000, 384, 24, F16, IP),
+    (200, 3000, 384, 56, F16, IP),      # largest single-pass k
+    (200, 3000, 384, 57, F16, IP),      # two passes (56 + 1: the second pass has a tiny k on the 128-query geometry)
+    (64, 3000, 128, 100, F16, IP),      # two passes (56 + 44)
+    (40, 2000, 64, 200, F16, L2),       # four passes, L2
+    (1500, 100000, 768, 20, F16, IP),   # 128-query geometry with several slabs and shared thresholds
+    (130, 3000, 200, 30, SPLIT, IP),    # fp32-accurate operands on the 128-query geometry
     (300, 5000, 768, 10, F16, L2),
     (300, 5000, 384, 10, SPLIT, L2),
     (2048, 200000, 768, 10, F16, IP),   # many slabs, shared thresholds

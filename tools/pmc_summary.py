@@ -10,7 +10,7 @@ src, tag = sys.argv[1], sys.argv[2]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out_dir = os.path.join(root, "profiles")
 os.makedirs(out_dir, exist_ok=True)
-KERNEL = "lvs_tile2_kernel"
+KERNEL = "lvs_tile_kernel"
 
 stats = glob.glob(os.path.join(src, "prof_*", "*kernel_stats.csv"))
 summary = {}
@@ -26,7 +26,7 @@ if stats:
                 r["Name"] = r["Name"][:157] + "..."
             w.writerow(r)
     for r in rows:
-        if KERNEL in r["Name"] and "<0>" in r["Name"]:
+        if KERNEL in r["Name"] and "<0, 4>" in r["Name"]:
             summary["kernel"] = r["Name"]
             summary["rocprof_kernel_avg_ms"] = float(r["AverageNs"]) / 1e6
             summary["rocprof_kernel_calls"] = int(r["Calls"])
