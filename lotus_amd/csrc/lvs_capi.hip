@@ -470,7 +470,7 @@ int make_plan(int64_t nq, int64_t nb, int32_t d, int32_t xb_pack, int32_t xq_pac
     off += lvs_round_up((int64_t)p.nslab * nq * p.kpass * 8, 256);
     p.off_pass = off;  // [nq][kpass] merged keys of one pass (multi-pass only)
     off += p.npass > 1 ? lvs_round_up(nq * p.kpass * 8, 256) : 0;
-    off += 768ll * LVS_STREAM_MAXQ * 16 * 8;  // candidates of the small-batch streaming kernel (<= 768 workgroups)
+    off += (int64_t)LVS_STREAM_MAXWG * LVS_STREAM_MAXQ * LVS_KPASS * 8;  // candidates of the small-batch kernel
     p.total = off;
     return LVS_OK;
 }
@@ -565,7 +565,7 @@ extern "C" int32_t lvs_flat_search_keys(const void* xb, int32_t xb_pack, int64_t
         const bool fits = lvs_stream_lds_bytes(nqseg * jper) <= 150 * 1024;
         const char* env = getenv("LVS_STREAM");
         const bool want = env ? atoi(env) != 0 : true;
-        if (want && fits && nq <= LVS_STREAM_MAXQ && k <= 15 && nb >= 4096) {
+        if (want && fits && nq <= LVS_STREAM_MAXQ && k <= LVS_KPASS && nb >= 4096) {
             LvsStreamArgs sa;
             memset(&sa, 0, sizeof(sa));
             sa.xb = xb;

@@ -10,7 +10,7 @@
 //     (16 KB per wave) in flight ahead of the MFMAs;
 //   * each wave owns 32-row blocks: 32 x 32 x K product on v_mfma_f32_32x32x16_f16, operands swapped as in the tile
 //     kernels (corpus = A, queries = B) so that a lane owns one query column and its threshold is a register;
-//   * hits go through the same wave-cooperative sorted insertion into per-query lists (LDS, 32 x 16 slots, one lock
+//   * hits go through the same wave-cooperative sorted insertion into per-query lists (LDS, 32 x 64 slots, one lock
 //     per query because the 4 waves of a workgroup share the queries); thresholds are shared across workgroups
 //     through the global per-query word; every workgroup writes its k candidates and lvs_merge_keys finishes.
 #include <stdlib.h>
@@ -22,7 +22,7 @@ namespace {
 
 constexpr int SQ = 32;          // queries per launch
 constexpr int WAVES = 4;        // waves per workgroup
-constexpr int KCAP = 16;        // list slots per query (k <= 15)
+constexpr int KCAP = 64;        // list slots per query = lanes of the cooperative insertion (k <= LVS_KPASS = 56)
 constexpr int UNROLL = 16;      // A-fragment loads in flight per wave (16 x 1 KB)
 
 __device__ inline float tau_float(uint32_t ord) { return ord == 0 ? -INFINITY : lvs_unord32(ord); }
@@ -196,6 +196,7 @@ int lvs_stream_blocks(int64_t nb) {
     const int64_t nblocks = (nb + 31) / 32;
     int64_t wgs = 256;  // one per CU: fewest partial lists to merge, cold start amortised over ~120 row blocks
     if (const char* e = getenv("LVS_STREAM_WGS")) wgs = atoll(e) > 0 ? atoll(e) : wgs;  // tuning override
+    if (wgs > LVS_STREAM_MAXWG) wgs = LVS_STREAM_MAXWG;
     if (wgs > (nblocks + 3) / 4) wgs = (nblocks + 3) / 4;
     if (wgs < 1) wgs = 1;
     return (int)wgs;

@@ -58,8 +58,9 @@ struct LvsTileArgs {
 int lvs_tile_grid_blocks(int nqt, int nslab, int gq);
 hipError_t lvs_tile_launch(int mode, const LvsTileArgs& a, hipStream_t stream);
 
-// ---- small-batch streaming kernel (lvs_stream.hip): nq <= 32, k <= 15 ----
+// ---- small-batch streaming kernel (lvs_stream.hip): nq <= 32, k <= LVS_KPASS ----
 #define LVS_STREAM_MAXQ 32
+#define LVS_STREAM_MAXWG 768   // most workgroups (= partial candidate lists) a launch may use
 struct LvsStreamArgs {
     const void* xb;
     const void* xq;

@@ -90,7 +90,9 @@ def test_mixed_precision_operands(hip_backend, cmode, qmode, k):
 @pytest.mark.parametrize("nq,nb,d,k,mode,metric", [
     (1, 100_000, 768, 10, F16, IP),    # the literal sem_search call
     (7, 50_001, 384, 5, SPLIT, IP),    # fp32-accurate path, ragged row count
-    (32, 30_000, 100, 15, F16, IP),    # full query block, padded d, largest k
+    (32, 30_000, 100, 15, F16, IP),    # full query block, padded d
+    (5, 60_000, 384, 56, F16, IP),     # largest k of the streaming path (sem_search's K-doubling asks for more than k)
+    (1, 100_000, 768, 40, F16, L2),
     (3, 20_000, 768, 1, F16, L2),
     (20, 40_000, 256, 10, SPLIT, L2),
 ])
