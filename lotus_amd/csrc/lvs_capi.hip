@@ -552,8 +552,8 @@ extern "C" int32_t lvs_flat_search_keys(const void* xb, int32_t xb_pack, int64_t
     unsigned long long* dbg_counters = nullptr;
 #ifdef LVS_COUNT_EVENTS
     if (getenv("LVS_COUNT") && atoi(getenv("LVS_COUNT"))) {  // tuning aid: count slow-path events of this call
-        LVS_HIP_CHECK(hipMalloc((void**)&dbg_counters, 3 * sizeof(unsigned long long)));
-        LVS_HIP_CHECK(hipMemsetAsync(dbg_counters, 0, 3 * sizeof(unsigned long long), st));
+        LVS_HIP_CHECK(hipMalloc((void**)&dbg_counters, 8 * sizeof(unsigned long long)));
+        LVS_HIP_CHECK(hipMemsetAsync(dbg_counters, 0, 8 * sizeof(unsigned long long), st));
         a.dbg = dbg_counters;
     }
 #endif
@@ -640,12 +640,17 @@ extern "C" int32_t lvs_flat_search_keys(const void* xb, int32_t xb_pack, int64_t
         LVS_HIP_CHECK(hipGetLastError());
     }
     if (dbg_counters) {
-        unsigned long long h[3] = {0, 0, 0};
+        unsigned long long h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         LVS_HIP_CHECK(hipStreamSynchronize(st));
         LVS_HIP_CHECK(hipMemcpy(h, dbg_counters, sizeof(h), hipMemcpyDeviceToHost));
         (void)hipFree(dbg_counters);
-        fprintf(stderr, "[lvs] nq=%lld nb=%lld k=%d nslab=%d: wave-tiles %llu, block visits %llu, insertions %llu (%.1f per query)\n",
-                (long long)nq, (long long)nb, k, p.nslab, h[2], h[0], h[1], (double)h[1] / (double)(nq > 0 ? nq : 1));
+        fprintf(stderr,
+                "[lvs] nq=%lld nb=%lld k=%d nslab=%d: wave-tiles %llu, block visits %llu, insertions %llu (%.1f per query); "
+                "cycles per wave-tile: filter %.0f, visit loop %.0f (of which insertions %.0f); per visit %.0f, per insertion %.0f\n",
+                (long long)nq, (long long)nb, k, p.nslab, h[2], h[0], h[1], (double)h[1] / (double)(nq > 0 ? nq : 1),
+                (double)h[3] / (double)(h[2] ? h[2] : 1), (double)h[4] / (double)(h[2] ? h[2] : 1),
+                (double)h[5] / (double)(h[2] ? h[2] : 1), (double)(h[4] - h[5]) / (double)(h[0] ? h[0] : 1),
+                (double)h[5] / (double)(h[1] ? h[1] : 1));
     }
     return LVS_OK;
 }

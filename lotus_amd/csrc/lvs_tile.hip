@@ -97,13 +97,21 @@ struct KStepOrder {
     }
 };
 
-__device__ inline float max16(const f32x16& v) {
-    float a = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
-    float b = fmaxf(fmaxf(v[4], v[5]), fmaxf(v[6], v[7]));
-    float c = fmaxf(fmaxf(v[8], v[9]), fmaxf(v[10], v[11]));
-    float d = fmaxf(fmaxf(v[12], v[13]), fmaxf(v[14], v[15]));
-    return fmaxf(fmaxf(a, b), fmaxf(c, d));
+// Scores are finite or -inf, never NaN, so the maxima need none of fmaxf's canonicalisation (hipcc emits one extra
+// `v_max_f32 x, x` per MFMA output to quiet signalling NaNs): v_max3_f32 directly - 8 instructions for 16 values.
+__device__ inline float max3(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
 }
+__device__ inline float max4(float a, float b, float c, float d) { return max3(max3(a, b, c), d, d); }
+__device__ inline float max16(const f32x16& v) {
+    const float a = max3(v[0], v[1], v[2]), b = max3(v[3], v[4], v[5]), c = max3(v[6], v[7], v[8]);
+    const float d = max3(v[9], v[10], v[11]), e = max3(v[12], v[13], v[14]);
+    return max3(max3(a, b, c), max3(d, e, v[15]), v[15]);
+}
+// wave-uniform "any lane" without materialising a per-lane bool
+__device__ inline bool wave_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
 
 __device__ inline float tau_float(uint32_t ord) { return ord == 0 ? -INFINITY : lvs_unord32(ord); }
 
@@ -271,6 +279,7 @@ __global__ __launch_bounds__(512, 2) void lvs_tile_kernel(const LvsTileArgs a) {
     uint32_t gpre[2] = {0u, 0u};  // cross-workgroup thresholds, prefetched one K-step before the tile epilogue
 #ifdef LVS_COUNT_EVENTS
     unsigned n_visit = 0, n_ins = 0, n_wt = 0;  // tuning aid, see a.dbg
+    unsigned long long c_filter = 0, c_visit = 0, c_ins = 0;  // cycles (s_memtime) in the filter / visit loop / insertions
 #endif
     for (int t = 0; t < T; ++t) {
         const int buf = t & 1;
@@ -474,27 +483,38 @@ __global__ __launch_bounds__(512, 2) void lvs_tile_kernel(const LvsTileArgs a) {
         uint32_t hitmask = 0;  // wave-uniform, bit tsel = mi * 2 + ni
 #ifdef LVS_COUNT_EVENTS
         ++n_wt;
+        const unsigned long long tm0 = __builtin_amdgcn_s_memtime();
 #endif
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
             for (int ni = 0; ni < 2; ++ni)
-                if (__any(qvalid[ni] && (max16(acc[mi][ni]) >= tauf[ni]))) hitmask |= 1u << (mi * 2 + ni);
+                if (wave_any(qvalid[ni] && (max16(acc[mi][ni]) >= tauf[ni]))) hitmask |= 1u << (mi * 2 + ni);
         if (a.debug_hot == 2) hitmask = 0;
+#ifdef LVS_COUNT_EVENTS
+        const unsigned long long tm1 = __builtin_amdgcn_s_memtime();
+        c_filter += tm1 - tm0;
+#endif
         {
             while (hitmask) {  // rare path: only blocks with candidates are visited
                 const int tsel = __builtin_ctz(hitmask);
                 hitmask &= hitmask - 1;
                 const int mi = tsel >> 1, ni = tsel & 1;
-                f32x16 tv = acc[0][0];
-                static_for<2 * MI>([&](auto ic) {  // wave-uniform select of the hit block
-                    constexpr int i = decltype(ic)::value;
-                    if (i > 0 && tsel == i) tv = acc[i >> 1][i & 1];
-                });
+                f32x16 tv;
+                switch (tsel) {  // wave-uniform: a branch table + 16 moves (a select chain would cost 7 x 16 VALU)
+                    case 0: tv = acc[0][0]; break;
+                    case 1: tv = acc[0][1]; break;
+                    case 2: tv = acc[1][0]; break;
+                    case 3: tv = acc[1][1]; break;
+                    case 4: tv = acc[2 % MI][0]; break;  // cases >= 2 * MI are never taken
+                    case 5: tv = acc[2 % MI][1]; break;
+                    case 6: tv = acc[3 % MI][0]; break;
+                    default: tv = acc[3 % MI][1]; break;
+                }
                 float tf = ni ? tauf[1] : tauf[0];
                 const bool qv = ni ? qvalid[1] : qvalid[0];
                 const bool th = qv && (max16(tv) >= tf);
-                if (!__any(th)) continue;
+                if (!wave_any(th)) continue;
 #ifdef LVS_COUNT_EVENTS
                 ++n_visit;
 #endif
@@ -507,13 +527,13 @@ __global__ __launch_bounds__(512, 2) void lvs_tile_kernel(const LvsTileArgs a) {
                 __builtin_amdgcn_s_setprio(3);
 #pragma unroll
                 for (int g4 = 0; g4 < 4; ++g4) {  // rows 8g .. 8g+3: skip the group when none of its four scores can enter
-                    const float m4 = fmaxf(fmaxf(tv[4 * g4], tv[4 * g4 + 1]), fmaxf(tv[4 * g4 + 2], tv[4 * g4 + 3]));
-                    if (!__any(th && m4 >= tf)) continue;
+                    const float m4 = max4(tv[4 * g4], tv[4 * g4 + 1], tv[4 * g4 + 2], tv[4 * g4 + 3]);
+                    if (!wave_any(th && m4 >= tf)) continue;
 #pragma unroll
                 for (int e4 = 0; e4 < 4; ++e4) {
                     const int r = 4 * g4 + e4;
                     const float s = tv[r];
-                    if (!__any(th && s >= tf)) continue;  // wave-uniform skip before any per-lane work
+                    if (!wave_any(th && s >= tf)) continue;  // wave-uniform skip before any per-lane work
                     bool pending = false;
                     u64 key = 0;
                     if (th && s >= tf) {
@@ -533,6 +553,7 @@ __global__ __launch_bounds__(512, 2) void lvs_tile_kernel(const LvsTileArgs a) {
                     while (pm) {
 #ifdef LVS_COUNT_EVENTS
                         ++n_ins;
+                        const unsigned long long ti0 = __builtin_amdgcn_s_memtime();
 #endif
                         const int src = __ffsll((long long)pm) - 1;
                         pm &= pm - 1;
@@ -569,6 +590,9 @@ __global__ __launch_bounds__(512, 2) void lvs_tile_kernel(const LvsTileArgs a) {
                         if (lane == 0)
                             __hip_atomic_store(&locks[uq], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                         if (q == uq) tf = fmaxf(tf, tau_float(ntau));
+#ifdef LVS_COUNT_EVENTS
+                        c_ins += __builtin_amdgcn_s_memtime() - ti0;
+#endif
                     }
                 }
                 }  // g4
@@ -576,8 +600,11 @@ __global__ __launch_bounds__(512, 2) void lvs_tile_kernel(const LvsTileArgs a) {
                 if (ni) tauf[1] = fmaxf(tauf[1], tf); else tauf[0] = fmaxf(tauf[0], tf);
             }
         }
-        // publish thresholds for the other slabs of these queries every 8 tiles and at the end of the item
-        if (((ti & 7) == 0) || t + 1 == T) {
+#ifdef LVS_COUNT_EVENTS
+        c_visit += __builtin_amdgcn_s_memtime() - tm1;
+#endif
+        // publish thresholds for the other slabs of these queries (several slabs of one query tile may run at the same time)
+        if (ti <= 8 || ((ti & 7) == 0) || t + 1 == T) {  // every tile while the lists are still filling, then every 8
 #pragma unroll
             for (int ni = 0; ni < 2; ++ni) {
                 const uint32_t lo = (uint32_t)(lists[qloc[ni] * KCAP + k - 1] >> 32);
@@ -598,6 +625,9 @@ __global__ __launch_bounds__(512, 2) void lvs_tile_kernel(const LvsTileArgs a) {
         atomicAdd(&a.dbg[0], (unsigned long long)n_visit);
         atomicAdd(&a.dbg[1], (unsigned long long)n_ins);
         atomicAdd(&a.dbg[2], (unsigned long long)n_wt);
+        atomicAdd(&a.dbg[3], c_filter);
+        atomicAdd(&a.dbg[4], c_visit);
+        atomicAdd(&a.dbg[5], c_ins);
     }
 #endif
     if constexpr (MODE == LVS_MODE_RANGE || MODE == LVS_MODE_SCORES) return;
