@@ -384,7 +384,7 @@ struct Plan {
     int seg_q[3], seg_c[3];
     int ntiles, nqt, nslab, tiles_per_slab;
     int kpass, npass;
-    int gq;
+    int gq, lead_slabs;
     int v2;  // 1: 256 x 256 geometry (k <= LVS2_KCAP, TOP1 / SCORES / RANGE); 0: 256 x 128 geometry (k > LVS2_KCAP)
     int64_t off_gtau, off_partial, off_pass, total;
 };
@@ -454,7 +454,11 @@ int make_plan(int64_t nq, int64_t nb, int32_t d, int32_t xb_pack, int32_t xq_pac
     s = lvs_round_up(s, gs);
     if (s > p.ntiles) s = p.ntiles;
     if (s < 1) s = 1;
-    if (slabs_l2 > 0) s = slabs_l2;
+    p.lead_slabs = 0;
+    if (slabs_l2 > 0) {  // one leading slab per query tile in wide groups + slabs_l2 slabs in the narrow groups
+        p.lead_slabs = getenv("LVS_LEAD") ? (atoi(getenv("LVS_LEAD")) != 0) : 1;
+        s = slabs_l2 + p.lead_slabs;
+    }
     if (const char* e = getenv("LVS_NSLAB")) {  // tuning override
         int64_t v = atoll(e);
         if (v >= 1 && v <= p.ntiles) s = v;
@@ -547,6 +551,7 @@ extern "C" int32_t lvs_flat_search_keys(const void* xb, int32_t xb_pack, int64_t
     a.nqt = p.nqt;
     a.bq = p.v2 ? LVS2_BQ : LVS3_BQ;
     a.gq = p.gq;
+    a.lead_slabs = p.lead_slabs;
     a.debug_hot = getenv("LVS_DEBUG_HOT") ? atoi(getenv("LVS_DEBUG_HOT")) : 0;
     a.dbg = nullptr;
     unsigned long long* dbg_counters = nullptr;
@@ -716,6 +721,7 @@ extern "C" int32_t lvs_scores(const void* xb, int32_t xb_pack, int64_t nb, const
     a.nqt = p.nqt;
     a.bq = p.v2 ? LVS2_BQ : LVS3_BQ;
     a.gq = p.gq;
+    a.lead_slabs = p.lead_slabs;
     LVS_HIP_CHECK(lvs_tile_launch(LVS_MODE_SCORES, a, (hipStream_t)stream));
     return LVS_OK;
 }
@@ -759,6 +765,7 @@ extern "C" int32_t lvs_range_join(const void* xb, int32_t xb_pack, int64_t nb, c
     a.nqt = p.nqt;
     a.bq = p.v2 ? LVS2_BQ : LVS3_BQ;
     a.gq = p.gq;
+    a.lead_slabs = p.lead_slabs;
     a.pair_q = (long long*)out_q;
     a.pair_j = (long long*)out_j;
     a.pair_s = out_s;

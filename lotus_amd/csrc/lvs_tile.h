@@ -52,10 +52,11 @@ struct LvsTileArgs {
                               // 2 skip the top-k slow path, 3 scan hits but skip insertions, 4 no wait for the
                               // staging loads (256x256 kernel only)
     int gq;                   // query tiles per XCD group (1,2,4,8,16,32); slabs per group = 32 / gq
+    int lead_slabs;           // slabs walked first in 32-wide groups (see item_of_block); 0 or 1
     unsigned long long* dbg;  // tuning aid (build with -DLVS_COUNT_EVENTS, run with LVS_COUNT=1): [0] block visits, [1] insertions, [2] wave-tiles, [3..5] cycles in filter / visit loop / insertions
 };
 
-int lvs_tile_grid_blocks(int nqt, int nslab, int gq);
+int lvs_tile_grid_blocks(int nqt, int nslab, int gq, int lead_slabs);
 hipError_t lvs_tile_launch(int mode, const LvsTileArgs& a, hipStream_t stream);
 
 // ---- small-batch streaming kernel (lvs_stream.hip): nq <= 32, k <= LVS_KPASS ----

@@ -115,15 +115,31 @@ __device__ inline bool wave_any(bool p) { return __builtin_amdgcn_ballot_w64(p) 
 
 __device__ inline float tau_float(uint32_t ord) { return ord == 0 ? -INFINITY : lvs_unord32(ord); }
 
+// blockIdx -> (query tile, slab).  Blocks are dealt to the XCDs round-robin (b % 8, observed; used for speed only) and an
+// XCD runs 32 of them at a time, so 32 consecutive blocks of one XCD form a "group" that shares operands through that
+// XCD's L2: gq query tiles x 32/gq slabs.  Groups walk the query tiles first, then the slabs, so a query's later slabs
+// start with the thresholds its earlier slabs published.  With a.lead_slabs = 1 the first slab of EVERY query tile is
+// done first in 32-wide groups (one slab at a time per query: a single cold start), and only the remaining slabs use
+// the narrow groups whose 32/gq slabs per query run concurrently.
 __device__ inline bool item_of_block(const LvsTileArgs& a, int b, int& qt, int& slab) {
     int x = b & 7, j = b >> 3;
     int gseq = j >> 5, r = j & 31;
     int g = gseq * 8 + x;
+    if (a.lead_slabs > 0) {
+        const int nqg32 = (a.nqt + 31) / 32;
+        const int n0 = nqg32 * a.lead_slabs;
+        if (g < n0) {
+            slab = g / nqg32;
+            qt = (g % nqg32) * 32 + r;
+            return qt < a.nqt && slab < a.nslab;
+        }
+        g -= n0;
+    }
     int gq = a.gq, gs = 32 / a.gq;
     int nqg = (a.nqt + gq - 1) / gq;
     int qgroup = g % nqg, sgroup = g / nqg;
     qt = qgroup * gq + (r % gq);
-    slab = sgroup * gs + (r / gq);
+    slab = a.lead_slabs + sgroup * gs + (r / gq);
     return qt < a.nqt && slab < a.nslab;
 }
 
@@ -667,7 +683,7 @@ static hipError_t launch_one(const LvsTileArgs& a, hipStream_t stream) {
         if (e != hipSuccess) return e;
         attr_done = true;
     }
-    dim3 grid(lvs_tile_grid_blocks(a.nqt, a.nslab, a.gq)), block(512);
+    dim3 grid(lvs_tile_grid_blocks(a.nqt, a.nslab, a.gq, a.lead_slabs)), block(512);
     hipLaunchKernelGGL((lvs_tile_kernel<MODE, MI>), grid, block, lds, stream, a);
     return hipGetLastError();
 }
@@ -686,9 +702,9 @@ hipError_t lvs_tile_launch(int mode, const LvsTileArgs& a, hipStream_t stream) {
     return launch_one<LVS_MODE_TOPK, 4>(a, stream);
 }
 
-int lvs_tile_grid_blocks(int nqt, int nslab, int gq) {
+int lvs_tile_grid_blocks(int nqt, int nslab, int gq, int lead_slabs) {
     int gs = 32 / gq;
-    long long nqg = (nqt + gq - 1) / gq, nsg = (nslab + gs - 1) / gs;
-    long long groups = lvs_round_up(nqg * nsg, 8);
-    return (int)(groups * 32);
+    long long nqg = (nqt + gq - 1) / gq, nsg = (nslab - lead_slabs + gs - 1) / gs;
+    long long groups = (long long)((nqt + 31) / 32) * lead_slabs + nqg * nsg;
+    return (int)(lvs_round_up(groups, 8) * 32);
 }
