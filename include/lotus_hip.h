@@ -46,8 +46,9 @@ extern "C" {
 #define LVS_PACK_F16 0   /* fp16 values, one MFMA pass (embeddings stored as fp16) */
 #define LVS_PACK_SPLIT 1 /* fp32 values carried as fp16 hi|lo pair, three MFMA passes, ~2^-21 relative error */
 
-/* largest k lvs_flat_search_keys accepts: one pass for k <= 56 (k <= 15 on the faster 256-query geometry), else
-   ceil(k/56) passes over the corpus */
+/* largest k lvs_flat_search_keys accepts: one pass for k <= 56 (k <= 15 on the faster 256-query geometry); beyond that
+   two passes (per-slab lists -> threshold key -> collect -> sort), falling back to ceil(k/56) selection passes when a
+   candidate bucket overflows */
 #define LVS_MAX_K 2048
 
 int32_t lvs_abi_version(void);

@@ -390,7 +390,7 @@ struct Plan {
 };
 
 int make_plan(int64_t nq, int64_t nb, int32_t d, int32_t xb_pack, int32_t xq_pack, int32_t k, Plan& p,
-              bool force_v2 = false) {
+              bool force_v2 = false, int64_t min_slabs = 0, int64_t max_slabs_cap = 0) {
     if (nq < 0 || nb < 0 || d <= 0 || k < 0) return LVS_EINVAL;
     if (xb_pack != LVS_PACK_F16 && xb_pack != LVS_PACK_SPLIT) return LVS_EINVAL;
     if (xq_pack != LVS_PACK_F16 && xq_pack != LVS_PACK_SPLIT) return LVS_EINVAL;
@@ -434,7 +434,7 @@ int make_plan(int64_t nq, int64_t nb, int32_t d, int32_t xb_pack, int32_t xq_pac
     // half the fabric traffic, +3 % clock) and win 1-5 % once each of >= 20 slabs still has >= 160 tiles
     // (profiles/r01_tuning.md); shorter slabs lose more to the extra cold starts than the locality returns.
     int64_t slabs_l2 = 0;
-    if (p.v2 && p.gq > 8 && p.nqt >= 64) {
+    if (p.v2 && p.gq > 8 && p.nqt >= 64 && min_slabs == 0) {
         const int64_t n8 = lvs_round_up(want > 20 ? want : 20, 4);
         if (p.ntiles / n8 >= 160) {
             p.gq = 8;
@@ -461,6 +461,11 @@ int make_plan(int64_t nq, int64_t nb, int32_t d, int32_t xb_pack, int32_t xq_pac
         p.lead_slabs = getenv("LVS_LEAD") ? (atoi(getenv("LVS_LEAD")) != 0) : 1;
         s = slabs_l2 + p.lead_slabs;
     }
+    if (min_slabs > 0 && s < min_slabs) {  // the caller needs at least this many per-slab candidate lists
+        s = lvs_round_up(min_slabs, gs);
+        if (s > p.ntiles) s = p.ntiles;
+    }
+    if (max_slabs_cap > 0 && s > max_slabs_cap) s = max_slabs_cap;  // ... and at most this many
     if (const char* e = getenv("LVS_NSLAB")) {  // tuning override
         int64_t v = atoll(e);
         if (v >= 1 && v <= p.ntiles) s = v;
@@ -481,6 +486,120 @@ int make_plan(int64_t nq, int64_t nb, int32_t d, int32_t xb_pack, int32_t xq_pac
     return LVS_OK;
 }
 
+// One workgroup per query: n candidate keys src[q * stride_q + (i / inner) * stride_outer + (i % inner)], i < n, are
+// sorted descending (bitonic, in LDS, P2 = power of two >= n slots) and the k-th largest (kth_out[q]; 0 when n < k)
+// and/or the k largest (topk_out[q * out_ld + 0..k)) are written.  With counts != NULL, n = min(counts[q], n_max) and
+// *overflow is set when some counts[q] > n_max (candidates were dropped by the producer).
+__global__ __launch_bounds__(256) void select_keys_kernel(const u64* __restrict__ src, long long stride_q, int inner,
+                                                          long long stride_outer, int n_max,
+                                                          const uint32_t* __restrict__ counts, int k, int P2,
+                                                          u64* __restrict__ kth_out, u64* __restrict__ topk_out,
+                                                          long long out_ld, uint32_t* __restrict__ overflow) {
+    extern __shared__ __attribute__((aligned(16))) char sel_smem[];
+    u64* sk = (u64*)sel_smem;
+    const long long q = blockIdx.x;
+    int n = n_max;
+    if (counts) {
+        uint32_t c = counts[q];
+        if (c > (uint32_t)n_max) {
+            if (threadIdx.x == 0 && overflow) atomicOr(overflow, 1u);
+            c = (uint32_t)n_max;
+        }
+        n = (int)c;
+    }
+    const u64* base = src + q * stride_q;
+    for (int i = threadIdx.x; i < P2; i += 256) {
+        u64 v = 0;
+        if (i < n) v = base[(long long)(i / inner) * stride_outer + (i % inner)];
+        sk[i] = v;
+    }
+    __syncthreads();
+    for (int size = 2; size <= P2; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int i = threadIdx.x; i < P2; i += 256) {
+                const int j = i ^ stride;
+                if (j > i) {
+                    const bool desc = (i & size) == 0;  // the last merge (size == P2) is descending everywhere
+                    const u64 x = sk[i], y = sk[j];
+                    if ((x < y) == desc) {
+                        sk[i] = y;
+                        sk[j] = x;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    if (kth_out && threadIdx.x == 0) kth_out[q] = k <= P2 ? sk[k - 1] : 0;
+    if (topk_out)
+        for (int j = threadIdx.x; j < k; j += 256) topk_out[q * out_ld + j] = j < P2 ? sk[j] : 0;
+}
+
+int pow2_ceil(int v) {
+    int p = 1;
+    while (p < v) p <<= 1;
+    return p;
+}
+constexpr int LVS_SELECT_MAX = 4096;  // most candidates per query select_keys_kernel sorts (32 KB of LDS)
+
+hipError_t launch_select(const u64* src, long long stride_q, int inner, long long stride_outer, int n_max,
+                         const uint32_t* counts, int k, u64* kth_out, u64* topk_out, long long out_ld, uint32_t* overflow,
+                         int64_t nq, hipStream_t st) {
+    const int P2 = pow2_ceil(n_max < 2 ? 2 : n_max);
+    hipLaunchKernelGGL(select_keys_kernel, dim3((unsigned)nq), dim3(256), (size_t)P2 * 8, st, src, stride_q, inner,
+                       stride_outer, n_max, counts, k, P2, kth_out, topk_out, out_ld, overflow);
+    return hipGetLastError();
+}
+
+// ---- large k in two phases (k > LVS_KPASS) ----------------------------------------------------------------------
+// Phase A is a 15-per-slab top-k pass with at least 3k/15 slabs that do NOT share thresholds, so every slab's list is
+// its own exact top 15.  The lists hold 15 * nslab DISTINCT rows,
+// so the k-th largest of all their keys is a valid lower bound T of the query's true k-th best key - and a tight one
+// unless one slab holds more than 15 of the true top k.  Phase B (LVS_MODE_COLLECT) streams the corpus once more and
+// drops every key >= T into the query's bucket (>= k keys by construction); phase C sorts the bucket and keeps k.
+// Exact; two corpus passes whatever k is.  If a bucket overflows (heavily tied or slab-clustered data) the caller falls
+// back to ceil(k / LVS_KPASS) selection passes.
+struct TwoPhasePlan {
+    Plan a;             // phase A geometry: 15-slot lists (256 x 256) for moderate k, 56-slot lists (256 x 128) beyond
+    Plan b;             // phase B (collect) geometry: always 256 x 256
+    int slots;          // list slots per (query, slab) in phase A
+    int capacity;       // bucket slots per query
+    int64_t off_thr, off_cnt, off_flag, off_bucket, total;
+};
+
+bool make_two_phase_plan(int64_t nq, int64_t nb, int32_t d, int32_t xb_pack, int32_t xq_pack, int32_t k,
+                         TwoPhasePlan& tp) {
+    if (k <= LVS_KPASS || nq <= 0 || nb <= 0) return false;
+    if (const char* e = getenv("LVS_TWO_PHASE"))
+        if (atoi(e) == 0) return false;
+    // 15-slot lists on the fast geometry beat 56-slot lists on the 128-query geometry at every k tried (100 .. 1000:
+    // 329 vs 402 ms, 545 vs 607 ms at 100 k x 1 M), although they need four times the slabs
+    tp.slots = LVS2_KCAP;
+    if (const char* e = getenv("LVS_TWO_PHASE_SLOTS")) tp.slots = atoi(e) == LVS3_KCAP ? LVS3_KCAP : LVS2_KCAP;  // tuning
+    const int64_t cap_slabs = LVS_SELECT_MAX / tp.slots;        // the selection kernel sorts at most 4096 keys per query
+    int64_t want_slabs = lvs_ceil_div(2ll * k, tp.slots);       // ~2k candidates: a tight bound at a moderate slab count
+    if (want_slabs > cap_slabs) want_slabs = cap_slabs;
+    if (make_plan(nq, nb, d, xb_pack, xq_pack, tp.slots, tp.a, tp.slots == LVS2_KCAP, want_slabs, cap_slabs) != LVS_OK)
+        return false;
+    if ((int64_t)tp.a.nslab * tp.slots > LVS_SELECT_MAX) return false;
+    if ((int64_t)tp.a.nslab * tp.slots < (int64_t)k + k / 4) return false;  // corpus too small for a useful bound
+    if (make_plan(nq, nb, d, xb_pack, xq_pack, LVS2_KCAP, tp.b, true) != LVS_OK) return false;
+    tp.capacity = pow2_ceil(2 * k < 512 ? 512 : 2 * k);
+    if (tp.capacity > LVS_SELECT_MAX) tp.capacity = LVS_SELECT_MAX;
+    if (tp.capacity < k) return false;
+    int64_t off = tp.a.off_pass;  // gtau and the per-slab lists use the phase-A plan's layout
+    tp.off_thr = off;
+    off += lvs_round_up(nq * 8, 256);
+    tp.off_cnt = off;
+    off += lvs_round_up(nq * 4, 256);
+    tp.off_flag = off;
+    off += 256;
+    tp.off_bucket = off;
+    off += lvs_round_up(nq * (int64_t)tp.capacity * 8, 256);
+    tp.total = off;
+    return true;
+}
+
 __global__ void copy_pass_kernel(const u64* __restrict__ src, long long nq, int kp, u64* __restrict__ dst, int k,
                                  int col0) {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -494,6 +613,8 @@ __global__ void copy_pass_kernel(const u64* __restrict__ src, long long nq, int 
 extern "C" int64_t lvs_flat_search_workspace_bytes(int64_t nq, int64_t nb, int32_t d, int32_t k) {
     Plan p;
     if (make_plan(nq, nb, d, LVS_PACK_F16, LVS_PACK_F16, k, p) != LVS_OK) return LVS_EINVAL;
+    TwoPhasePlan tp;
+    if (make_two_phase_plan(nq, nb, d, LVS_PACK_F16, LVS_PACK_F16, k, tp) && tp.total > p.total) return tp.total;
     return p.total;
 }
 
@@ -525,36 +646,102 @@ extern "C" int32_t lvs_flat_search_keys(const void* xb, int32_t xb_pack, int64_t
     u64* partial = (u64*)(ws + p.off_partial);
     u64* passbuf = (u64*)(ws + p.off_pass);
 
-    LvsTileArgs a;
-    memset(&a, 0, sizeof(a));
-    a.xb = xb;
-    a.xq = xq;
-    a.bn = xb_norms_sq;
-    a.qn = xq_norms_sq;
-    a.row_ids = row_ids;
-    a.gtau = gtau;
-    a.out = partial;
-    a.nb = nb;
-    a.nq = nq;
-    a.ldb = p.ldb;
-    a.ldq = p.ldq;
-    a.nseg = p.nseg;
-    for (int i = 0; i < 3; ++i) {
-        a.seg_q[i] = p.seg_q[i];
-        a.seg_c[i] = p.seg_c[i];
+    auto fill_args = [&](LvsTileArgs& a, const Plan& pl, uint32_t* gtau_, u64* out_) {
+        memset(&a, 0, sizeof(a));
+        a.xb = xb;
+        a.xq = xq;
+        a.bn = xb_norms_sq;
+        a.qn = xq_norms_sq;
+        a.row_ids = row_ids;
+        a.gtau = gtau_;
+        a.out = out_;
+        a.nb = nb;
+        a.nq = nq;
+        a.ldb = pl.ldb;
+        a.ldq = pl.ldq;
+        a.nseg = pl.nseg;
+        for (int i = 0; i < 3; ++i) {
+            a.seg_q[i] = pl.seg_q[i];
+            a.seg_c[i] = pl.seg_c[i];
+        }
+        a.id_offset = id_offset;
+        a.nkd = pl.nkd;
+        a.nk = pl.nk;
+        a.metric = metric;
+        a.ntiles = pl.ntiles;
+        a.tiles_per_slab = pl.tiles_per_slab;
+        a.nslab = pl.nslab;
+        a.nqt = pl.nqt;
+        a.bq = pl.v2 ? LVS2_BQ : LVS3_BQ;
+        a.gq = pl.gq;
+        a.lead_slabs = pl.lead_slabs;
+        a.debug_hot = getenv("LVS_DEBUG_HOT") ? atoi(getenv("LVS_DEBUG_HOT")) : 0;
+    };
+
+    // ---- k > LVS_KPASS: two corpus passes whatever k is (see make_two_phase_plan); on bucket overflow fall through ----
+    {
+        TwoPhasePlan tp;
+        if (make_two_phase_plan(nq, nb, d, xb_pack, xq_pack, k, tp) && tp.total <= workspace_bytes) {
+            uint32_t* gtau2 = (uint32_t*)(ws + tp.a.off_gtau);
+            u64* lists = (u64*)(ws + tp.a.off_partial);          // [nslab][nq][slots]
+            u64* thr = (u64*)(ws + tp.off_thr);                  // [nq]
+            uint32_t* cnt = (uint32_t*)(ws + tp.off_cnt);        // [nq]
+            uint32_t* flag = (uint32_t*)(ws + tp.off_flag);
+            u64* bucket = (u64*)(ws + tp.off_bucket);            // [nq][capacity]
+            LvsTileArgs ta;
+            fill_args(ta, tp.a, gtau2, lists);
+            ta.k = tp.slots;
+            ta.no_share = 1;  // the bound needs every slab's own top list, not lists pruned by other slabs' thresholds
+            LVS_HIP_CHECK(hipMemsetAsync(gtau2, 0, (size_t)nq * 4, st));
+            LVS_HIP_CHECK(hipMemsetAsync(cnt, 0, (size_t)nq * 4, st));
+            LVS_HIP_CHECK(hipMemsetAsync(flag, 0, 4, st));
+            {
+                ScopedKernelTimer timer(st);
+                LVS_HIP_CHECK(lvs_tile_launch(LVS_MODE_TOPK, ta, st));
+            }
+            // T[q] = k-th largest of the nslab * slots listed keys (element (slab, j) of query q at (slab * nq + q) * slots + j)
+            LVS_HIP_CHECK(launch_select(lists, tp.slots, tp.slots, (long long)nq * tp.slots, tp.a.nslab * tp.slots,
+                                        nullptr, k, thr, nullptr, 0, nullptr, nq, st));
+            LvsTileArgs tb;
+            fill_args(tb, tp.b, gtau2, lists);
+            tb.k = 1;
+            tb.thr_key = thr;
+            tb.bucket_count = cnt;
+            tb.bucket = bucket;
+            tb.bucket_capacity = tp.capacity;
+            LVS_HIP_CHECK(lvs_tile_launch(LVS_MODE_COLLECT, tb, st));
+            LVS_HIP_CHECK(launch_select(bucket, tp.capacity, tp.capacity, 0, tp.capacity, cnt, k, nullptr,
+                                        (u64*)out_keys, k, flag, nq, st));
+            uint32_t overflowed = 0;
+            LVS_HIP_CHECK(hipMemcpyAsync(&overflowed, flag, 4, hipMemcpyDeviceToHost, st));
+            LVS_HIP_CHECK(hipStreamSynchronize(st));
+            if (getenv("LVS_TWO_PHASE_DEBUG")) {  // tuning aid
+                std::vector<uint32_t> h((size_t)nq);
+                LVS_HIP_CHECK(hipMemcpy(h.data(), cnt, (size_t)nq * 4, hipMemcpyDeviceToHost));
+                uint32_t mn = ~0u, mx = 0;
+                double sum = 0;
+                for (uint32_t v : h) {
+                    mn = v < mn ? v : mn;
+                    mx = v > mx ? v : mx;
+                    sum += v;
+                }
+                fprintf(stderr, "[lvs] two-phase k=%d slots=%d slabs=%d capacity=%d: bucket counts min %u mean %.1f max %u overflow=%u\n",
+                        k, tp.slots, tp.a.nslab, tp.capacity, mn, sum / (double)nq, mx, overflowed);
+                std::vector<unsigned long long> ht((size_t)nq);
+                LVS_HIP_CHECK(hipMemcpy(ht.data(), thr, (size_t)nq * 8, hipMemcpyDeviceToHost));
+                int shown = 0;
+                for (int64_t q = 0; q < nq && shown < 24; ++q)
+                    if (h[(size_t)q] > (uint32_t)tp.capacity) {
+                        fprintf(stderr, "[lvs]   q=%lld count=%u thr=%016llx\n", (long long)q, h[(size_t)q], ht[(size_t)q]);
+                        ++shown;
+                    }
+            }
+            if (!overflowed) return LVS_OK;
+        }
     }
-    a.id_offset = id_offset;
-    a.nkd = p.nkd;
-    a.nk = p.nk;
-    a.metric = metric;
-    a.ntiles = p.ntiles;
-    a.tiles_per_slab = p.tiles_per_slab;
-    a.nslab = p.nslab;
-    a.nqt = p.nqt;
-    a.bq = p.v2 ? LVS2_BQ : LVS3_BQ;
-    a.gq = p.gq;
-    a.lead_slabs = p.lead_slabs;
-    a.debug_hot = getenv("LVS_DEBUG_HOT") ? atoi(getenv("LVS_DEBUG_HOT")) : 0;
+
+    LvsTileArgs a;
+    fill_args(a, p, gtau, partial);
     a.dbg = nullptr;
     unsigned long long* dbg_counters = nullptr;
 #ifdef LVS_COUNT_EVENTS
@@ -665,9 +852,15 @@ extern "C" int32_t lvs_flat_search_keys(const void* xb, int32_t xb_pack, int64_t
 extern "C" int32_t lvs_merge_keys(const uint64_t* parts, int32_t nparts, int64_t nq, int32_t k, uint64_t* out_keys,
                                   void* stream) {
     LVS_REQUIRE(nparts >= 1 && nq >= 0 && k >= 0, "bad arguments");
-    LVS_REQUIRE(k <= 64, "lvs_merge_keys handles k <= 64 per call (got %d)", k);
     if (nq == 0 || k == 0) return LVS_OK;
     LVS_REQUIRE(parts && out_keys, "NULL buffer");
+    if (k > 64) {  // long lists: sort all nparts * k candidates of a query in LDS
+        LVS_REQUIRE((int64_t)nparts * k <= LVS_SELECT_MAX, "lvs_merge_keys: nparts * k = %lld exceeds %d",
+                    (long long)nparts * k, LVS_SELECT_MAX);
+        LVS_HIP_CHECK(launch_select((const u64*)parts, k, k, (long long)nq * k, nparts * k, nullptr, k, nullptr,
+                                    (u64*)out_keys, k, nullptr, nq, (hipStream_t)stream));
+        return LVS_OK;
+    }
     hipLaunchKernelGGL(merge_keys_kernel, dim3((unsigned)lvs_ceil_div(nq, 4)), dim3(256), 0, (hipStream_t)stream,
                        (const u64*)parts, nparts, (long long)nq, k, (u64*)out_keys, (long long)k);
     LVS_HIP_CHECK(hipGetLastError());

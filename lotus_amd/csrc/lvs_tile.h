@@ -15,6 +15,7 @@
 #define LVS_MODE_SCORES 1
 #define LVS_MODE_TOP1 2
 #define LVS_MODE_RANGE 3
+#define LVS_MODE_COLLECT 4
 
 struct LvsTileArgs {
     const void* xb;           // [nb][ld] fp16 packed corpus shard
@@ -53,6 +54,13 @@ struct LvsTileArgs {
                               // staging loads (256x256 kernel only)
     int gq;                   // query tiles per XCD group (1,2,4,8,16,32); slabs per group = 32 / gq
     int lead_slabs;           // slabs walked first in 32-wide groups (see item_of_block); 0 or 1
+    int no_share;             // 1: slabs do not exchange thresholds - every slab's list is its own exact top-k
+    // LVS_MODE_COLLECT: keys >= thr_key[q] go to bucket[q][*] (unordered, at most bucket_capacity are kept; bucket_count
+    // keeps counting so that the caller sees an overflow)
+    const u64* thr_key;       // [nq]
+    uint32_t* bucket_count;   // [nq] zero-initialised
+    u64* bucket;              // [nq][bucket_capacity]
+    int bucket_capacity;
     unsigned long long* dbg;  // tuning aid (build with -DLVS_COUNT_EVENTS, run with LVS_COUNT=1): [0] block visits, [1] insertions, [2] wave-tiles, [3..5] cycles in filter / visit loop / insertions
 };
 

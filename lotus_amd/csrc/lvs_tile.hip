@@ -145,7 +145,8 @@ __device__ inline bool item_of_block(const LvsTileArgs& a, int b, int& qt, int& 
 
 }  // namespace
 
-// MODE  TOPK: sorted lists (k <= KCAP); TOP1: k == 1, per-lane best; RANGE: threshold join; SCORES: matrix out
+// MODE  TOPK: sorted lists (k <= KCAP); TOP1: k == 1, per-lane best; RANGE: threshold join; SCORES: matrix out;
+//       COLLECT: every key >= a per-query threshold key into that query's bucket (second phase of large-k search)
 template <int MODE, int MI>
 __global__ __launch_bounds__(512, 2) void lvs_tile_kernel(const LvsTileArgs a) {
     using G = Geo<MI>;
@@ -248,6 +249,10 @@ __global__ __launch_bounds__(512, 2) void lvs_tile_kernel(const LvsTileArgs a) {
         if (qvalid[ni]) {
             if (a.ub) ubk[ni] = a.ub[(q0 + qloc[ni]) * a.ub_stride];
             if (a.metric == LVS_METRIC_L2) qnv[ni] = a.qn[q0 + qloc[ni]];
+            if (MODE == LVS_MODE_COLLECT) {  // ubk = LOWER bound key here, tauf = its score
+                ubk[ni] = a.thr_key[q0 + qloc[ni]];
+                tauf[ni] = tau_float((uint32_t)(ubk[ni] >> 32));
+            }
         }
     }
 
@@ -305,7 +310,7 @@ __global__ __launch_bounds__(512, 2) void lvs_tile_kernel(const LvsTileArgs a) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
         }
-        if (MODE == LVS_MODE_TOPK && ks_in_tile == nk - 1) {
+        if (MODE == LVS_MODE_TOPK && ks_in_tile == nk - 1 && !a.no_share) {
 #pragma unroll
             for (int ni = 0; ni < 2; ++ni)
                 if (qvalid[ni]) gpre[ni] = a.gtau[q0 + qloc[ni]];
@@ -376,7 +381,7 @@ __global__ __launch_bounds__(512, 2) void lvs_tile_kernel(const LvsTileArgs a) {
         ++ti;
         const int lrow_base = wm * (MI * 32) + 4 * (lane >> 5);  // + mi*32 + (r&3) + 8*(r>>2)
 
-        if constexpr (MODE == LVS_MODE_RANGE || MODE == LVS_MODE_SCORES) {
+        if constexpr (MODE == LVS_MODE_RANGE || MODE == LVS_MODE_SCORES || MODE == LVS_MODE_COLLECT) {
             if (a.metric == LVS_METRIC_L2) {
 #pragma unroll
                 for (int mi = 0; mi < MI; ++mi)
@@ -394,7 +399,24 @@ __global__ __launch_bounds__(512, 2) void lvs_tile_kernel(const LvsTileArgs a) {
 #pragma unroll
                 for (int ni = 0; ni < 2; ++ni) {
                     const long long qg = q0 + qloc[ni];
-                    if (MODE == LVS_MODE_SCORES) {
+                    if constexpr (MODE == LVS_MODE_COLLECT) {
+                        // tauf / ubk were loaded from a.thr_key: score part (fast filter) and full key (exact test)
+                        const bool th = qvalid[ni] && (max16(acc[mi][ni]) >= tauf[ni]);
+                        if (!wave_any(th)) continue;
+                        if (!th) continue;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const float s = acc[mi][ni][r];
+                            if (!(s >= tauf[ni])) continue;
+                            const long long row = trow0 + lrow_base + mi * 32 + (r & 3) + 8 * (r >> 2);
+                            if (row >= a.nb) continue;
+                            const uint32_t id = a.row_ids ? a.row_ids[row] : (uint32_t)(row + a.id_offset);
+                            const u64 key = lvs_pack_key(s, id);
+                            if (key < ubk[ni]) continue;  // below the threshold KEY (same score, larger id)
+                            const uint32_t pos = atomicAdd(&a.bucket_count[qg], 1u);
+                            if (pos < (uint32_t)a.bucket_capacity) a.bucket[qg * a.bucket_capacity + pos] = key;
+                        }
+                    } else if (MODE == LVS_MODE_SCORES) {
                         if (!qvalid[ni]) continue;
                         float* orow = a.scores + qg * a.ld_scores;
 #pragma unroll
@@ -620,7 +642,7 @@ __global__ __launch_bounds__(512, 2) void lvs_tile_kernel(const LvsTileArgs a) {
         c_visit += __builtin_amdgcn_s_memtime() - tm1;
 #endif
         // publish thresholds for the other slabs of these queries (several slabs of one query tile may run at the same time)
-        if (ti <= 8 || ((ti & 7) == 0) || t + 1 == T) {  // every tile while the lists are still filling, then every 8
+        if (!a.no_share && (ti <= 8 || ((ti & 7) == 0) || t + 1 == T)) {  // every tile while the lists fill, then every 8
 #pragma unroll
             for (int ni = 0; ni < 2; ++ni) {
                 const uint32_t lo = (uint32_t)(lists[qloc[ni] * KCAP + k - 1] >> 32);
@@ -646,7 +668,7 @@ __global__ __launch_bounds__(512, 2) void lvs_tile_kernel(const LvsTileArgs a) {
         atomicAdd(&a.dbg[5], c_ins);
     }
 #endif
-    if constexpr (MODE == LVS_MODE_RANGE || MODE == LVS_MODE_SCORES) return;
+    if constexpr (MODE == LVS_MODE_RANGE || MODE == LVS_MODE_SCORES || MODE == LVS_MODE_COLLECT) return;
     if constexpr (MODE == LVS_MODE_TOP1) {
         // four lanes (l, l+32 of waves wm = 0, 1) hold partial winners of each query: combine by key
         __syncthreads();
@@ -699,6 +721,7 @@ hipError_t lvs_tile_launch(int mode, const LvsTileArgs& a, hipStream_t stream) {
     if (mode == LVS_MODE_TOP1) return launch_one<LVS_MODE_TOP1, 4>(a, stream);
     if (mode == LVS_MODE_RANGE) return launch_one<LVS_MODE_RANGE, 4>(a, stream);
     if (mode == LVS_MODE_SCORES) return launch_one<LVS_MODE_SCORES, 4>(a, stream);
+    if (mode == LVS_MODE_COLLECT) return launch_one<LVS_MODE_COLLECT, 4>(a, stream);
     return launch_one<LVS_MODE_TOPK, 4>(a, stream);
 }
 

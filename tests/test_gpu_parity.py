@@ -46,6 +46,10 @@ CASES = [
     (64, 3000, 128, 100, F16, IP),      # two passes (56 + 44)
     (40, 2000, 64, 200, F16, L2),       # four passes, L2
     (1500, 100000, 768, 20, F16, IP),   # 128-query geometry with several slabs and shared thresholds
+    (300, 60000, 384, 100, F16, IP),    # k > 56: two-phase (15-per-slab lists -> threshold key -> collect -> sort)
+    (64, 80000, 128, 300, F16, L2),
+    (10, 120000, 64, 1000, F16, IP),
+    (40, 150000, 100, 2048, SPLIT, IP), # LVS_MAX_K
     (130, 3000, 200, 30, SPLIT, IP),    # fp32-accurate operands on the 128-query geometry
     (300, 5000, 768, 10, F16, L2),
     (300, 5000, 384, 10, SPLIT, L2),
@@ -296,3 +300,29 @@ def test_full_size_properties(hip_backend):
     Dr, Ir = oracle.flat_search(xb_h, xq[torch.from_numpy(sel).to(be.device)].cpu().numpy().astype(np.float32), k, IP)
     err, hard, recall = synth.compare_topk(Dr, Ir, D[sel], I[sel])
     assert err <= 1e-5 and hard == 0 and recall == 1.0
+
+
+def test_large_k_with_mass_ties_falls_back_to_selection_passes(hip_backend):
+    """Thousands of identical rows overflow the two-phase buckets (every copy ties with the threshold score but only
+    the lower ids may enter): the call must fall back to the multi-pass selection and stay exact."""
+    be = hip_backend
+    base = synth.corpus(40, 64, seed=3)
+    xb = np.concatenate([np.repeat(base[:4], 3000, axis=0), synth.corpus(20000, 64, seed=4)])
+    xq, _ = synth.queries(base, 30, seed=5)
+    k = 200
+    D, I, _ = _run(be, xb, xq, k, F16, IP)
+    Dr, Ir = oracle.flat_search(_stored(xb, F16), _stored(xq, F16), k, IP)
+    assert np.abs(D - Dr).max() <= 1e-5
+    assert (I == Ir).mean() > 0.99  # exact ties are ordered by id on both sides
+
+
+def test_merge_keys_long_lists(hip_backend):
+    import torch
+
+    be = hip_backend
+    rng = np.random.default_rng(0)
+    parts = rng.integers(1, 2 ** 62, size=(8, 50, 300), dtype=np.int64)
+    out = be.merge_keys(torch.from_numpy(parts).to(be.device)).cpu().numpy().view(np.uint64)
+    ref = -np.sort(-parts.view(np.uint64).transpose(1, 0, 2).reshape(50, -1).astype(np.float64), axis=1)  # order only
+    want = np.sort(parts.view(np.uint64).transpose(1, 0, 2).reshape(50, -1), axis=1)[:, ::-1][:, :300]
+    assert np.array_equal(out, want)
