@@ -436,7 +436,8 @@ int make_plan(int64_t nq, int64_t nb, int32_t d, int32_t xb_pack, int32_t xq_pac
     int64_t slabs_l2 = 0;
     if (p.v2 && p.gq > 8 && p.nqt >= 64 && min_slabs == 0) {
         const int64_t n8 = lvs_round_up(want > 20 ? want : 20, 4);
-        if (p.ntiles / n8 >= 160) {
+        const int64_t min_tiles = getenv("LVS_L2_MIN_TILES") ? atoll(getenv("LVS_L2_MIN_TILES")) : 160;  // tuning override
+        if (p.ntiles / n8 >= min_tiles) {
             p.gq = 8;
             slabs_l2 = n8;
         }
