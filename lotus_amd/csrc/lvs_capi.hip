@@ -598,6 +598,7 @@ bool make_two_phase_plan(int64_t nq, int64_t nb, int32_t d, int32_t xb_pack, int
     tp.off_bucket = off;
     off += lvs_round_up(nq * (int64_t)tp.capacity * 8, 256);
     tp.total = off;
+    if (tp.total > (24ll << 30)) return false;  // lists + buckets beyond 24 GB: not worth it, use the selection passes
     return true;
 }
 
