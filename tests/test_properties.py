@@ -6,9 +6,11 @@ import pytest
 from hypothesis import HealthCheck, given, settings, strategies as st
 
 import oracle
+import synth
 from oracle_backend import OracleBackend
 
-hyp = settings(max_examples=25, deadline=None, suppress_health_check=[HealthCheck.too_slow])
+# derandomize: the same examples on every run (a CI run must not depend on which shapes hypothesis happens to draw)
+hyp = settings(max_examples=25, deadline=None, derandomize=True, suppress_health_check=[HealthCheck.too_slow])
 
 
 def _data(seed, nb, nq, d, dup):
@@ -48,8 +50,11 @@ def test_oracle_invariants(seed, nb, nq, d, k, metric, dup):
         import torch
 
         Dm, Im = be.keys_to_result(be.merge_keys(torch.stack([k1, k2])), metric)
-        assert np.array_equal(Im.numpy(), I)
-        assert np.allclose(Dm.numpy(), D, atol=1e-6)
+        # BLAS may sum a row's dot product in a different order depending on where the row sits in its block, so exact
+        # duplicates can differ in the last bit between the sharded and the unsharded call: compare with the tie rule
+        tol = 1e-5 * max(1.0, float(np.abs(D[I >= 0]).max()))  # the data here is not unit-norm
+        err, hard, recall = synth.compare_topk(D, I, Dm.numpy(), Im.numpy(), atol=tol, tie_gap=2 * tol)
+        assert err <= tol and hard == 0
 
 
 @hyp
