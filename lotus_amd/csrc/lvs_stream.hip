@@ -71,40 +71,81 @@ __global__ __launch_bounds__(WAVES * 64, 2) void lvs_stream_kernel(const LvsStre
     const long long b1 = b0 + a.blocks_per_wg < nblocks ? b0 + a.blocks_per_wg : nblocks;
     const int nj = a.nj, jper = a.jper;
 
+    // ---- fragment stream: one continuous software pipeline over ALL of this wave's row blocks --------------------
+    // The A-fragment loads run UNROLL fragments ahead of the MFMAs and cross block boundaries (the first fragments of
+    // the next block are in flight while this block's last MFMAs and its epilogue run), so the HBM latency is paid once
+    // per wave, not once per 32-row block.  A block's fragment count is padded to a multiple of UNROLL with repeats of
+    // its last fragment (d = 768: 48 fragments, no padding).  All stream state below is wave-uniform except the
+    // per-lane row pointers.
+    const int njp = (nj + UNROLL - 1) / UNROLL * UNROLL;
+    const int segc0 = a.seg_c[0], segc1 = a.seg_c[1], segc2 = a.seg_c[2];
+    const int segb0 = a.seg_b[0], segb1 = a.seg_b[1], segb2 = a.seg_b[2];
+    auto row_ptr = [&](long long blk) {
+        long long arow = blk * 32 + (lane & 31);
+        if (arow > a.nb - 1) arow = a.nb - 1;
+        return xb + arow * a.ldb + (lane >> 5) * 8;  // + seg_c[seg] + jj * 16
+    };
+    // load stream position: block l_blk, step l_s in [0, njp), fragment (l_seg, l_jj) while l_s < nj
+    long long l_blk = b0 + wave;
+    const _Float16* l_ap = row_ptr(l_blk < b1 ? l_blk : b0 + wave);
+    int l_s = 0, l_seg = 0, l_jj = 0, l_off = segc0;  // l_off = seg_c[l_seg] + l_jj * 16 (halfs)
+    auto next_load = [&]() {
+        const half8 v = *(const half8*)(l_ap + l_off);
+        ++l_s;
+        if (l_s < nj) {  // next real fragment of this block
+            if (++l_jj == jper) {
+                l_jj = 0;
+                ++l_seg;
+                l_off = l_seg == 1 ? segc1 : segc2;
+            } else {
+                l_off += 16;
+            }
+        } else if (l_s == njp) {  // block done: move to this wave's next block (or stay on the last one)
+            l_s = 0;
+            l_seg = 0;
+            l_jj = 0;
+            l_off = segc0;
+            if (l_blk + WAVES < b1) {
+                l_blk += WAVES;
+                l_ap = row_ptr(l_blk);
+            }
+        }  // else: padding step, repeat the last fragment
+        return v;
+    };
+    half8 abuf[UNROLL];
+    if (b0 + wave < b1) {
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) abuf[u] = next_load();
+    }
+
     for (long long blk = b0 + wave; blk < b1; blk += WAVES) {
         const long long row0 = blk * 32;
-        long long arow = row0 + (lane & 31);
-        if (arow > a.nb - 1) arow = a.nb - 1;
-        const _Float16* ap = xb + arow * a.ldb + (lane >> 5) * 8;  // + seg_c[seg] + jj * 16
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        // software pipeline: UNROLL fragments in flight
-        half8 abuf[UNROLL];
-#pragma unroll
-        for (int u = 0; u < UNROLL; ++u) {
-            const int j = u < nj ? u : nj - 1;
-            const int seg = j / jper, jj = j - seg * jper;
-            abuf[u] = *(const half8*)(ap + a.seg_c[seg] + jj * 16);
-        }
-        for (int j0 = 0; j0 < nj; j0 += UNROLL) {
+        int c_seg = 0, c_jj = 0, c_b = segb0;  // compute stream: B fragment index c_b = seg_b[c_seg] + c_jj
+        for (int j0 = 0; j0 < njp; j0 += UNROLL) {
 #pragma unroll
             for (int u = 0; u < UNROLL; ++u) {
-                const int j = j0 + u;
                 const half8 av = abuf[u];
-                // refill this slot with the fragment UNROLL steps ahead (clamped; surplus loads are harmless)
-                int jn = j + UNROLL;
-                jn = jn < nj ? jn : nj - 1;
-                const int segn = jn / jper, jjn = jn - segn * jper;
-                abuf[u] = *(const half8*)(ap + a.seg_c[segn] + jjn * 16);
-                if (j < nj) {
-                    const int sg = j / jper;
-                    const half8 bv = bfrag[(a.seg_b[sg] + j - sg * jper) * 64 + lane];
+                abuf[u] = next_load();  // the fragment UNROLL steps ahead (possibly of the next block)
+                if (a.debug == 1) {
+                    acc[0] += (float)av[0];
+                } else if (j0 + u < nj) {
+                    const half8 bv = bfrag[c_b * 64 + lane];
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bv, acc, 0, 0, 0);
+                    if (++c_jj == jper) {
+                        c_jj = 0;
+                        ++c_seg;
+                        c_b = c_seg == 1 ? segb1 : segb2;
+                    } else {
+                        ++c_b;
+                    }
                 }
             }
         }
         // ---- block epilogue: 32 rows x 32 queries; lane holds query q, rows row0 + (r&3) + 8*(r>>2) + 4*(lane>>5)
+        if (a.debug == 2) continue;
         const long long rbase = row0 + 4 * (lane >> 5);
         if (a.metric == LVS_METRIC_L2) {
 #pragma unroll
@@ -208,6 +249,7 @@ hipError_t lvs_stream_launch(LvsStreamArgs& a, hipStream_t stream) {
     const int64_t nblocks = (a.nb + 31) / 32;
     const int wgs = lvs_stream_blocks(a.nb);
     a.blocks_per_wg = (int)((nblocks + wgs - 1) / wgs);
+    a.debug = getenv("LVS_STREAM_DEBUG") ? atoi(getenv("LVS_STREAM_DEBUG")) : 0;
     const int grid = (int)((nblocks + a.blocks_per_wg - 1) / a.blocks_per_wg);
     const size_t lds = (size_t)a.nbfrag * 1024 + SQ * KCAP * 8 + SQ * 4;
     static size_t attr_bytes = 0;

@@ -87,6 +87,7 @@ struct LvsStreamArgs {
     int seg_b[3];            // first B-fragment index of each K segment (segments sharing query columns share fragments)
     int nbfrag;              // B fragments held in LDS
     int blocks_per_wg;       // 32-row blocks per workgroup (contiguous)
+    int debug;               // tuning aid (env LVS_STREAM_DEBUG): 1 no MFMA / B reads, 2 no block epilogue - timing only
 };
 
 int lvs_stream_blocks(int64_t nb);
