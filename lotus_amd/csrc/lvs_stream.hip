@@ -112,10 +112,20 @@ __global__ __launch_bounds__(WAVES * 64, 2) void lvs_stream_kernel(const LvsStre
         }  // else: padding step, repeat the last fragment
         return v;
     };
+    // the common shape (one K segment: fp16 rows; fragment count a multiple of UNROLL: d = 512, 768, 1024, ...) has a
+    // branch-free inner loop: the 16 loads of an iteration share one base pointer (the same block 16 fragments on, or
+    // the next block's first 16) and differ by immediate offsets, like the 16 B-fragment reads
+    const bool simple = a.nseg == 1 && nj % UNROLL == 0 && segc0 == 0 && segb0 == 0;
     half8 abuf[UNROLL];
     if (b0 + wave < b1) {
+        if (simple) {
+            const _Float16* p0 = row_ptr(b0 + wave);
 #pragma unroll
-        for (int u = 0; u < UNROLL; ++u) abuf[u] = next_load();
+            for (int u = 0; u < UNROLL; ++u) abuf[u] = *(const half8*)(p0 + u * 16);
+        } else {
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) abuf[u] = next_load();
+        }
     }
 
     for (long long blk = b0 + wave; blk < b1; blk += WAVES) {
@@ -123,15 +133,31 @@ __global__ __launch_bounds__(WAVES * 64, 2) void lvs_stream_kernel(const LvsStre
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        if (simple) {
+            const _Float16* ap_cur = row_ptr(blk);
+            const _Float16* ap_nxt = row_ptr(blk + WAVES < b1 ? blk + WAVES : blk);
+            for (int j0 = 0; j0 < nj; j0 += UNROLL) {
+                const _Float16* nsrc = j0 + UNROLL < nj ? ap_cur + (j0 + UNROLL) * 16 : ap_nxt;
+                const half8* bsrc = bfrag + (long long)j0 * 64 + lane;
+#pragma unroll
+                for (int u = 0; u < UNROLL; ++u) {
+                    const half8 av = abuf[u];
+                    abuf[u] = *(const half8*)(nsrc + u * 16);
+                    if (a.debug == 1) {
+                        acc[0] += (float)av[0];
+                    } else {
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bsrc[u * 64], acc, 0, 0, 0);
+                    }
+                }
+            }
+        } else {
         int c_seg = 0, c_jj = 0, c_b = segb0;  // compute stream: B fragment index c_b = seg_b[c_seg] + c_jj
         for (int j0 = 0; j0 < njp; j0 += UNROLL) {
 #pragma unroll
             for (int u = 0; u < UNROLL; ++u) {
                 const half8 av = abuf[u];
                 abuf[u] = next_load();  // the fragment UNROLL steps ahead (possibly of the next block)
-                if (a.debug == 1) {
-                    acc[0] += (float)av[0];
-                } else if (j0 + u < nj) {
+                if (j0 + u < nj) {
                     const half8 bv = bfrag[c_b * 64 + lane];
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bv, acc, 0, 0, 0);
                     if (++c_jj == jper) {
@@ -143,6 +169,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void lvs_stream_kernel(const LvsStre
                     }
                 }
             }
+        }
         }
         // ---- block epilogue: 32 rows x 32 queries; lane holds query q, rows row0 + (r&3) + 8*(r>>2) + 4*(lane>>5)
         if (a.debug == 2) continue;
