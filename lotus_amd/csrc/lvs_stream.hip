@@ -112,14 +112,15 @@ __global__ __launch_bounds__(WAVES * 64, 2) void lvs_stream_kernel(const LvsStre
         }  // else: padding step, repeat the last fragment
         return v;
     };
-    // the common shape (one K segment: fp16 rows; fragment count a multiple of UNROLL: d = 512, 768, 1024, ...) has a
-    // branch-free inner loop: the 16 loads of an iteration share one base pointer (the same block 16 fragments on, or
-    // the next block's first 16) and differ by immediate offsets, like the 16 B-fragment reads
-    const bool simple = a.nseg == 1 && nj % UNROLL == 0 && segc0 == 0 && segb0 == 0;
+    // the common shapes (fragments per K segment a multiple of UNROLL: d = 256, 512, 768, 1024, ..., fp16 or hi|lo rows)
+    // have a branch-free inner loop: a block is 1..3 runs of jper contiguous fragments, the 16 loads of an iteration
+    // share one base pointer (the same run 16 fragments on, the next run's start, or the next block's first run) and
+    // differ by immediate offsets, like the 16 B-fragment reads
+    const bool simple = jper % UNROLL == 0;
     half8 abuf[UNROLL];
     if (b0 + wave < b1) {
         if (simple) {
-            const _Float16* p0 = row_ptr(b0 + wave);
+            const _Float16* p0 = row_ptr(b0 + wave) + segc0;
 #pragma unroll
             for (int u = 0; u < UNROLL; ++u) abuf[u] = *(const half8*)(p0 + u * 16);
         } else {
@@ -135,18 +136,23 @@ __global__ __launch_bounds__(WAVES * 64, 2) void lvs_stream_kernel(const LvsStre
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
         if (simple) {
             const _Float16* ap_cur = row_ptr(blk);
-            const _Float16* ap_nxt = row_ptr(blk + WAVES < b1 ? blk + WAVES : blk);
-            for (int j0 = 0; j0 < nj; j0 += UNROLL) {
-                const _Float16* nsrc = j0 + UNROLL < nj ? ap_cur + (j0 + UNROLL) * 16 : ap_nxt;
-                const half8* bsrc = bfrag + (long long)j0 * 64 + lane;
+            const _Float16* ap_nxt = row_ptr(blk + WAVES < b1 ? blk + WAVES : blk) + segc0;
+            for (int run = 0; run < a.nseg; ++run) {
+                const int c_off = run == 0 ? segc0 : (run == 1 ? segc1 : segc2);
+                const int b_off = run == 0 ? segb0 : (run == 1 ? segb1 : segb2);
+                const _Float16* run_next = run + 1 < a.nseg ? ap_cur + (run == 0 ? segc1 : segc2) : ap_nxt;
+                for (int j0 = 0; j0 < jper; j0 += UNROLL) {
+                    const _Float16* nsrc = j0 + UNROLL < jper ? ap_cur + c_off + (j0 + UNROLL) * 16 : run_next;
+                    const half8* bsrc = bfrag + (long long)(b_off + j0) * 64 + lane;
 #pragma unroll
-                for (int u = 0; u < UNROLL; ++u) {
-                    const half8 av = abuf[u];
-                    abuf[u] = *(const half8*)(nsrc + u * 16);
-                    if (a.debug == 1) {
-                        acc[0] += (float)av[0];
-                    } else {
-                        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bsrc[u * 64], acc, 0, 0, 0);
+                    for (int u = 0; u < UNROLL; ++u) {
+                        const half8 av = abuf[u];
+                        abuf[u] = *(const half8*)(nsrc + u * 16);
+                        if (a.debug == 1) {
+                            acc[0] += (float)av[0];
+                        } else {
+                            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bsrc[u * 64], acc, 0, 0, 0);
+                        }
                     }
                 }
             }
