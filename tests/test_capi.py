@@ -60,3 +60,23 @@ def test_no_product_module_imports_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 text = open(os.path.join(dirpath, f)).read()
                 assert "import oracle" not in text and "from oracle" not in text, f
+
+
+def test_workspace_sizes_cover_every_routing_decision():
+    """`lvs_flat_search_workspace_bytes` is pure host arithmetic: it must accept every shape the search accepts and be
+    large enough for the path the search will take (k <= 15, 16..56, and the two-phase path beyond 56, whose lists and
+    buckets dominate)."""
+    lib = _capi.load()
+    f = lib.lvs_flat_search_workspace_bytes
+    base = f(100_000, 1_000_000, 768, 10)
+    assert base > 100_000 * 4 + 11 * 100_000 * 10 * 8 // 2  # thresholds + per-slab candidate lists
+    assert f(100_000, 1_000_000, 768, 24) > 0 and f(100_000, 1_000_000, 768, 56) > 0
+    big = f(100_000, 1_000_000, 768, 100)
+    # two-phase: >= 2k/15 slabs x 15 keys per query of lists + a 512-slot bucket per query, 8 B each
+    assert big >= 100_000 * (14 * 15 + 512) * 8
+    assert f(100_000, 1_000_000, 768, 2048) >= 100_000 * 4096 * 8
+    assert f(1, 1_000_000, 768, 1000) < 1 << 30          # one query: small
+    assert f(0, 1000, 64, 5) >= 0 and f(10, 0, 64, 5) >= 0  # empty sides are legal
+    assert f(10, 1000, 0, 5) < 0 and f(10, 1000, 64, -1) < 0  # bad shapes are refused
+    # beyond 24 GB the two-phase path is not planned: the call falls back to selection passes and their small workspace
+    assert f(4_000_000, 1_000_000, 768, 2048) < 24 << 30
