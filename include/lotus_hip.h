@@ -9,8 +9,11 @@
  *   - every function returns int32 status: LVS_OK (0) or a negative LVS_E*; lvs_last_error() gives the
  *     thread-local message of the last failure.
  *   - all data pointers are DEVICE pointers (HBM) unless the name ends in _host; the caller owns every buffer;
- *     the library allocates nothing and keeps no pointer after a call returns (work is enqueued on `stream`,
- *     a hipStream_t passed as void*, NULL = default stream).
+ *     the library allocates nothing, keeps no pointer after a call returns and never synchronises: work is only
+ *     enqueued on `stream` (a hipStream_t passed as void*, NULL = default stream).  The stream's device is made
+ *     current for the duration of a call, so one process may drive several GPUs.
+ *   - the library reads no environment variable.  (A separate tuning build, `make -C lotus_amd/csrc tuning`, compiles
+ *     the LVS_* tuning/ablation knobs in; lvs_build_flags() tells the two apart.)
  *   - "rows" matrices are the library's device layout produced by lvs_pack_rows(): fp16, row-major, leading
  *     dimension lvs_packed_ld(d, mode) halfs.
  *   - result keys: one uint64 per (query, rank): ord32(score where larger = better) << 32 | (0xFFFFFFFF - id);
@@ -26,7 +29,7 @@
 extern "C" {
 #endif
 
-#define LVS_ABI_VERSION 1
+#define LVS_ABI_VERSION 2 /* 2: pack modes in lvs_flat_search_workspace_bytes, lvs_build_flags, k-means device update */
 
 #define LVS_OK 0
 #define LVS_EINVAL (-1)   /* bad argument */
@@ -53,6 +56,10 @@ extern "C" {
 
 int32_t lvs_abi_version(void);
 const char* lvs_last_error(void);
+/* bit set of LVS_BUILD_*: 0 for the shipped library */
+#define LVS_BUILD_TUNING 1       /* environment-variable tuning / ablation knobs compiled in (results may be wrong) */
+#define LVS_BUILD_COUNT_EVENTS 2 /* slow-path event counters compiled into the tile kernel */
+int32_t lvs_build_flags(void);
 
 /* Device discovery (no reference counterpart; the reference is CPU-only). */
 int32_t lvs_device_count(int32_t* out_count);
@@ -73,19 +80,23 @@ int32_t lvs_gather_f32(const float* src, const int64_t* ids, int64_t n_ids, floa
 
 /* ---- exact top-k search: replaces faiss `IndexFlat::search` behind `index.search(query_vectors, K)`
  * (faiss_vs.py:67,75) - tiled MFMA distance + fused per-query top-k. ---- */
-/* bytes of scratch lvs_flat_search_keys needs for this problem */
-int64_t lvs_flat_search_workspace_bytes(int64_t nq, int64_t nb, int32_t d, int32_t k);
+/* bytes of scratch lvs_flat_search_keys needs for this problem (same shape and pack modes as the search call) */
+int64_t lvs_flat_search_workspace_bytes(int64_t nq, int64_t nb, int32_t d, int32_t k, int32_t xb_pack,
+                                        int32_t xq_pack);
 /* xb: [nb][ld(xb_pack)] packed corpus shard, xq: [nq][ld(xq_pack)] packed queries; the two sides may use
  * different pack modes (e.g. fp16 points against fp32-accurate centroids).
  * xb_norms_sq / xq_norms_sq: |.|^2 per row, required for LVS_METRIC_L2, ignored for IP.
  * id_offset: global id of shard row 0 (keys carry global ids < 2^32).
  * row_ids (nullable): [nb] uint32 - id to report for each shard row instead of id_offset + row (subset search).
- * out_keys: [nq][k] uint64, best first. */
+ * out_keys: [nq][k] uint64, best first.
+ * k > 56 runs two corpus passes (per-slab lists -> threshold key -> collect -> sort); should a candidate bucket
+ * overflow (mass ties), ceil(k/56) selection passes follow, predicated on a device-side flag - no host round trip. */
 int32_t lvs_flat_search_keys(const void* xb, int32_t xb_pack, int64_t nb, const void* xq, int32_t xq_pack, int64_t nq,
                              int32_t d, int32_t metric, int32_t k, const float* xb_norms_sq, const float* xq_norms_sq,
                              int64_t id_offset, const uint32_t* row_ids, uint64_t* out_keys, void* workspace,
                              int64_t workspace_bytes, void* stream);
-/* Merge `nparts` candidate lists (e.g. the all-gathered per-shard lists): parts [nparts][nq][k] -> out [nq][k]. */
+/* Merge `nparts` candidate lists (e.g. the all-gathered per-shard lists): parts [nparts][nq][k] -> out [nq][k].
+ * Any nparts >= 1 and k <= LVS_MAX_K (long lists are folded in rounds of at most 4096 keys per query). */
 int32_t lvs_merge_keys(const uint64_t* parts, int32_t nparts, int64_t nq, int32_t k, uint64_t* out_keys,
                        void* stream);
 /* keys -> faiss-shaped result (faiss_vs.py:67,75 return values): D float32 [nq][k], I int64 [nq][k];
@@ -109,7 +120,7 @@ int32_t lvs_sort_rows_desc(const float* scores, int64_t nq, int64_t nb, int64_t 
  * materialises N^2 results in the reference.  Emits (query, corpus row id, score) for every score STRICTLY greater
  * than `threshold` (for L2 the score is minus the squared distance).  q_row0 >= 0 selects the self-join: query r is
  * corpus row q_row0 + r and only pairs with id > q_row0 + r are kept (each unordered pair once), tiles below the
- * diagonal are skipped.  qt_stride / qt_phase deal 128-query tiles round-robin to ranks (multi-GPU, corpus replicated).
+ * diagonal are skipped.  qt_stride / qt_phase deal 256-query tiles round-robin to ranks (multi-GPU, corpus replicated).
  * out_count (device uint64, zeroed by the caller) receives the number of qualifying pairs; pairs beyond `capacity`
  * are counted but not stored, so a caller can size the buffers and run again.  Pair order is unspecified. ---- */
 int32_t lvs_range_join(const void* xb, int32_t xb_pack, int64_t nb, const void* xq, int32_t xq_pack, int64_t nq,

@@ -17,6 +17,8 @@ DTYPE_F32, DTYPE_F16 = 0, 1
 METRIC_IP, METRIC_L2 = 0, 1
 PACK_F16, PACK_SPLIT = 0, 1
 MAX_K = 2048
+ABI_VERSION = 2
+BUILD_TUNING, BUILD_COUNT_EVENTS = 1, 2
 
 _i32, _i64, _vp, _dbl = ctypes.c_int32, ctypes.c_int64, ctypes.c_void_p, ctypes.c_double
 
@@ -24,13 +26,14 @@ _i32, _i64, _vp, _dbl = ctypes.c_int32, ctypes.c_int64, ctypes.c_void_p, ctypes.
 SIGNATURES = {
     "lvs_abi_version": (_i32, []),
     "lvs_last_error": (ctypes.c_char_p, []),
+    "lvs_build_flags": (_i32, []),
     "lvs_device_count": (_i32, [ctypes.POINTER(_i32)]),
     "lvs_device_info": (_i32, [_i32, ctypes.c_char_p, _i32, ctypes.POINTER(_i32), ctypes.POINTER(_i64)]),
     "lvs_packed_ld": (_i32, [_i32, _i32]),
     "lvs_pack_rows": (_i32, [_vp, _i32, _i64, _i32, _i32, _i32, _vp, _vp, _vp]),
     "lvs_gather_rows": (_i32, [_vp, _i32, _vp, _i64, _vp, _vp]),
     "lvs_gather_f32": (_i32, [_vp, _vp, _i64, _vp, _vp]),
-    "lvs_flat_search_workspace_bytes": (_i64, [_i64, _i64, _i32, _i32]),
+    "lvs_flat_search_workspace_bytes": (_i64, [_i64, _i64, _i32, _i32, _i32, _i32]),
     "lvs_flat_search_keys": (_i32, [_vp, _i32, _i64, _vp, _i32, _i64, _i32, _i32, _i32, _vp, _vp, _i64, _vp, _vp,
                                     _vp, _i64, _vp]),
     "lvs_merge_keys": (_i32, [_vp, _i32, _i64, _i32, _vp, _vp]),
@@ -64,14 +67,19 @@ def declared_symbols() -> list[str]:
     return sorted(set(re.findall(r"\b(lvs_[a-z0-9_]+)\s*\(", text)))
 
 
-def load():
-    """dlopen the library and bind every declared symbol.  Raises if the library is missing."""
+def load(path: str | None = None):
+    """dlopen the library and bind every declared symbol.  Raises if the library is missing.
+
+    ``path`` selects another build explicitly (development: the ``make tuning`` library with the LVS_* knobs); the
+    default library must be the shipped build - one that reports tuning knobs is refused."""
     global _lib
-    if _lib is not None:
+    if _lib is not None and path is None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    explicit = path is not None
+    path = path or LIB_PATH
+    if not os.path.exists(path):
         raise LotusHipError(
-            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950). lotus_amd has no CPU fallback.")
     # PyTorch-ROCm wheels bundle their own libamdhip64.so.  The device buffers and streams this library receives come
     # from torch, so both must share ONE HIP runtime: load torch's first, then our NEEDED libamdhip64.so.7 resolves to
@@ -81,13 +89,15 @@ def load():
         import torch  # noqa: F401
     except Exception:  # symbol checks still work without torch
         pass
-    lib = ctypes.CDLL(LIB_PATH)
+    lib = ctypes.CDLL(path)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    if lib.lvs_abi_version() != 1:
-        raise LotusHipError(f"ABI version mismatch: library reports {lib.lvs_abi_version()}")
+    if lib.lvs_abi_version() != ABI_VERSION:
+        raise LotusHipError(f"ABI version mismatch: library reports {lib.lvs_abi_version()}, binding is {ABI_VERSION}")
+    if (lib.lvs_build_flags() & BUILD_TUNING) and not explicit:
+        raise LotusHipError(f"{path} is a tuning build (environment knobs that can corrupt results); rebuild with `make`")
     _lib = lib
     return lib
 

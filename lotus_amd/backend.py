@@ -104,7 +104,7 @@ class HipBackend:
         if corpus.d != queries.d:
             raise ValueError("corpus / query dimension mismatch")
         keys = torch.empty((queries.n, k), dtype=torch.int64, device=self.device)
-        need = int(self.lib.lvs_flat_search_workspace_bytes(queries.n, corpus.n, corpus.d, k))
+        need = int(self.lib.lvs_flat_search_workspace_bytes(queries.n, corpus.n, corpus.d, k, corpus.mode, queries.mode))
         if need < 0:
             raise LotusHipError("lvs_flat_search_workspace_bytes rejected the shape")
         ws = self._workspace(need)

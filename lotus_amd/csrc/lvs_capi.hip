@@ -25,6 +25,16 @@ void lvs_set_error(const char* fmt, ...) {
 
 extern "C" const char* lvs_last_error(void) { return g_err; }
 extern "C" int32_t lvs_abi_version(void) { return LVS_ABI_VERSION; }
+extern "C" int32_t lvs_build_flags(void) {
+    int32_t f = 0;
+#ifdef LVS_TUNING
+    f |= LVS_BUILD_TUNING;
+#endif
+#ifdef LVS_COUNT_EVENTS
+    f |= LVS_BUILD_COUNT_EVENTS;
+#endif
+    return f;
+}
 
 extern "C" int32_t lvs_device_count(int32_t* out_count) {
     LVS_REQUIRE(out_count, "out_count is NULL");
@@ -272,7 +282,9 @@ __global__ __launch_bounds__(256) void merge_top1_kernel(const u64* __restrict__
 
 // one wave per query: merge nparts sorted-or-not candidate lists of k keys into the best k (k <= 64)
 __global__ __launch_bounds__(256) void merge_keys_kernel(const u64* __restrict__ parts, int nparts, long long nq, int k,
-                                                         u64* __restrict__ out, long long out_ld) {
+                                                         u64* __restrict__ out, long long out_ld,
+                                                         const uint32_t* __restrict__ pred) {
+    if (pred && *pred == 0u) return;  // predicated launch, see lvs_flat_search_keys
     const int lane = threadIdx.x & 63;
     const long long q = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (q >= nq) return;
@@ -325,6 +337,7 @@ extern "C" int32_t lvs_pack_rows(const void* src, int32_t src_dtype, int64_t n, 
     if (n == 0) return LVS_OK;
     LVS_REQUIRE(src && dst, "NULL buffer");
     const int dpad = (int)lvs_round_up(d, LVS_BK);
+    LVS_DEVICE_GUARD(stream);
     dim3 block(256), grid((unsigned)lvs_ceil_div(n, 4));
     hipStream_t st = (hipStream_t)stream;
     const bool split = pack_mode == LVS_PACK_SPLIT;
@@ -357,6 +370,7 @@ extern "C" int32_t lvs_gather_rows(const void* src, int32_t ld, const int64_t* i
     LVS_REQUIRE(ld > 0 && ld % 8 == 0, "ld must be a positive multiple of 8 halfs");
     if (n_ids == 0) return LVS_OK;
     LVS_REQUIRE(src && ids && dst && n_ids > 0, "bad arguments");
+    LVS_DEVICE_GUARD(stream);
     long long ld16 = ld / 8;
     long long total = n_ids * ld16;
     unsigned grid = (unsigned)(lvs_ceil_div(total, 256) < 16384 ? lvs_ceil_div(total, 256) : 16384);
@@ -369,6 +383,7 @@ extern "C" int32_t lvs_gather_rows(const void* src, int32_t ld, const int64_t* i
 extern "C" int32_t lvs_gather_f32(const float* src, const int64_t* ids, int64_t n_ids, float* dst, void* stream) {
     if (n_ids == 0) return LVS_OK;
     LVS_REQUIRE(src && ids && dst && n_ids > 0, "bad arguments");
+    LVS_DEVICE_GUARD(stream);
     hipLaunchKernelGGL(gather_f32_kernel, dim3((unsigned)lvs_ceil_div(n_ids, 256)), dim3(256), 0,
                        (hipStream_t)stream, src, (const long long*)ids, (long long)n_ids, dst);
     LVS_HIP_CHECK(hipGetLastError());
@@ -414,7 +429,7 @@ int make_plan(int64_t nq, int64_t nb, int32_t d, int32_t xb_pack, int32_t xq_pac
     // geometry: 256 queries per tile with 15 list slots (k <= 15 and every non-top-k mode), else 128 queries / 56 slots
     p.v2 = force_v2 || k <= LVS2_KCAP;
     // a single, at most half-full query tile: the 128-query geometry does half the (padding) MFMA work
-    if (!force_v2 && k > 1 && nq <= LVS3_BQ && !(getenv("LVS_SMALLQ") && atoi(getenv("LVS_SMALLQ")) == 0)) p.v2 = 0;
+    if (!force_v2 && k > 1 && nq <= LVS3_BQ && lvs_tune("LVS_SMALLQ", 1) != 0) p.v2 = 0;
     p.nqt = (int)lvs_ceil_div(nq > 0 ? nq : 1, p.v2 ? LVS2_BQ : LVS3_BQ);
     // XCD group = gq query tiles x (32 / gq) slabs resident on one XCD at a time.  Wide groups (one corpus stream per
     // XCD) are fastest (profiles/r01_tuning.md) but must be full: groups are dealt round-robin to the 8 XCDs, so a
@@ -436,14 +451,14 @@ int make_plan(int64_t nq, int64_t nb, int32_t d, int32_t xb_pack, int32_t xq_pac
     int64_t slabs_l2 = 0;
     if (p.v2 && p.gq > 8 && p.nqt >= 64 && min_slabs == 0) {
         const int64_t n8 = lvs_round_up(want > 20 ? want : 20, 4);
-        const int64_t min_tiles = getenv("LVS_L2_MIN_TILES") ? atoll(getenv("LVS_L2_MIN_TILES")) : 160;  // tuning override
+        const int64_t min_tiles = lvs_tune("LVS_L2_MIN_TILES", 160);
         if (p.ntiles / n8 >= min_tiles) {
             p.gq = 8;
             slabs_l2 = n8;
         }
     }
-    if (const char* e = getenv("LVS_GQ")) {
-        int v = atoi(e);
+    if (lvs_tune_set("LVS_GQ")) {  // -DLVS_TUNING builds only
+        const int v = (int)lvs_tune("LVS_GQ", 0);
         if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16 || v == 32) {
             p.gq = v;
             slabs_l2 = 0;
@@ -459,7 +474,7 @@ int make_plan(int64_t nq, int64_t nb, int32_t d, int32_t xb_pack, int32_t xq_pac
     if (s < 1) s = 1;
     p.lead_slabs = 0;
     if (slabs_l2 > 0) {  // one leading slab per query tile in wide groups + slabs_l2 slabs in the narrow groups
-        p.lead_slabs = getenv("LVS_LEAD") ? (atoi(getenv("LVS_LEAD")) != 0) : 1;
+        p.lead_slabs = lvs_tune("LVS_LEAD", 1) != 0;
         s = slabs_l2 + p.lead_slabs;
     }
     if (min_slabs > 0 && s < min_slabs) {  // the caller needs at least this many per-slab candidate lists
@@ -467,15 +482,15 @@ int make_plan(int64_t nq, int64_t nb, int32_t d, int32_t xb_pack, int32_t xq_pac
         if (s > p.ntiles) s = p.ntiles;
     }
     if (max_slabs_cap > 0 && s > max_slabs_cap) s = max_slabs_cap;  // ... and at most this many
-    if (const char* e = getenv("LVS_NSLAB")) {  // tuning override
-        int64_t v = atoll(e);
+    if (lvs_tune_set("LVS_NSLAB")) {  // -DLVS_TUNING builds only
+        const int64_t v = lvs_tune("LVS_NSLAB", 0);
         if (v >= 1 && v <= p.ntiles) s = v;
     }
     p.tiles_per_slab = (int)lvs_ceil_div(p.ntiles, s);
     p.nslab = (int)lvs_ceil_div(p.ntiles, p.tiles_per_slab);
     p.kpass = k < LVS_KPASS ? (k > 0 ? k : 1) : LVS_KPASS;  // k <= 15 -> one pass on the 256-query geometry
     p.npass = k > 0 ? (int)lvs_ceil_div(k, p.kpass) : 0;
-    int64_t off = 0;
+    int64_t off = 256;  // the first 256 bytes hold status words (the large-k overflow flag) in every layout
     p.off_gtau = off;
     off += lvs_round_up(nq * 4, 256);
     p.off_partial = off;
@@ -552,6 +567,56 @@ hipError_t launch_select(const u64* src, long long stride_q, int inner, long lon
     return hipGetLastError();
 }
 
+// One workgroup per query: out[q][0..k) = the k largest of {acc[q][0..k) if acc} U {parts[p][q][0..k) : p0 <= p < p0 + np}
+// (bitonic sort of P2 >= (np + (acc != 0)) * k slots in LDS).  acc may alias out: every input of the query is in LDS
+// before the first result is written.
+__global__ __launch_bounds__(256) void merge_long_kernel(const u64* __restrict__ parts, int p0, int np,
+                                                         const u64* acc, long long nq, int k, int P2, u64* out) {
+    extern __shared__ __attribute__((aligned(16))) char sel_smem[];
+    u64* sk = (u64*)sel_smem;
+    const long long q = blockIdx.x;
+    const int nacc = acc ? k : 0;
+    const int n = nacc + np * k;
+    for (int i = threadIdx.x; i < P2; i += 256) {
+        u64 v = 0;
+        if (i < nacc) {
+            v = acc[q * k + i];
+        } else if (i < n) {
+            const int c = i - nacc, p = c / k, j = c - p * k;
+            v = parts[((long long)(p0 + p) * nq + q) * k + j];
+        }
+        sk[i] = v;
+    }
+    __syncthreads();
+    for (int size = 2; size <= P2; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int i = threadIdx.x; i < P2; i += 256) {
+                const int j = i ^ stride;
+                if (j > i) {
+                    const bool desc = (i & size) == 0;
+                    const u64 x = sk[i], y = sk[j];
+                    if ((x < y) == desc) {
+                        sk[i] = y;
+                        sk[j] = x;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (int j = threadIdx.x; j < k; j += 256) out[q * k + j] = sk[j];
+}
+
+hipError_t launch_merge_long(const u64* parts, int p0, int np, const u64* acc, int64_t nq, int k, u64* out,
+                             hipStream_t st) {
+    const int n = (np + (acc ? 1 : 0)) * k;
+    const int P2 = pow2_ceil(n < 2 ? 2 : n);
+    if (P2 > LVS_SELECT_MAX) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(merge_long_kernel, dim3((unsigned)nq), dim3(256), (size_t)P2 * 8, st, parts, p0, np, acc,
+                       (long long)nq, k, P2, out);
+    return hipGetLastError();
+}
+
 // ---- large k in two phases (k > LVS_KPASS) ----------------------------------------------------------------------
 // Phase A is a 15-per-slab top-k pass with at least 3k/15 slabs that do NOT share thresholds, so every slab's list is
 // its own exact top 15.  The lists hold 15 * nslab DISTINCT rows,
@@ -565,18 +630,17 @@ struct TwoPhasePlan {
     Plan b;             // phase B (collect) geometry: always 256 x 256
     int slots;          // list slots per (query, slab) in phase A
     int capacity;       // bucket slots per query
-    int64_t off_thr, off_cnt, off_flag, off_bucket, total;
+    int64_t off_thr, off_cnt, off_bucket, total;
 };
 
 bool make_two_phase_plan(int64_t nq, int64_t nb, int32_t d, int32_t xb_pack, int32_t xq_pack, int32_t k,
                          TwoPhasePlan& tp) {
     if (k <= LVS_KPASS || nq <= 0 || nb <= 0) return false;
-    if (const char* e = getenv("LVS_TWO_PHASE"))
-        if (atoi(e) == 0) return false;
+    if (lvs_tune("LVS_TWO_PHASE", 1) == 0) return false;
     // 15-slot lists on the fast geometry beat 56-slot lists on the 128-query geometry at every k tried (100 .. 1000:
     // 329 vs 402 ms, 545 vs 607 ms at 100 k x 1 M), although they need four times the slabs
     tp.slots = LVS2_KCAP;
-    if (const char* e = getenv("LVS_TWO_PHASE_SLOTS")) tp.slots = atoi(e) == LVS3_KCAP ? LVS3_KCAP : LVS2_KCAP;  // tuning
+    if (lvs_tune("LVS_TWO_PHASE_SLOTS", LVS2_KCAP) == LVS3_KCAP) tp.slots = LVS3_KCAP;
     const int64_t cap_slabs = LVS_SELECT_MAX / tp.slots;        // the selection kernel sorts at most 4096 keys per query
     int64_t want_slabs = lvs_ceil_div(2ll * k, tp.slots);       // ~2k candidates: a tight bound at a moderate slab count
     if (want_slabs > cap_slabs) want_slabs = cap_slabs;
@@ -593,8 +657,6 @@ bool make_two_phase_plan(int64_t nq, int64_t nb, int32_t d, int32_t xb_pack, int
     off += lvs_round_up(nq * 8, 256);
     tp.off_cnt = off;
     off += lvs_round_up(nq * 4, 256);
-    tp.off_flag = off;
-    off += 256;
     tp.off_bucket = off;
     off += lvs_round_up(nq * (int64_t)tp.capacity * 8, 256);
     tp.total = off;
@@ -603,7 +665,8 @@ bool make_two_phase_plan(int64_t nq, int64_t nb, int32_t d, int32_t xb_pack, int
 }
 
 __global__ void copy_pass_kernel(const u64* __restrict__ src, long long nq, int kp, u64* __restrict__ dst, int k,
-                                 int col0) {
+                                 int col0, const uint32_t* __restrict__ pred) {
+    if (pred && *pred == 0u) return;
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nq * kp) return;
     long long q = i / kp;
@@ -612,11 +675,12 @@ __global__ void copy_pass_kernel(const u64* __restrict__ src, long long nq, int 
 }
 }  // namespace
 
-extern "C" int64_t lvs_flat_search_workspace_bytes(int64_t nq, int64_t nb, int32_t d, int32_t k) {
+extern "C" int64_t lvs_flat_search_workspace_bytes(int64_t nq, int64_t nb, int32_t d, int32_t k, int32_t xb_pack,
+                                                   int32_t xq_pack) {
     Plan p;
-    if (make_plan(nq, nb, d, LVS_PACK_F16, LVS_PACK_F16, k, p) != LVS_OK) return LVS_EINVAL;
+    if (make_plan(nq, nb, d, xb_pack, xq_pack, k, p) != LVS_OK) return LVS_EINVAL;
     TwoPhasePlan tp;
-    if (make_two_phase_plan(nq, nb, d, LVS_PACK_F16, LVS_PACK_F16, k, tp) && tp.total > p.total) return tp.total;
+    if (make_two_phase_plan(nq, nb, d, xb_pack, xq_pack, k, tp) && tp.total > p.total) return tp.total;
     return p.total;
 }
 
@@ -632,6 +696,7 @@ extern "C" int32_t lvs_flat_search_keys(const void* xb, int32_t xb_pack, int64_t
     LVS_REQUIRE(id_offset >= 0 && id_offset + nb < 0xFFFFFFFFll, "ids must stay below 2^32-1");
     if (nq == 0 || k == 0) return LVS_OK;
     LVS_REQUIRE(out_keys, "out_keys is NULL");
+    LVS_DEVICE_GUARD(stream);
     hipStream_t st = (hipStream_t)stream;
     if (nb == 0) {
         LVS_HIP_CHECK(hipMemsetAsync(out_keys, 0, (size_t)nq * k * 8, st));
@@ -677,10 +742,13 @@ extern "C" int32_t lvs_flat_search_keys(const void* xb, int32_t xb_pack, int64_t
         a.bq = pl.v2 ? LVS2_BQ : LVS3_BQ;
         a.gq = pl.gq;
         a.lead_slabs = pl.lead_slabs;
-        a.debug_hot = getenv("LVS_DEBUG_HOT") ? atoi(getenv("LVS_DEBUG_HOT")) : 0;
+        a.debug_hot = (int)lvs_tune("LVS_DEBUG_HOT", 0);
     };
 
-    // ---- k > LVS_KPASS: two corpus passes whatever k is (see make_two_phase_plan); on bucket overflow fall through ----
+    // ---- k > LVS_KPASS: two corpus passes whatever k is (see make_two_phase_plan).  A bucket overflow (mass ties, or
+    // the top k clustered in one slab) sets a device-side flag; the selection passes below then run PREDICATED on that
+    // flag (their kernels return at once when it is clear), so the call never synchronises the stream. ----
+    const uint32_t* pred = nullptr;
     {
         TwoPhasePlan tp;
         if (make_two_phase_plan(nq, nb, d, xb_pack, xq_pack, k, tp) && tp.total <= workspace_bytes) {
@@ -688,7 +756,7 @@ extern "C" int32_t lvs_flat_search_keys(const void* xb, int32_t xb_pack, int64_t
             u64* lists = (u64*)(ws + tp.a.off_partial);          // [nslab][nq][slots]
             u64* thr = (u64*)(ws + tp.off_thr);                  // [nq]
             uint32_t* cnt = (uint32_t*)(ws + tp.off_cnt);        // [nq]
-            uint32_t* flag = (uint32_t*)(ws + tp.off_flag);
+            uint32_t* flag = (uint32_t*)ws;                      // status word 0: some bucket overflowed
             u64* bucket = (u64*)(ws + tp.off_bucket);            // [nq][capacity]
             LvsTileArgs ta;
             fill_args(ta, tp.a, gtau2, lists);
@@ -714,11 +782,13 @@ extern "C" int32_t lvs_flat_search_keys(const void* xb, int32_t xb_pack, int64_t
             LVS_HIP_CHECK(lvs_tile_launch(LVS_MODE_COLLECT, tb, st));
             LVS_HIP_CHECK(launch_select(bucket, tp.capacity, tp.capacity, 0, tp.capacity, cnt, k, nullptr,
                                         (u64*)out_keys, k, flag, nq, st));
-            uint32_t overflowed = 0;
-            LVS_HIP_CHECK(hipMemcpyAsync(&overflowed, flag, 4, hipMemcpyDeviceToHost, st));
-            LVS_HIP_CHECK(hipStreamSynchronize(st));
-            if (getenv("LVS_TWO_PHASE_DEBUG")) {  // tuning aid
+            pred = flag;
+#ifdef LVS_TUNING
+            if (lvs_tune_set("LVS_TWO_PHASE_DEBUG")) {  // bucket statistics of this call (synchronises)
                 std::vector<uint32_t> h((size_t)nq);
+                uint32_t overflowed = 0;
+                LVS_HIP_CHECK(hipStreamSynchronize(st));
+                LVS_HIP_CHECK(hipMemcpy(&overflowed, flag, 4, hipMemcpyDeviceToHost));
                 LVS_HIP_CHECK(hipMemcpy(h.data(), cnt, (size_t)nq * 4, hipMemcpyDeviceToHost));
                 uint32_t mn = ~0u, mx = 0;
                 double sum = 0;
@@ -729,25 +799,18 @@ extern "C" int32_t lvs_flat_search_keys(const void* xb, int32_t xb_pack, int64_t
                 }
                 fprintf(stderr, "[lvs] two-phase k=%d slots=%d slabs=%d capacity=%d: bucket counts min %u mean %.1f max %u overflow=%u\n",
                         k, tp.slots, tp.a.nslab, tp.capacity, mn, sum / (double)nq, mx, overflowed);
-                std::vector<unsigned long long> ht((size_t)nq);
-                LVS_HIP_CHECK(hipMemcpy(ht.data(), thr, (size_t)nq * 8, hipMemcpyDeviceToHost));
-                int shown = 0;
-                for (int64_t q = 0; q < nq && shown < 24; ++q)
-                    if (h[(size_t)q] > (uint32_t)tp.capacity) {
-                        fprintf(stderr, "[lvs]   q=%lld count=%u thr=%016llx\n", (long long)q, h[(size_t)q], ht[(size_t)q]);
-                        ++shown;
-                    }
             }
-            if (!overflowed) return LVS_OK;
+#endif
         }
     }
 
     LvsTileArgs a;
     fill_args(a, p, gtau, partial);
+    a.pred = pred;
     a.dbg = nullptr;
     unsigned long long* dbg_counters = nullptr;
-#ifdef LVS_COUNT_EVENTS
-    if (getenv("LVS_COUNT") && atoi(getenv("LVS_COUNT"))) {  // tuning aid: count slow-path events of this call
+#if defined(LVS_COUNT_EVENTS) && defined(LVS_TUNING)
+    if (lvs_tune("LVS_COUNT", 0)) {  // tuning build only: count slow-path events of this call (allocates, synchronises)
         LVS_HIP_CHECK(hipMalloc((void**)&dbg_counters, 8 * sizeof(unsigned long long)));
         LVS_HIP_CHECK(hipMemsetAsync(dbg_counters, 0, 8 * sizeof(unsigned long long), st));
         a.dbg = dbg_counters;
@@ -759,8 +822,7 @@ extern "C" int32_t lvs_flat_search_keys(const void* xb, int32_t xb_pack, int64_t
         const int nqseg = xq_pack == LVS_PACK_SPLIT ? 2 : 1;
         const int jper = p.dpad / 16;
         const bool fits = lvs_stream_lds_bytes(nqseg * jper) <= 150 * 1024;
-        const char* env = getenv("LVS_STREAM");
-        const bool want = env ? atoi(env) != 0 : true;
+        const bool want = lvs_tune("LVS_STREAM", 1) != 0;
         if (want && fits && nq <= LVS_STREAM_MAXQ && k <= LVS_KPASS && nb >= 4096) {
             LvsStreamArgs sa;
             memset(&sa, 0, sizeof(sa));
@@ -796,7 +858,7 @@ extern "C" int32_t lvs_flat_search_keys(const void* xb, int32_t xb_pack, int64_t
                 nparts = (int)((nblocks + sa.blocks_per_wg - 1) / sa.blocks_per_wg);
             }
             hipLaunchKernelGGL(merge_keys_kernel, dim3((unsigned)lvs_ceil_div(nq, 4)), dim3(256), 0, st, partial, nparts,
-                               (long long)nq, k, (u64*)out_keys, (long long)k);
+                               (long long)nq, k, (u64*)out_keys, (long long)k, (const uint32_t*)nullptr);
             LVS_HIP_CHECK(hipGetLastError());
             return LVS_OK;
         }
@@ -806,7 +868,7 @@ extern "C" int32_t lvs_flat_search_keys(const void* xb, int32_t xb_pack, int64_t
     // kernel skips almost every block, so k = 1 goes through it like any other k.  Same winner either way
     // (best score, lowest row among equals).
     bool use_top1 = k == 1 && !row_ids && p.tiles_per_slab <= 64;
-    if (const char* e = getenv("LVS_TOP1")) use_top1 = k == 1 && !row_ids && atoi(e) != 0;  // tuning override
+    if (lvs_tune_set("LVS_TOP1")) use_top1 = k == 1 && !row_ids && lvs_tune("LVS_TOP1", 0) != 0;  // -DLVS_TUNING only
     for (int pass = 0; pass < p.npass; ++pass) {
         const int col0 = pass * p.kpass;
         const int kp = (k - col0) < p.kpass ? (k - col0) : p.kpass;
@@ -815,7 +877,9 @@ extern "C" int32_t lvs_flat_search_keys(const void* xb, int32_t xb_pack, int64_t
         a.ub = pass == 0 ? nullptr : (const u64*)out_keys + (col0 - 1);
         a.ub_stride = k;
         LVS_HIP_CHECK(hipMemsetAsync(gtau, 0, (size_t)nq * 4, st));
-        {
+        if (pred) {  // predicated fallback pass: not a measurement of the dominant kernel
+            LVS_HIP_CHECK(lvs_tile_launch(LVS_MODE_TOPK, a, st));
+        } else {
             ScopedKernelTimer timer(st);
             LVS_HIP_CHECK(lvs_tile_launch(use_top1 ? LVS_MODE_TOP1 : LVS_MODE_TOPK, a, st));
         }
@@ -825,13 +889,13 @@ extern "C" int32_t lvs_flat_search_keys(const void* xb, int32_t xb_pack, int64_t
                                p.nslab, (long long)nq, (u64*)out_keys, (long long)k);
         } else if (p.npass == 1) {
             hipLaunchKernelGGL(merge_keys_kernel, mgrid, mblock, 0, st, partial, p.nslab, (long long)nq, kp,
-                               (u64*)out_keys, (long long)k);
+                               (u64*)out_keys, (long long)k, pred);
         } else {
             // the upper bounds of this pass live in out_keys, so merge into a side buffer first
             hipLaunchKernelGGL(merge_keys_kernel, mgrid, mblock, 0, st, partial, p.nslab, (long long)nq, kp, passbuf,
-                               (long long)kp);
+                               (long long)kp, pred);
             hipLaunchKernelGGL(copy_pass_kernel, dim3((unsigned)lvs_ceil_div(nq * kp, 256)), dim3(256), 0, st, passbuf,
-                               (long long)nq, kp, (u64*)out_keys, k, col0);
+                               (long long)nq, kp, (u64*)out_keys, k, col0, pred);
         }
         LVS_HIP_CHECK(hipGetLastError());
     }
@@ -856,15 +920,26 @@ extern "C" int32_t lvs_merge_keys(const uint64_t* parts, int32_t nparts, int64_t
     LVS_REQUIRE(nparts >= 1 && nq >= 0 && k >= 0, "bad arguments");
     if (nq == 0 || k == 0) return LVS_OK;
     LVS_REQUIRE(parts && out_keys, "NULL buffer");
-    if (k > 64) {  // long lists: sort all nparts * k candidates of a query in LDS
-        LVS_REQUIRE((int64_t)nparts * k <= LVS_SELECT_MAX, "lvs_merge_keys: nparts * k = %lld exceeds %d",
-                    (long long)nparts * k, LVS_SELECT_MAX);
-        LVS_HIP_CHECK(launch_select((const u64*)parts, k, k, (long long)nq * k, nparts * k, nullptr, k, nullptr,
-                                    (u64*)out_keys, k, nullptr, nq, (hipStream_t)stream));
+    LVS_REQUIRE(k <= LVS_MAX_K, "k=%d exceeds LVS_MAX_K", k);
+    LVS_DEVICE_GUARD(stream);
+    hipStream_t st = (hipStream_t)stream;
+    if (k > 64) {
+        // long lists: sort the candidates of a query in LDS, at most LVS_SELECT_MAX at a time.  More than that (e.g. 8
+        // shards x k = 1000) is folded in rounds: out = top k of (out U the next group of parts); one workgroup owns a
+        // query and reads everything it needs before it writes, so `out` is updated in place and no scratch is needed.
+        const int per_round0 = LVS_SELECT_MAX / k;            // parts in the first round (>= 2 because k <= 2048)
+        const int per_round = per_round0 - 1;                 // later rounds: one slot goes to the running result
+        int done = nparts < per_round0 ? nparts : per_round0;
+        LVS_HIP_CHECK(launch_merge_long((const u64*)parts, 0, done, nullptr, nq, k, (u64*)out_keys, st));
+        while (done < nparts) {
+            const int take = nparts - done < per_round ? nparts - done : per_round;
+            LVS_HIP_CHECK(launch_merge_long((const u64*)parts, done, take, (const u64*)out_keys, nq, k, (u64*)out_keys, st));
+            done += take;
+        }
         return LVS_OK;
     }
-    hipLaunchKernelGGL(merge_keys_kernel, dim3((unsigned)lvs_ceil_div(nq, 4)), dim3(256), 0, (hipStream_t)stream,
-                       (const u64*)parts, nparts, (long long)nq, k, (u64*)out_keys, (long long)k);
+    hipLaunchKernelGGL(merge_keys_kernel, dim3((unsigned)lvs_ceil_div(nq, 4)), dim3(256), 0, st, (const u64*)parts, nparts,
+                       (long long)nq, k, (u64*)out_keys, (long long)k, (const uint32_t*)nullptr);
     LVS_HIP_CHECK(hipGetLastError());
     return LVS_OK;
 }
@@ -876,6 +951,7 @@ extern "C" int32_t lvs_keys_to_result(const uint64_t* keys, int64_t nq, int32_t 
     long long n = (long long)nq * k;
     if (n == 0) return LVS_OK;
     LVS_REQUIRE(keys && out_D && out_I, "NULL buffer");
+    LVS_DEVICE_GUARD(stream);
     hipLaunchKernelGGL(keys_to_result_kernel, dim3((unsigned)lvs_ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream,
                        (const u64*)keys, n, metric, (const long long*)id_map, out_D, (long long*)out_I);
     LVS_HIP_CHECK(hipGetLastError());
@@ -891,6 +967,7 @@ extern "C" int32_t lvs_scores(const void* xb, int32_t xb_pack, int64_t nb, const
     if (nq == 0 || nb == 0) return LVS_OK;
     LVS_REQUIRE(xb && xq && out && ld_out >= nb, "bad buffers");
     LVS_REQUIRE(metric != LVS_METRIC_L2 || (xb_norms_sq && xq_norms_sq), "L2 needs both norm vectors");
+    LVS_DEVICE_GUARD(stream);
     LvsTileArgs a;
     memset(&a, 0, sizeof(a));
     a.xb = xb;
@@ -936,6 +1013,7 @@ extern "C" int32_t lvs_range_join(const void* xb, int32_t xb_pack, int64_t nb, c
     if (nq == 0 || nb == 0) return LVS_OK;
     LVS_REQUIRE(xb && xq && (capacity == 0 || (out_q && out_j && out_s)), "NULL buffer");
     LVS_REQUIRE(metric != LVS_METRIC_L2 || (xb_norms_sq && xq_norms_sq), "L2 needs both norm vectors");
+    LVS_DEVICE_GUARD(stream);
     LvsTileArgs a;
     memset(&a, 0, sizeof(a));
     a.xb = xb;

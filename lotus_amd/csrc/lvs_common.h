@@ -87,3 +87,65 @@ void lvs_set_error(const char* fmt, ...);
 
 static inline int64_t lvs_round_up(int64_t a, int64_t b) { return (a + b - 1) / b * b; }
 static inline int64_t lvs_ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// ---- tuning / debug knobs ----------------------------------------------------------------------------------
+// The shipped library reads NO environment variable: every knob below is a compile-time constant unless the library is
+// built with -DLVS_TUNING (`make tuning` -> liblotus_hip_tuning.so, reported by lvs_build_flags()).  Some knobs skip
+// work and produce wrong results on purpose (timing ablations); they exist in the tuning build only.
+#ifdef LVS_TUNING
+#include <stdlib.h>
+static inline long long lvs_tune(const char* name, long long dflt) {
+    const char* e = getenv(name);
+    return e ? atoll(e) : dflt;
+}
+static inline bool lvs_tune_set(const char* name) { return getenv(name) != nullptr; }
+#else
+#define lvs_tune(name, dflt) ((long long)(dflt))
+#define lvs_tune_set(name) (false)
+#endif
+
+// Entry points launch on `stream`; make that stream's device current for the duration of the call (the caller may
+// drive several GPUs from one process) and restore the previous one afterwards.
+struct LvsDeviceGuard {
+    int prev = -1;
+    int dev = -1;
+    bool switched = false;
+    hipError_t err = hipSuccess;
+    explicit LvsDeviceGuard(hipStream_t st) {
+        err = hipGetDevice(&prev);
+        dev = prev;
+        if (err != hipSuccess || st == nullptr) return;
+        hipDevice_t sd = 0;
+        if (hipStreamGetDevice(st, &sd) != hipSuccess) {
+            (void)hipGetLastError();
+            return;  // legacy/default-stream handles: keep the current device
+        }
+        dev = (int)sd;
+        if (dev != prev) {
+            err = hipSetDevice(dev);
+            switched = err == hipSuccess;
+        }
+    }
+    ~LvsDeviceGuard() {
+        if (switched) (void)hipSetDevice(prev);
+    }
+};
+#define LVS_DEVICE_GUARD(stream)                  \
+    LvsDeviceGuard _lvs_guard((hipStream_t)(stream)); \
+    LVS_HIP_CHECK(_lvs_guard.err)
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per device: remember which devices have it (bit per device id).
+#include <atomic>
+struct LvsPerDeviceOnce {
+    std::atomic<unsigned long long> mask{0};
+    std::atomic<unsigned long long> bytes[64];
+    bool done(int dev, size_t need) const {
+        return dev >= 0 && dev < 64 && (mask.load(std::memory_order_acquire) >> dev & 1ull) &&
+               bytes[dev].load(std::memory_order_relaxed) >= need;
+    }
+    void set(int dev, size_t have) {
+        if (dev < 0 || dev >= 64) return;
+        bytes[dev].store(have, std::memory_order_relaxed);
+        mask.fetch_or(1ull << dev, std::memory_order_release);
+    }
+};

@@ -109,6 +109,7 @@ extern "C" int32_t lvs_kmeans_accumulate(const void* x, int64_t n, int32_t d, in
         lvs_set_error("workspace too small: need %lld bytes", (long long)need);
         return LVS_ENOMEM;
     }
+    LVS_DEVICE_GUARD(stream);
     hipStream_t st = (hipStream_t)stream;
     size_t tmp = 0;
     uint32_t* nil = nullptr;

@@ -51,6 +51,7 @@ extern "C" int32_t lvs_sort_rows_desc(const float* scores, int64_t nq, int64_t n
         lvs_set_error("workspace too small: need %lld bytes", (long long)need);
         return LVS_ENOMEM;
     }
+    LVS_DEVICE_GUARD(stream);
     hipStream_t st = (hipStream_t)stream;
     size_t tmp = sort_temp_bytes(nq, nb);
     char* w = (char*)workspace;

@@ -13,8 +13,6 @@
 //   * hits go through the same wave-cooperative sorted insertion into per-query lists (LDS, 32 x 64 slots, one lock
 //     per query because the 4 waves of a workgroup share the queries); thresholds are shared across workgroups
 //     through the global per-query word; every workgroup writes its k candidates and lvs_merge_keys finishes.
-#include <stdlib.h>
-
 #include "lvs_common.h"
 #include "lvs_tile.h"
 
@@ -148,11 +146,13 @@ __global__ __launch_bounds__(WAVES * 64, 2) void lvs_stream_kernel(const LvsStre
                     for (int u = 0; u < UNROLL; ++u) {
                         const half8 av = abuf[u];
                         abuf[u] = *(const half8*)(nsrc + u * 16);
-                        if (a.debug == 1) {
+#ifdef LVS_TUNING
+                        if (a.debug == 1) {  // timing ablation: no MFMA / B reads (results are wrong)
                             acc[0] += (float)av[0];
-                        } else {
-                            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bsrc[u * 64], acc, 0, 0, 0);
+                            continue;
                         }
+#endif
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bsrc[u * 64], acc, 0, 0, 0);
                     }
                 }
             }
@@ -178,7 +178,9 @@ __global__ __launch_bounds__(WAVES * 64, 2) void lvs_stream_kernel(const LvsStre
         }
         }
         // ---- block epilogue: 32 rows x 32 queries; lane holds query q, rows row0 + (r&3) + 8*(r>>2) + 4*(lane>>5)
-        if (a.debug == 2) continue;
+#ifdef LVS_TUNING
+        if (a.debug == 2) continue;  // timing ablation: no block epilogue (results are wrong)
+#endif
         const long long rbase = row0 + 4 * (lane >> 5);
         if (a.metric == LVS_METRIC_L2) {
 #pragma unroll
@@ -269,7 +271,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void lvs_stream_kernel(const LvsStre
 int lvs_stream_blocks(int64_t nb) {
     const int64_t nblocks = (nb + 31) / 32;
     int64_t wgs = 256;  // one per CU: fewest partial lists to merge, cold start amortised over ~120 row blocks
-    if (const char* e = getenv("LVS_STREAM_WGS")) wgs = atoll(e) > 0 ? atoll(e) : wgs;  // tuning override
+    if (lvs_tune("LVS_STREAM_WGS", 0) > 0) wgs = lvs_tune("LVS_STREAM_WGS", 0);  // -DLVS_TUNING builds only
     if (wgs > LVS_STREAM_MAXWG) wgs = LVS_STREAM_MAXWG;
     if (wgs > (nblocks + 3) / 4) wgs = (nblocks + 3) / 4;
     if (wgs < 1) wgs = 1;
@@ -282,15 +284,17 @@ hipError_t lvs_stream_launch(LvsStreamArgs& a, hipStream_t stream) {
     const int64_t nblocks = (a.nb + 31) / 32;
     const int wgs = lvs_stream_blocks(a.nb);
     a.blocks_per_wg = (int)((nblocks + wgs - 1) / wgs);
-    a.debug = getenv("LVS_STREAM_DEBUG") ? atoi(getenv("LVS_STREAM_DEBUG")) : 0;
+    a.debug = (int)lvs_tune("LVS_STREAM_DEBUG", 0);
     const int grid = (int)((nblocks + a.blocks_per_wg - 1) / a.blocks_per_wg);
     const size_t lds = (size_t)a.nbfrag * 1024 + SQ * KCAP * 8 + SQ * 4;
-    static size_t attr_bytes = 0;
-    if (lds > attr_bytes) {
-        hipError_t e = hipFuncSetAttribute((const void*)lvs_stream_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)lds);
+    static LvsPerDeviceOnce attr;  // the attribute is a per-device property
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (!attr.done(dev, lds)) {
+        e = hipFuncSetAttribute((const void*)lvs_stream_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        attr_bytes = lds;
+        attr.set(dev, lds);
     }
     hipLaunchKernelGGL(lvs_stream_kernel, dim3(grid), dim3(WAVES * 64), lds, stream, a);
     return hipGetLastError();

@@ -49,9 +49,10 @@ struct LvsTileArgs {
     int k;                    // <= the geometry's list capacity
     int bq;                   // queries per tile the plan was made for: LVS2_BQ (256 x 256 geometry) or LVS3_BQ
     int ntiles, tiles_per_slab, nslab, nqt;
-    int debug_hot;            // tuning aid (env LVS_DEBUG_HOT), timing only - results are wrong unless 0:
-                              // 2 skip the top-k slow path, 3 scan hits but skip insertions, 4 no wait for the
-                              // staging loads (256x256 kernel only)
+    int debug_hot;            // -DLVS_TUNING builds only (env LVS_DEBUG_HOT), timing ablations - results are wrong
+                              // unless 0: 2 skip the top-k slow path, 3 scan hits but skip insertions, 4 no wait for
+                              // the staging loads.  The shipped kernel does not read this field.
+    const uint32_t* pred;     // nullable: the launch is a no-op unless *pred != 0 (device-side predicate)
     int gq;                   // query tiles per XCD group (1,2,4,8,16,32); slabs per group = 32 / gq
     int lead_slabs;           // slabs walked first in 32-wide groups (see item_of_block); 0 or 1
     int no_share;             // 1: slabs do not exchange thresholds - every slab's list is its own exact top-k
@@ -87,7 +88,7 @@ struct LvsStreamArgs {
     int seg_b[3];            // first B-fragment index of each K segment (segments sharing query columns share fragments)
     int nbfrag;              // B fragments held in LDS
     int blocks_per_wg;       // 32-row blocks per workgroup (contiguous)
-    int debug;               // tuning aid (env LVS_STREAM_DEBUG): 1 no MFMA / B reads, 2 no block epilogue - timing only
+    int debug;               // -DLVS_TUNING builds only (env LVS_STREAM_DEBUG): 1 no MFMA / B reads, 2 no block epilogue
 };
 
 int lvs_stream_blocks(int64_t nb);

@@ -161,6 +161,8 @@ __global__ __launch_bounds__(512, 2) void lvs_tile_kernel(const LvsTileArgs a) {
 
     int qt, slab;
     if (!item_of_block(a, blockIdx.x, qt, slab)) return;
+    // predicated launch (fallback passes of the large-k search): nothing to do unless the device-side flag is set
+    if (a.pred && __builtin_nontemporal_load(a.pred) == 0u) return;
     const long long q0 = (long long)qt * BQ;
     int tile0_ = slab * a.tiles_per_slab;
     const int tile1 = min(a.ntiles, tile0_ + a.tiles_per_slab);
@@ -304,9 +306,12 @@ __global__ __launch_bounds__(512, 2) void lvs_tile_kernel(const LvsTileArgs a) {
 #endif
     for (int t = 0; t < T; ++t) {
         const int buf = t & 1;
+#ifdef LVS_TUNING
         if (a.debug_hot == 4) {  // tuning aid: no wait for the staging loads (results are garbage, timing only)
             __builtin_amdgcn_s_barrier();
-        } else {
+        } else
+#endif
+        {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
         }
@@ -528,7 +533,9 @@ __global__ __launch_bounds__(512, 2) void lvs_tile_kernel(const LvsTileArgs a) {
 #pragma unroll
             for (int ni = 0; ni < 2; ++ni)
                 if (wave_any(qvalid[ni] && (max16(acc[mi][ni]) >= tauf[ni]))) hitmask |= 1u << (mi * 2 + ni);
-        if (a.debug_hot == 2) hitmask = 0;
+#ifdef LVS_TUNING
+        if (a.debug_hot == 2) hitmask = 0;  // tuning aid: skip the slow path (results are wrong, timing only)
+#endif
 #ifdef LVS_COUNT_EVENTS
         const unsigned long long tm1 = __builtin_amdgcn_s_memtime();
         c_filter += tm1 - tm0;
@@ -587,7 +594,9 @@ __global__ __launch_bounds__(512, 2) void lvs_tile_kernel(const LvsTileArgs a) {
                     // (new[j] = L[j] if L[j] > key, else key if L[j-1] > key, else L[j-1]) - cost independent of k.
                     // The list's lock is taken by lane 0 only (waves wm = 0, 1 share queries).
                     unsigned long long pm = __ballot(pending);
+#ifdef LVS_TUNING
                     if (a.debug_hot == 3) pm = 0;  // tuning aid: scan for hits but skip the insertions
+#endif
                     while (pm) {
 #ifdef LVS_COUNT_EVENTS
                         ++n_ins;
@@ -697,13 +706,15 @@ __global__ __launch_bounds__(512, 2) void lvs_tile_kernel(const LvsTileArgs a) {
 
 template <int MODE, int MI>
 static hipError_t launch_one(const LvsTileArgs& a, hipStream_t stream) {
-    static bool attr_done = false;  // one flag per instantiation
+    static LvsPerDeviceOnce attr;  // one per instantiation; the attribute is a per-device property
     constexpr int lds = Geo<MI>::LDS_TOTAL;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)lvs_tile_kernel<MODE, MI>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (!attr.done(dev, (size_t)lds)) {
+        e = hipFuncSetAttribute((const void*)lvs_tile_kernel<MODE, MI>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return e;
-        attr_done = true;
+        attr.set(dev, (size_t)lds);
     }
     dim3 grid(lvs_tile_grid_blocks(a.nqt, a.nslab, a.gq, a.lead_slabs)), block(512);
     hipLaunchKernelGGL((lvs_tile_kernel<MODE, MI>), grid, block, lds, stream, a);

@@ -18,7 +18,7 @@ def threshold_pairs(backend, packed, threshold: float, metric: int = _capi.METRI
                     process_group=None):
     """-> (i, j, score) numpy arrays of all row pairs i < j of ``packed`` with score > threshold, sorted by (i, j).
 
-    With ``shard=True`` and ``torch.distributed`` initialised the rows are replicated on every rank, 128-row query
+    With ``shard=True`` and ``torch.distributed`` initialised the rows are replicated on every rank, 256-row query
     tiles are dealt round-robin to the ranks, and the per-rank pair lists are exchanged with an all-gather."""
     rank, world, dist = 0, 1, None
     if shard:

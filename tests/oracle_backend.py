@@ -103,7 +103,7 @@ class OracleBackend:
         if metric == 1:
             s = -np.maximum((queries.norms.numpy()[:, None] + corpus.norms.numpy()[None, :]) - 2 * s, 0)
         q, j = np.nonzero(s > np.float32(threshold))
-        keep = ((q // 128) % stride) == phase
+        keep = ((q // 256) % stride) == phase  # 256-query tiles, as the kernel deals them
         if q_row0 >= 0:
             keep &= (j + id_offset) > (q + q_row0)
         q, j = q[keep], j[keep]

@@ -28,14 +28,15 @@ def test_shared_object_is_gfx950_code():
 
 def test_host_side_entry_points_without_a_gpu():
     lib = _capi.load()
-    assert lib.lvs_abi_version() == 1
+    assert lib.lvs_abi_version() == 2 and lib.lvs_build_flags() == 0
     assert lib.lvs_packed_ld(768, _capi.PACK_F16) == 768
     assert lib.lvs_packed_ld(100, _capi.PACK_F16) == 128
     assert lib.lvs_packed_ld(384, _capi.PACK_SPLIT) == 768
     assert lib.lvs_packed_ld(0, _capi.PACK_F16) < 0 and lib.lvs_packed_ld(8, 7) < 0
-    ws = lib.lvs_flat_search_workspace_bytes(100000, 1000000, 768, 10)
+    ws = lib.lvs_flat_search_workspace_bytes(100000, 1000000, 768, 10, 0, 0)
     assert 100000 * 10 * 8 <= ws < 1 << 30
-    assert lib.lvs_flat_search_workspace_bytes(-1, 10, 8, 1) < 0
+    assert lib.lvs_flat_search_workspace_bytes(-1, 10, 8, 1, 0, 0) < 0
+    assert lib.lvs_flat_search_workspace_bytes(10, 10, 8, 1, 5, 0) < 0  # bad pack mode
     # argument validation happens before any device work
     st = lib.lvs_flat_search_keys(None, 0, 10, None, 0, 10, 8, 5, 3, None, None, 0, None, None, None, 0, None)
     assert st == _capi.EINVAL and b"metric" in lib.lvs_last_error()
@@ -67,7 +68,7 @@ def test_workspace_sizes_cover_every_routing_decision():
     large enough for the path the search will take (k <= 15, 16..56, and the two-phase path beyond 56, whose lists and
     buckets dominate)."""
     lib = _capi.load()
-    f = lib.lvs_flat_search_workspace_bytes
+    f = lambda nq, nb, d, k, bm=0, qm=0: lib.lvs_flat_search_workspace_bytes(nq, nb, d, k, bm, qm)  # noqa: E731
     base = f(100_000, 1_000_000, 768, 10)
     assert base > 100_000 * 4 + 11 * 100_000 * 10 * 8 // 2  # thresholds + per-slab candidate lists
     assert f(100_000, 1_000_000, 768, 24) > 0 and f(100_000, 1_000_000, 768, 56) > 0
@@ -80,3 +81,52 @@ def test_workspace_sizes_cover_every_routing_decision():
     assert f(10, 1000, 0, 5) < 0 and f(10, 1000, 64, -1) < 0  # bad shapes are refused
     # beyond 24 GB the two-phase path is not planned: the call falls back to selection passes and their small workspace
     assert f(4_000_000, 1_000_000, 768, 2048) < 24 << 30
+    # pack modes are part of the contract (ABI 2); sizes must never shrink below the fp16 case
+    for k in (1, 10, 56, 100):
+        assert f(5000, 300_000, 384, k, 1, 1) >= f(5000, 300_000, 384, k, 0, 0) > 0
+
+
+KNOBS = ["LVS_DEBUG_HOT", "LVS_STREAM_DEBUG", "LVS_GQ", "LVS_NSLAB", "LVS_TOP1", "LVS_TWO_PHASE", "LVS_SMALLQ",
+         "LVS_LEAD", "LVS_L2_MIN_TILES", "LVS_STREAM", "LVS_STREAM_WGS", "LVS_COUNT", "LVS_TWO_PHASE_SLOTS"]
+
+
+def test_shipped_library_has_no_tuning_or_debug_knob():
+    """one stray LVS_* environment variable must not be able to change (or corrupt) results.
+    The shipped .so contains none of the knob names and reports build flags 0; the names only exist in the separate
+    `make tuning` build."""
+    blob = open(_capi.LIB_PATH, "rb").read()
+    for name in KNOBS:
+        assert (name.encode() + b"\0") not in blob, name
+    assert _capi.load().lvs_build_flags() == 0
+    # the only getenv left is rocPRIM's own (ROCPRIM_USE_ATOMIC_BLOCK_ID, header-inlined into the two sort users)
+    out = subprocess.run(["nm", "-D", "--undefined-only", _capi.LIB_PATH], capture_output=True, text=True).stdout
+    assert "atoll" not in out and "atoi" not in out
+
+
+def test_tuning_build_is_refused_by_default(tmp_path):
+    import pytest
+
+    csrc = os.path.join(os.path.dirname(_capi.LIB_PATH), "csrc")
+    r = subprocess.run(["make", "-C", csrc, "tuning", "-j4"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    tuning = os.path.join(os.path.dirname(_capi.LIB_PATH), "liblotus_hip_tuning.so")
+    blob = open(tuning, "rb").read()
+    assert b"LVS_DEBUG_HOT\0" in blob
+    lib = ctypes.CDLL(tuning)
+    lib.lvs_build_flags.restype = ctypes.c_int32
+    assert lib.lvs_build_flags() & _capi.BUILD_TUNING
+    saved, saved_path = _capi._lib, _capi.LIB_PATH
+    try:
+        _capi._lib, _capi.LIB_PATH = None, tuning
+        with pytest.raises(_capi.LotusHipError, match="tuning build"):
+            _capi.load()
+        assert _capi.load(tuning).lvs_build_flags() & _capi.BUILD_TUNING  # explicit path: allowed (tools/)
+    finally:
+        _capi._lib, _capi.LIB_PATH = saved, saved_path
+
+
+def test_merge_keys_accepts_long_lists_from_many_parts():
+    """8 shards x k > 512 used to be rejected.  Argument validation only (no GPU here)."""
+    lib = _capi.load()
+    assert lib.lvs_merge_keys(None, 8, 0, 1000, None, None) == 0          # nq == 0: nothing to do, accepted
+    assert lib.lvs_merge_keys(None, 8, 5, 4000, None, None) == _capi.EINVAL  # NULL buffers / k beyond LVS_MAX_K
