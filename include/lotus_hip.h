@@ -75,6 +75,11 @@ int32_t lvs_pack_rows(const void* src, int32_t src_dtype, int64_t n, int32_t d, 
                       int32_t normalize, void* dst, float* out_norms_sq, void* stream);
 /* dst[i] = src[ids[i]] for packed rows (the `ids` branch gather, faiss_vs.py:59-64). */
 int32_t lvs_gather_rows(const void* src, int32_t ld, const int64_t* ids, int64_t n_ids, void* dst, void* stream);
+/* dst[i][0..d) = float32 value (hi + lo) of packed row ids[i] (row i when ids is NULL): the inverse of lvs_pack_rows
+ * up to its rounding - serves `get_vectors_from_index` (faiss_vs.py:38-41) for device-resident indexes and the initial
+ * k-means centroids (lotus/utils.py:62) without a host copy of the matrix. */
+int32_t lvs_unpack_rows(const void* src, int32_t d, int32_t pack_mode, const int64_t* ids, int64_t n, float* dst,
+                        void* stream);
 /* dst[i] = src[ids[i]] for a float32 vector (row norms of a gathered subset). */
 int32_t lvs_gather_f32(const float* src, const int64_t* ids, int64_t n_ids, float* dst, void* stream);
 
@@ -137,6 +142,10 @@ int64_t lvs_kmeans_accumulate_workspace_bytes(int64_t n, int32_t k);
 int32_t lvs_kmeans_accumulate(const void* x, int64_t n, int32_t d, int32_t pack_mode, const int64_t* assign,
                               int32_t k, float* sums, float* counts, void* workspace, int64_t workspace_bytes,
                               void* stream);
+/* centroids [k][d] float32 (in/out): c = sums * (1 / count) where count > 0, unchanged where the cluster is empty
+ * (faiss compute_centroids; empty clusters are then re-seeded by lvs_kmeans_split_clusters_host). */
+int32_t lvs_kmeans_update_centroids(const float* sums, const float* counts, int32_t k, int32_t d, float* centroids,
+                                    void* stream);
 /* HOST helpers (plain host pointers), bit-exact with faiss: rand_perm(n, seed) = Fisher-Yates on std::mt19937
  * (training subsample and initial centroids), and split_clusters (empty-cluster re-seeding, RNG seed 1234). */
 int32_t lvs_rand_perm_host(int64_t n, int64_t seed, int64_t* out_perm);

@@ -33,6 +33,7 @@ SIGNATURES = {
     "lvs_pack_rows": (_i32, [_vp, _i32, _i64, _i32, _i32, _i32, _vp, _vp, _vp]),
     "lvs_gather_rows": (_i32, [_vp, _i32, _vp, _i64, _vp, _vp]),
     "lvs_gather_f32": (_i32, [_vp, _vp, _i64, _vp, _vp]),
+    "lvs_unpack_rows": (_i32, [_vp, _i32, _i32, _vp, _i64, _vp, _vp]),
     "lvs_flat_search_workspace_bytes": (_i64, [_i64, _i64, _i32, _i32, _i32, _i32]),
     "lvs_flat_search_keys": (_i32, [_vp, _i32, _i64, _vp, _i32, _i64, _i32, _i32, _i32, _vp, _vp, _i64, _vp, _vp,
                                     _vp, _i64, _vp]),
@@ -45,6 +46,7 @@ SIGNATURES = {
                               _i32, _i64, _vp, _vp, _vp, _vp, _vp]),
     "lvs_kmeans_accumulate_workspace_bytes": (_i64, [_i64, _i32]),
     "lvs_kmeans_accumulate": (_i32, [_vp, _i64, _i32, _i32, _vp, _i32, _vp, _vp, _vp, _i64, _vp]),
+    "lvs_kmeans_update_centroids": (_i32, [_vp, _vp, _i32, _i32, _vp, _vp]),
     "lvs_rand_perm_host": (_i32, [_i64, _i64, _vp]),
     "lvs_kmeans_split_clusters_host": (_i32, [_i32, _i32, _i64, _vp, _vp, ctypes.POINTER(_i32)]),
     "lvs_timing_enable": (_i32, [_i32]),

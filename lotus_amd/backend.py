@@ -43,6 +43,12 @@ class HipBackend:
     def _stream(self) -> int:
         return int(self.torch.cuda.current_stream(self.device).cuda_stream)
 
+    def _c(self, name: str, *args) -> None:
+        """One C-ABI call on this backend's device.  The library makes the stream's device current itself, but torch's
+        default stream is the NULL handle, which names no device - so the device is also made current here."""
+        with self.torch.cuda.device(self.device):
+            _capi.check(getattr(self.lib, name)(*args), name)
+
     def _workspace(self, nbytes: int):
         if self._ws is None or self._ws.numel() < nbytes:
             self._ws = self.torch.empty(max(nbytes, 1 << 20), dtype=self.torch.uint8, device=self.device)
@@ -79,8 +85,8 @@ class HipBackend:
                 c = np.ascontiguousarray(c, dtype=np.float16 if c.dtype == np.float16 else np.float32)
                 chunk = torch.from_numpy(c).to(self.device)
             src_dtype = _capi.DTYPE_F16 if chunk.dtype == torch.float16 else _capi.DTYPE_F32
-            _capi.check(self.lib.lvs_pack_rows(_ptr(chunk), src_dtype, r1 - r0, d, mode, int(bool(normalize)),
-                                               _ptr(rows[r0:r1]), _ptr(norms[r0:r1]), self._stream()), "lvs_pack_rows")
+            self._c("lvs_pack_rows", _ptr(chunk), src_dtype, r1 - r0, d, mode, int(bool(normalize)), _ptr(rows[r0:r1]),
+                    _ptr(norms[r0:r1]), self._stream())
             del chunk
         return PackedRows(rows=rows, norms=norms, n=n, d=d, mode=mode)
 
@@ -90,11 +96,22 @@ class HipBackend:
         ld = int(src.rows.shape[1])
         rows = torch.empty((m, ld), dtype=torch.float16, device=self.device)
         norms = torch.empty((m,), dtype=torch.float32, device=self.device)
-        _capi.check(self.lib.lvs_gather_rows(_ptr(src.rows), ld, _ptr(ids_dev), m, _ptr(rows), self._stream()),
-                    "lvs_gather_rows")
-        _capi.check(self.lib.lvs_gather_f32(_ptr(src.norms), _ptr(ids_dev), m, _ptr(norms), self._stream()),
-                    "lvs_gather_f32")
+        self._c("lvs_gather_rows", _ptr(src.rows), ld, _ptr(ids_dev), m, _ptr(rows), self._stream())
+        self._c("lvs_gather_f32", _ptr(src.norms), _ptr(ids_dev), m, _ptr(norms), self._stream())
         return PackedRows(rows=rows, norms=norms, n=m, d=src.d, mode=src.mode)
+
+    def unpack(self, src: PackedRows, ids_dev=None):
+        """float32 values [m, d] of the packed rows ``ids_dev`` (all rows when None), as a device tensor."""
+        torch = self.torch
+        m = src.n if ids_dev is None else int(ids_dev.numel())
+        out = torch.empty((m, src.d), dtype=torch.float32, device=self.device)
+        self._c("lvs_unpack_rows", _ptr(src.rows), src.d, src.mode, _ptr(ids_dev), m, _ptr(out), self._stream())
+        return out
+
+    @staticmethod
+    def slice_rows(src: PackedRows, r0: int, r1: int) -> PackedRows:
+        """Rows [r0, r1) of a packed matrix (a view: same HBM)."""
+        return PackedRows(rows=src.rows[r0:r1], norms=src.norms[r0:r1], n=r1 - r0, d=src.d, mode=src.mode)
 
     # ---- search ----
     def search_keys(self, corpus: PackedRows, queries: PackedRows, k: int, metric: int, id_offset: int = 0,
@@ -108,10 +125,9 @@ class HipBackend:
         if need < 0:
             raise LotusHipError("lvs_flat_search_workspace_bytes rejected the shape")
         ws = self._workspace(need)
-        _capi.check(self.lib.lvs_flat_search_keys(
-            _ptr(corpus.rows), corpus.mode, corpus.n, _ptr(queries.rows), queries.mode, queries.n, corpus.d, metric, k,
-            _ptr(corpus.norms), _ptr(queries.norms), int(id_offset), _ptr(row_ids), _ptr(keys), _ptr(ws),
-            int(ws.numel()), self._stream()), "lvs_flat_search_keys")
+        self._c("lvs_flat_search_keys", _ptr(corpus.rows), corpus.mode, corpus.n, _ptr(queries.rows), queries.mode,
+                queries.n, corpus.d, metric, k, _ptr(corpus.norms), _ptr(queries.norms), int(id_offset), _ptr(row_ids),
+                _ptr(keys), _ptr(ws), int(ws.numel()), self._stream())
         return keys
 
     def merge_keys(self, parts):
@@ -119,8 +135,7 @@ class HipBackend:
         torch = self.torch
         P, nq, k = (int(s) for s in parts.shape)
         out = torch.empty((nq, k), dtype=torch.int64, device=self.device)
-        _capi.check(self.lib.lvs_merge_keys(_ptr(parts.contiguous()), P, nq, k, _ptr(out), self._stream()),
-                    "lvs_merge_keys")
+        self._c("lvs_merge_keys", _ptr(parts.contiguous()), P, nq, k, _ptr(out), self._stream())
         return out
 
     def keys_to_result(self, keys, metric: int, id_map=None):
@@ -128,50 +143,83 @@ class HipBackend:
         nq, k = int(keys.shape[0]), int(keys.shape[1])
         D = torch.empty((nq, k), dtype=torch.float32, device=self.device)
         I = torch.empty((nq, k), dtype=torch.int64, device=self.device)
-        _capi.check(self.lib.lvs_keys_to_result(_ptr(keys), nq, k, metric, _ptr(id_map), _ptr(D), _ptr(I),
-                                                self._stream()), "lvs_keys_to_result")
+        self._c("lvs_keys_to_result", _ptr(keys), nq, k, metric, _ptr(id_map), _ptr(D), _ptr(I), self._stream())
         return D, I
 
     def scores(self, corpus: PackedRows, queries: PackedRows, metric: int):
         torch = self.torch
         out = torch.empty((queries.n, corpus.n), dtype=torch.float32, device=self.device)
-        _capi.check(self.lib.lvs_scores(_ptr(corpus.rows), corpus.mode, corpus.n, _ptr(queries.rows), queries.mode,
-                                        queries.n, corpus.d, metric, _ptr(corpus.norms), _ptr(queries.norms), _ptr(out),
-                                        corpus.n, self._stream()), "lvs_scores")
+        self._c("lvs_scores", _ptr(corpus.rows), corpus.mode, corpus.n, _ptr(queries.rows), queries.mode, queries.n,
+                corpus.d, metric, _ptr(corpus.norms), _ptr(queries.norms), _ptr(out), corpus.n, self._stream())
         return out
+
+    def rank_scores(self, sc, id_offset: int = 0):
+        """Rank every float32 score row best-first: ``sc`` [nq, nb] (larger = better) -> int64 key tensor [nq, nb].
+        The device sort handles < 2^32 scores per launch, so the queries go through in chunks."""
+        torch = self.torch
+        nq, nb = int(sc.shape[0]), int(sc.shape[1])
+        keys = torch.empty((nq, nb), dtype=torch.int64, device=self.device)
+        if nq == 0 or nb == 0:
+            return keys
+        step = max(1, min(nq, (2**32 - 2) // nb))
+        for q0 in range(0, nq, step):
+            q1 = min(nq, q0 + step)
+            need = int(self.lib.lvs_sort_rows_workspace_bytes(q1 - q0, nb))
+            if need < 0:
+                raise LotusHipError("lvs_sort_rows_workspace_bytes rejected the shape")
+            ws = self._workspace(need)
+            self._c("lvs_sort_rows_desc", _ptr(sc[q0:q1]), q1 - q0, nb, int(sc.stride(0)), int(id_offset),
+                    _ptr(keys[q0:q1]), _ptr(ws), int(ws.numel()), self._stream())
+        return keys
 
     def rank_all(self, corpus: PackedRows, queries: PackedRows, metric: int, id_offset: int = 0):
         """Every corpus row ranked for every query (K = N callers): int64 key tensor [nq, nb], best first."""
-        torch = self.torch
-        if queries.n * corpus.n >= 2**32 - 1:
-            raise ValueError("K = N ranking is limited to nq * nb < 2^32 scores")
-        sc = self.scores(corpus, queries, metric)
-        keys = torch.empty((queries.n, corpus.n), dtype=torch.int64, device=self.device)
-        need = int(self.lib.lvs_sort_rows_workspace_bytes(queries.n, corpus.n))
-        ws = self._workspace(need)
-        _capi.check(self.lib.lvs_sort_rows_desc(_ptr(sc), queries.n, corpus.n, corpus.n, int(id_offset), _ptr(keys),
-                                                _ptr(ws), int(ws.numel()), self._stream()), "lvs_sort_rows_desc")
-        return keys
+        if corpus.n >= 2**32 - 2:
+            raise ValueError("K = N ranking needs fewer than 2^32 - 2 rows")
+        return self.rank_scores(self.scores(corpus, queries, metric), id_offset)
 
     # ---- threshold join (sem_dedup) ----
+    RANGE_CHUNK_ROWS = 65536  # query rows per launch (a multiple of 256 x any rank count that divides it)
+
     def range_join(self, corpus: PackedRows, queries: PackedRows, threshold: float, metric: int = _capi.METRIC_IP,
                    q_row0: int = -1, id_offset: int = 0, stride: int = 1, phase: int = 0, capacity: int = 1 << 22):
         """All (query, corpus id, score) with score > threshold.  q_row0 >= 0: self-join, pairs with id > query row
-        only.  Returns three device tensors (int64, int64, float32); order unspecified."""
+        only.  Returns three device tensors (int64, int64, float32); order unspecified.
+
+        The query rows go through in chunks, each with its own pair buffer: when a chunk finds more than `capacity`
+        pairs only that chunk is run again with a buffer of the counted size (the kernel keeps counting past the
+        capacity) - a 5 M-row self-join repeats at most 1/77 of its work, not all of it."""
         torch = self.torch
-        while True:
-            oq = torch.empty((capacity,), dtype=torch.int64, device=self.device)
-            oj = torch.empty((capacity,), dtype=torch.int64, device=self.device)
-            os_ = torch.empty((capacity,), dtype=torch.float32, device=self.device)
-            cnt = torch.zeros((1,), dtype=torch.int64, device=self.device)
-            _capi.check(self.lib.lvs_range_join(
-                _ptr(corpus.rows), corpus.mode, corpus.n, _ptr(queries.rows), queries.mode, queries.n, corpus.d, metric,
-                _ptr(corpus.norms), _ptr(queries.norms), float(threshold), int(q_row0), int(id_offset), int(stride),
-                int(phase), int(capacity), _ptr(oq), _ptr(oj), _ptr(os_), _ptr(cnt), self._stream()), "lvs_range_join")
-            n = int(cnt.item())
-            if n <= capacity:
-                return oq[:n], oj[:n], os_[:n]
-            capacity = n  # counted but not stored: size the buffers and run again
+        step = max(256 * stride, self.RANGE_CHUNK_ROWS // (256 * stride) * (256 * stride))
+        outs = []
+        cnt = torch.zeros((1,), dtype=torch.int64, device=self.device)
+        oq = oj = os_ = None
+        for c0 in range(0, max(queries.n, 1), step):
+            c1 = min(queries.n, c0 + step)
+            if c1 <= c0:
+                break
+            qs = self.slice_rows(queries, c0, c1)
+            cap = capacity
+            while True:
+                if oq is None or oq.numel() < cap:
+                    oq = torch.empty((cap,), dtype=torch.int64, device=self.device)
+                    oj = torch.empty((cap,), dtype=torch.int64, device=self.device)
+                    os_ = torch.empty((cap,), dtype=torch.float32, device=self.device)
+                cnt.zero_()
+                self._c("lvs_range_join", _ptr(corpus.rows), corpus.mode, corpus.n, _ptr(qs.rows), qs.mode, qs.n,
+                        corpus.d, metric, _ptr(corpus.norms), _ptr(qs.norms), float(threshold),
+                        int(q_row0 + c0) if q_row0 >= 0 else -1, int(id_offset), int(stride), int(phase), int(cap),
+                        _ptr(oq), _ptr(oj), _ptr(os_), _ptr(cnt), self._stream())
+                n = int(cnt.item())
+                if n <= cap:
+                    break
+                cap = n  # counted but not stored: size the buffers and run this chunk again
+            if n:
+                outs.append((oq[:n] + c0, oj[:n].clone(), os_[:n].clone()))
+        if not outs:
+            e = torch.empty((0,), dtype=torch.int64, device=self.device)
+            return e, e.clone(), torch.empty((0,), dtype=torch.float32, device=self.device)
+        return (torch.cat([o[0] for o in outs]), torch.cat([o[1] for o in outs]), torch.cat([o[2] for o in outs]))
 
     # ---- k-means pieces ----
     def kmeans_accumulate(self, x: PackedRows, assign, k: int):
@@ -181,10 +229,14 @@ class HipBackend:
         counts = torch.zeros((k,), dtype=torch.float32, device=self.device)
         need = int(self.lib.lvs_kmeans_accumulate_workspace_bytes(x.n, k))
         ws = self._workspace(need)
-        _capi.check(self.lib.lvs_kmeans_accumulate(_ptr(x.rows), x.n, x.d, x.mode, _ptr(assign), k, _ptr(sums),
-                                                   _ptr(counts), _ptr(ws), int(ws.numel()), self._stream()),
-                    "lvs_kmeans_accumulate")
+        self._c("lvs_kmeans_accumulate", _ptr(x.rows), x.n, x.d, x.mode, _ptr(assign), k, _ptr(sums), _ptr(counts),
+                _ptr(ws), int(ws.numel()), self._stream())
         return sums, counts
+
+    def kmeans_update_centroids(self, sums, counts, centroids) -> None:
+        """centroids (device float32 [k,d], in place) = sums / counts where counts > 0 (faiss compute_centroids)."""
+        k, d = int(centroids.shape[0]), int(centroids.shape[1])
+        self._c("lvs_kmeans_update_centroids", _ptr(sums), _ptr(counts), k, d, _ptr(centroids), self._stream())
 
     def rand_perm(self, n: int, seed: int) -> np.ndarray:
         out = np.empty(n, np.int64)

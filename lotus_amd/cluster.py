@@ -18,7 +18,7 @@ from dataclasses import dataclass
 
 import numpy as np
 
-from . import _capi
+from . import _capi, _dist
 
 
 @dataclass
@@ -30,20 +30,26 @@ class KMeansResult:
     train_ids: np.ndarray  # rows used for training
 
 
-def _dist_ctx(shard: bool, pg=None):
-    if not shard:
-        return None, 0, 1
-    import torch.distributed as dist
-
-    if not (dist.is_available() and dist.is_initialized()):
-        return None, 0, 1
-    return dist, dist.get_rank(pg), dist.get_world_size(pg)
-
-
 def kmeans(x, k: int, niter: int = 20, seed: int = 1234, max_points_per_centroid: int | None = 256, backend=None,
            pack_mode: int | None = None, packed=None, shard: bool = False, process_group=None,
-           final_assign: bool = True, centroid_precision: str = "fp32") -> KMeansResult:
-    """faiss-parity k-means.  ``x``: host matrix [n,d] (float16/32/64); ``packed`` optionally its device image.
+           final_assign: bool = True, centroid_precision: str = "fp32", n_total: int | None = None,
+           local_pos=None) -> KMeansResult:
+    """faiss-parity k-means (``faiss.Kmeans(d, k, niter).train(x)`` + ``index.search(x, 1)``, ``lotus/utils.py:61-65``).
+
+    ``x``: host matrix [n,d] (float16/32/64) and/or ``packed``: its device image.  Everything after the packing runs
+    on the device image: initial centroids are unpacked from it, assignment is the tile kernel in top-1 / squared-L2
+    mode, sums are accumulated in row order, the centroid division happens on the device; per iteration only the
+    ``[k]`` counts come back to the host (4 KB), where faiss's empty-cluster split decides whether anything is left
+    to do (it needs the centroids on the host only when a cluster is empty).
+
+    Multi-GPU (``shard=True`` with ``torch.distributed`` initialised):
+      * rows replicated (``packed`` holds all ``n`` rows on every rank): the training rows are dealt to the ranks in
+        contiguous slices of the training order, the final assignment in contiguous row slices;
+      * rows sharded (``packed`` holds the rows at positions ``local_pos`` - ascending - of an ``n_total``-row matrix,
+        e.g. this rank's shard of a row-sharded ``HipVS``): every rank trains on the training rows it holds and
+        assigns the rows it holds.
+      Either way one all-reduce of the ``[k,d]`` sums, ``[k]`` counts and the objective per iteration, and one
+      all-gather of the final cluster ids; nothing else crosses the ranks.
 
     ``centroid_precision="fp32"`` (default) keeps the centroids fp32-accurate on the device (fp16 hi|lo pair) as
     faiss does, whatever the storage of the points; ``"fp16"`` rounds them to fp16 (half the MFMA work when the
@@ -53,21 +59,40 @@ def kmeans(x, k: int, niter: int = 20, seed: int = 1234, max_points_per_centroid
 
         backend = HipBackend()
     be = backend
-    x = np.asarray(x)
-    if x.ndim != 2:
-        raise ValueError("x must be 2-D")
-    n, d = x.shape
+    if packed is None:
+        x = np.asarray(x)
+        if x.ndim != 2:
+            raise ValueError("x must be 2-D")
+        if pack_mode is None:
+            pack_mode = _capi.PACK_F16 if x.dtype == np.float16 else _capi.PACK_SPLIT
+        packed = be.pack(x, pack_mode)
+    d = packed.d
+    n = int(n_total) if n_total is not None else packed.n
     k = int(k)
     if n < k:
         raise ValueError(f"Number of training points ({n}) should be at least as large as number of clusters ({k})")
-    if pack_mode is None:
-        pack_mode = _capi.PACK_F16 if x.dtype == np.float16 else _capi.PACK_SPLIT
-    if packed is None:
-        packed = be.pack(x, pack_mode)
     if centroid_precision not in ("fp32", "fp16"):
         raise ValueError("centroid_precision must be 'fp32' or 'fp16'")
-    cmode = _capi.PACK_SPLIT if centroid_precision == "fp32" else pack_mode
-    dist, rank, world = _dist_ctx(shard, process_group)
+    cmode = _capi.PACK_SPLIT if centroid_precision == "fp32" else packed.mode
+    dist, rank, world = _dist.context(shard, process_group)
+    sharded_rows = packed.n != n  # this rank holds only the rows at local_pos
+    if sharded_rows:
+        if local_pos is None:
+            raise ValueError("a partial device image needs local_pos (the positions of its rows)")
+        local_pos = np.asarray(local_pos, dtype=np.int64)
+        if len(local_pos) != packed.n:
+            raise ValueError("local_pos must name every row of the device image")
+        if dist is None and packed.n != n:
+            raise ValueError("a partial device image needs shard=True and an initialised process group")
+
+    def local_rows(ids: np.ndarray) -> tuple[np.ndarray, np.ndarray]:
+        """(mask of `ids` held by this rank, their row numbers in `packed`)."""
+        if not sharded_rows:
+            return np.ones(len(ids), bool), ids
+        at = np.searchsorted(local_pos, ids)
+        at[at >= len(local_pos)] = 0
+        held = local_pos[at] == ids if len(local_pos) else np.zeros(len(ids), bool)
+        return held, at[held]
 
     train_ids = np.arange(n, dtype=np.int64)
     if max_points_per_centroid is not None and n > k * max_points_per_centroid:
@@ -75,48 +100,87 @@ def kmeans(x, k: int, niter: int = 20, seed: int = 1234, max_points_per_centroid
     nt = len(train_ids)
     obj = np.zeros(niter, np.float32)
     nsplit = np.zeros(niter, np.int64)
-    x32 = None
 
-    def rows32(idx):
-        return np.ascontiguousarray(x[idx], dtype=np.float32)
+    def centroid_rows(ids: np.ndarray):
+        """float32 [len(ids), d] values of the rows `ids` on the device (every rank gets all of them)."""
+        held, rows = local_rows(ids)
+        if not sharded_rows:
+            return be.unpack(packed, be.to_device(rows))
+        import torch
+
+        vals = torch.zeros((len(ids), d), dtype=torch.float32, device=packed.rows.device)
+        if held.any():
+            vals[be.to_device(np.flatnonzero(held))] = be.unpack(packed, be.to_device(rows))
+        _dist.all_reduce_sum_([vals], process_group)  # every row is held by exactly one rank: x + 0 + ... is exact
+        return vals
 
     if nt == k:
-        centroids = rows32(train_ids)  # faiss: "n == k: copy points as centroids and stop"
+        centroids = centroid_rows(train_ids)  # faiss: "n == k: copy points as centroids and stop"
     else:
         perm = be.rand_perm(nt, seed + 1)
-        centroids = rows32(train_ids[perm[:k]])
-        # this rank's share of the training rows (all of them without sharding)
-        per = -(-nt // world)
-        lo, hi = min(nt, rank * per), min(nt, (rank + 1) * per)
-        local_ids = train_ids[lo:hi]
-        if nt == n and world == 1:
+        centroids = centroid_rows(train_ids[perm[:k]])
+        # the training rows this rank works on
+        if sharded_rows:
+            held, rows = local_rows(train_ids)
+            train = be.gather(packed, be.to_device(rows))
+        elif dist is not None:
+            per = -(-nt // world)
+            lo, hi = min(nt, rank * per), min(nt, (rank + 1) * per)
+            train = be.gather(packed, be.to_device(train_ids[lo:hi]))
+        elif nt == n:
             train = packed
         else:
-            train = be.gather(packed, be.to_device(local_ids))
+            train = be.gather(packed, be.to_device(train_ids))
+        objs = []
         for it in range(niter):
             cpk = be.pack(centroids, cmode)
             keys = be.search_keys(cpk, train, 1, _capi.METRIC_L2)
             D, I = be.keys_to_result(keys, _capi.METRIC_L2)
             sums, counts = be.kmeans_accumulate(train, I.reshape(-1), k)
-            o = D.sum()
-            if dist is not None and world > 1:
-                dist.all_reduce(sums, group=process_group)
-                dist.all_reduce(counts, group=process_group)
-                dist.all_reduce(o, group=process_group)
-            obj[it] = float(o.item())
-            hs = counts.cpu().numpy().astype(np.float32)
-            sm = sums.cpu().numpy()
-            nz = hs > 0
-            centroids = np.ascontiguousarray(centroids, dtype=np.float32)
-            centroids[nz] = sm[nz] * (np.float32(1.0) / hs[nz])[:, None]  # faiss: c *= 1 / count
-            nsplit[it] = be.split_clusters(nt, hs, centroids)
+            o = D.sum().reshape(1)
+            if dist is not None:
+                _dist.all_reduce_sum_([sums, counts, o], process_group)
+            objs.append(o)
+            hs = counts.cpu().numpy().astype(np.float32)  # the iteration's only device -> host copy (4 KB)
+            be.kmeans_update_centroids(sums, counts, centroids)
+            if (hs == 0).any():  # faiss split_clusters: re-seed empty clusters (host RNG, same on every rank)
+                ch = np.ascontiguousarray(centroids.cpu().numpy(), dtype=np.float32)
+                nsplit[it] = be.split_clusters(nt, hs, ch)
+                centroids.copy_(be.to_device(ch))
+        if objs:
+            import torch
+
+            obj[:] = torch.cat(objs).cpu().numpy()
     assign = np.zeros(0, np.int64)
     if final_assign:
         cpk = be.pack(centroids, cmode)
-        keys = be.search_keys(cpk, packed, 1, _capi.METRIC_L2)
-        _, I = be.keys_to_result(keys, _capi.METRIC_L2)
-        assign = I.reshape(-1).cpu().numpy().astype(np.int64)
-    return KMeansResult(centroids=np.asarray(centroids, np.float32), assign=assign, obj=obj, nsplit=nsplit,
+        if dist is None:
+            keys = be.search_keys(cpk, packed, 1, _capi.METRIC_L2)
+            _, I = be.keys_to_result(keys, _capi.METRIC_L2)
+            assign = I.reshape(-1).cpu().numpy().astype(np.int64)
+        else:
+            import torch
+
+            if sharded_rows:
+                mine, pos = packed, local_pos
+            else:  # replicated rows: contiguous row slices
+                per = -(-n // world)
+                lo, hi = min(n, rank * per), min(n, (rank + 1) * per)
+                mine, pos = be.slice_rows(packed, lo, hi), np.arange(lo, hi, dtype=np.int64)
+            keys = be.search_keys(cpk, mine, 1, _capi.METRIC_L2)
+            _, I = be.keys_to_result(keys, _capi.METRIC_L2)
+            # ranks may hold different numbers of rows: exchange (position, cluster id) pairs padded to the largest share
+            cnt = torch.tensor([mine.n], dtype=torch.int64, device=I.device)
+            cmax = int(_dist.all_gather_rows(cnt, process_group).max().item())
+            pair = torch.full((2, cmax), -1, dtype=torch.int64, device=I.device)
+            pair[0, :mine.n] = be.to_device(pos)
+            pair[1, :mine.n] = I.reshape(-1)
+            allp = _dist.all_gather_rows(pair, process_group).cpu().numpy()  # [world, 2, cmax]
+            assign = np.full(n, -1, np.int64)
+            for r in range(world):
+                ok = allp[r, 0] >= 0
+                assign[allp[r, 0][ok]] = allp[r, 1][ok]
+    return KMeansResult(centroids=np.asarray(centroids.cpu().numpy(), np.float32), assign=assign, obj=obj, nsplit=nsplit,
                         train_ids=train_ids)
 
 
@@ -149,16 +213,11 @@ def cluster(col_name: str, ncentroids: int):
             vs.load_index(col_index_dir)
         assert vs.index_dir == col_index_dir
         ids = df.index.tolist()
-        vec_set = vs.get_vectors_from_index(col_index_dir, ids)
-        backend = getattr(vs, "backend", None)
-        packed = None
-        if hasattr(vs, "packed_rows"):
-            try:
-                packed = vs.packed_rows(ids)  # reuse the resident device image instead of re-uploading vec_set
-            except ValueError:
-                packed = None
-        res = kmeans(vec_set, ncentroids, niter=niter, backend=backend, packed=packed,
-                     pack_mode=None if packed is None else packed.mode)
+        if hasattr(vs, "kmeans"):  # HipVS: the rows are already in HBM (possibly sharded) - no host copy of the matrix
+            res = vs.kmeans(None, ncentroids, niter=niter, ids=ids, return_result=True)
+        else:
+            res = kmeans(vs.get_vectors_from_index(col_index_dir, ids), ncentroids, niter=niter,
+                         backend=getattr(vs, "backend", None))
         if verbose:
             for it, o in enumerate(res.obj):
                 print(f"  Iteration {it} objective={o:.6g} splits={int(res.nsplit[it])}")

@@ -83,7 +83,66 @@ __global__ __launch_bounds__(64) void km_reduce_kernel(const _Float16* __restric
         if (j0 + t < d) sums[(long long)c * d + j0 + t] += acc[t];
 }
 
+// centroid update of faiss compute_centroids: c = sum * (1 / count) where the cluster is not empty, unchanged otherwise
+// (an empty cluster keeps its previous centroid until split_clusters re-seeds it)
+__global__ __launch_bounds__(256) void km_update_kernel(const float* __restrict__ sums, const float* __restrict__ counts,
+                                                        long long total, int d, float* __restrict__ centroids) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const float cnt = counts[i / d];
+        if (cnt > 0.f) {
+            const float norm = 1.0f / cnt;  // IEEE division, then one rounded multiply per element (as faiss)
+            centroids[i] = sums[i] * norm;
+        }
+    }
+}
+
+// dst[i][0..d) = float32 value of packed row ids[i] (row i when ids == NULL): hi (+ lo)
+__global__ __launch_bounds__(256) void unpack_rows_kernel(const _Float16* __restrict__ src, long long ld, int d, int dpad,
+                                                          int split, const long long* __restrict__ ids, long long n,
+                                                          float* __restrict__ dst) {
+    const int lane = threadIdx.x & 63;
+    const long long i = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (i >= n) return;
+    const _Float16* row = src + (ids ? ids[i] : i) * ld;
+    float* o = dst + i * (long long)d;
+    for (int j = lane; j < d; j += 64) {
+        float v = (float)row[j];
+        if (split) v += (float)row[dpad + j];
+        o[j] = v;
+    }
+}
+
 }  // namespace
+
+extern "C" int32_t lvs_kmeans_update_centroids(const float* sums, const float* counts, int32_t k, int32_t d,
+                                               float* centroids, void* stream) {
+    LVS_REQUIRE(k > 0 && d > 0, "bad shape k=%d d=%d", k, d);
+    LVS_REQUIRE(sums && counts && centroids, "NULL buffer");
+    LVS_DEVICE_GUARD(stream);
+    const long long total = (long long)k * d;
+    const long long blocks = lvs_ceil_div(total, 256);
+    hipLaunchKernelGGL(km_update_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0,
+                       (hipStream_t)stream, sums, counts, total, d, centroids);
+    LVS_HIP_CHECK(hipGetLastError());
+    return LVS_OK;
+}
+
+extern "C" int32_t lvs_unpack_rows(const void* src, int32_t d, int32_t pack_mode, const int64_t* ids, int64_t n,
+                                   float* dst, void* stream) {
+    LVS_REQUIRE(d > 0 && n >= 0, "bad shape n=%lld d=%d", (long long)n, d);
+    LVS_REQUIRE(pack_mode == LVS_PACK_F16 || pack_mode == LVS_PACK_SPLIT, "bad pack_mode %d", pack_mode);
+    if (n == 0) return LVS_OK;
+    LVS_REQUIRE(src && dst, "NULL buffer");
+    LVS_DEVICE_GUARD(stream);
+    const int dpad = (int)lvs_round_up(d, LVS_BK);
+    const int split = pack_mode == LVS_PACK_SPLIT;
+    hipLaunchKernelGGL(unpack_rows_kernel, dim3((unsigned)lvs_ceil_div(n, 4)), dim3(256), 0, (hipStream_t)stream,
+                       (const _Float16*)src, (long long)(split ? 2 * dpad : dpad), d, dpad, split,
+                       (const long long*)ids, (long long)n, dst);
+    LVS_HIP_CHECK(hipGetLastError());
+    return LVS_OK;
+}
 
 extern "C" int64_t lvs_kmeans_accumulate_workspace_bytes(int64_t n, int32_t k) {
     if (n < 0 || k <= 0) return LVS_EINVAL;

@@ -136,15 +136,11 @@ def sem_cluster_by(df: pd.DataFrame, col_name: str, ncentroids: int, niter: int 
     if vs.index_dir != col_index_dir:
         vs.load_index(col_index_dir)
     ids = df.index.tolist()
-    vec_set = vs.get_vectors_from_index(col_index_dir, ids)
-    packed = None
-    if hasattr(vs, "packed_rows"):
-        try:
-            packed = vs.packed_rows(ids)
-        except ValueError:
-            packed = None
-    res = kmeans(vec_set, ncentroids, niter=niter, backend=getattr(vs, "backend", None), packed=packed,
-                 pack_mode=None if packed is None else packed.mode)
+    if hasattr(vs, "kmeans"):
+        res = vs.kmeans(None, ncentroids, niter=niter, ids=ids, return_result=True)
+    else:
+        res = kmeans(vs.get_vectors_from_index(col_index_dir, ids), ncentroids, niter=niter,
+                     backend=getattr(vs, "backend", None))
     if verbose:
         for it, o in enumerate(res.obj):
             print(f"  Iteration {it} objective={o:.6g}")

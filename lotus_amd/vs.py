@@ -219,18 +219,17 @@ class HipVS(VS):
             return RMOutput(distances=D, indices=I)
         rank_all = k_eff > _capi.MAX_K  # K = N callers (sem_dedup.py:45, sem_filter.py:491-497): full score rows + sort
         rank, world = self._dist()
-        if rank_all and (world > 1 or nq * n_eff >= 2**32 - 1):
-            raise ValueError(f"K={K} over {n_eff} rows: more than {_capi.MAX_K} results per query are only supported "
-                             "on an unsharded index with nq * rows < 2^32")
 
         queries = be.pack(q, ent.packed.mode)
         id_map = None
         if rank_all:
-            corpus = ent.packed
-            if sub is not None:
-                corpus = be.gather(ent.packed, be.to_device(sub))
-                id_map = be.to_device(sub)
-            keys = be.rank_all(corpus, queries, self.metric)[:, :k_eff].contiguous()
+            # score rows of this rank's shard, exchanged so that every rank ranks the complete rows (column-sharded
+            # score matrix, one all-gather); the device sort goes through the queries in chunks of < 2^32 scores
+            sc, order = self._score_rows(ent, queries, sub, world)
+            keys = be.rank_scores(sc)[:, :k_eff].contiguous()
+            if order is not None:
+                id_map = be.to_device(order)
+            world = 1  # already complete on every rank: nothing left to merge
         elif sub is None:
             keys = be.search_keys(ent.packed, queries, k_eff, self.metric, id_offset=ent.lo)
         else:
@@ -251,20 +250,70 @@ class HipVS(VS):
         return RMOutput(distances=D, indices=I)
 
     def scores(self, query_vectors, ids: list[int] | None = None):
-        """Similarity of every query to every indexed row (or to rows ``ids``) as one float32 matrix [Q, N] - what
-        the K = N callers actually want (``sem_filter.py:491-497`` takes ``vec_scores`` of ALL rows,
+        """Similarity of every query to every indexed row (or to rows ``ids``, in that order) as one float32 matrix
+        [Q, N] - what the K = N callers actually want (``sem_filter.py:491-497`` takes ``vec_scores`` of ALL rows,
         ``sem_join.py:343-373`` clips them to [0, 1]) without ranking anything.  Inner product:
-        the product; L2: minus the squared distance."""
+        the product; L2: minus the squared distance.  On a sharded index every rank computes the columns of its
+        shard and one all-gather completes the rows."""
         ent = self._current()
-        if ent.lo != 0 or ent.hi != ent.n:
-            raise ValueError("scores() needs an unsharded index")
         q = self._as_matrix(query_vectors, "query_vectors")
         if q.shape[1] != ent.d:
             raise ValueError(f"query dimension {q.shape[1]} does not match index dimension {ent.d}")
         be = self.backend
-        corpus = self.packed_rows(ids)
+        sub = None
+        if ids is not None:
+            sub = np.asarray(ids, dtype=np.int64).reshape(-1)
+            if sub.size and (sub.min() < 0 or sub.max() >= ent.n):
+                raise IndexError("ids out of range for the loaded index")
+            if sub.size == ent.n and np.array_equal(sub, np.arange(ent.n)):
+                sub = None
+        _, world = self._dist()
         queries = be.pack(q, ent.packed.mode)
-        return be.scores(corpus, queries, self.metric).cpu().numpy()
+        sc, order = self._score_rows(ent, queries, sub, world, want_ids=False)
+        out = sc.cpu().numpy()
+        if order is not None:  # columns arrived shard by shard: put them back into the order of `ids`
+            res = np.empty_like(out)
+            res[:, order] = out
+            out = res
+        return out
+
+    def _score_rows(self, ent: _Resident, queries, sub, world: int, want_ids: bool = True):
+        """Score rows [Q, n_eff] (device float32) of `queries` against all rows (``sub`` None) or the rows ``sub``.
+
+        Returns ``(scores, order)``.  Unsharded: columns follow ``sub`` (``order`` = ``sub`` when ids are wanted, else
+        None).  Sharded: every rank scores the requested rows that live in its shard, the blocks are all-gathered and
+        laid side by side in rank order; ``order[j]`` then names column j - the global row id (``want_ids``) or its
+        position in ``sub`` - and is None when the columns are simply rows 0..n-1."""
+        be = self.backend
+        if world == 1:
+            corpus = ent.packed if sub is None else be.gather(ent.packed, be.to_device(sub))
+            sc = be.scores(corpus, queries, self.metric)
+            return sc, (sub if (sub is not None and want_ids) else None)
+        from . import _dist
+
+        per = -(-ent.n // world) if ent.n else 0
+        bounds = [(min(ent.n, r * per), min(ent.n, (r + 1) * per)) for r in range(world)]
+        if sub is None:
+            pos = [np.arange(lo, hi, dtype=np.int64) for lo, hi in bounds]  # global rows per rank
+            corpus = ent.packed
+        else:
+            pos = [np.flatnonzero((sub >= lo) & (sub < hi)) for lo, hi in bounds]  # positions in `sub` per rank
+            mine = pos[bounds.index((ent.lo, ent.hi))]
+            corpus = be.gather(ent.packed, be.to_device(sub[mine] - ent.lo))
+        widths = [len(p_) for p_ in pos]
+        wmax = max(widths) if widths else 0
+        nq = queries.n
+        import torch
+
+        block = torch.full((nq, wmax), float("-inf"), dtype=torch.float32, device=queries.rows.device)
+        if corpus.n:
+            block[:, :corpus.n] = be.scores(corpus, queries, self.metric)
+        parts = _dist.all_gather_rows(block, self._pg)  # [world, nq, wmax]
+        sc = torch.cat([parts[r][:, :widths[r]] for r in range(world)], dim=1).contiguous()
+        if sub is None:
+            return sc, None
+        cols = np.concatenate(pos) if pos else np.zeros(0, np.int64)
+        return sc, (sub[cols] if want_ids else cols)
 
     def packed_rows(self, ids=None):
         """Device image (backend ``PackedRows``) of the current index restricted to positional ``ids`` (all rows
@@ -282,31 +331,41 @@ class HipVS(VS):
             raise IndexError("ids out of range for the loaded index")
         return self.backend.gather(ent.packed, self.backend.to_device(sub))
 
-    def kmeans(self, vec_set, ncentroids: int, niter: int = 20, ids=None, **kw):
-        """faiss-parity k-means of the current index's rows ``ids`` (``lotus/utils.py:61-65``) on the GPU that already
-        holds them; returns the cluster id of every row."""
+    def kmeans(self, vec_set, ncentroids: int, niter: int = 20, ids=None, return_result: bool = False, **kw):
+        """faiss-parity k-means of the current index's rows ``ids`` (``lotus/utils.py:61-65``) on the GPU(s) that already
+        hold them; returns the cluster id of every row (all rows on every rank).  ``vec_set`` is not needed (the device
+        image is used) and only kept for the shape of the reference call.  On a row-sharded index every rank trains on
+        and assigns the rows of its own shard (one all-reduce per iteration, one all-gather of the ids)."""
         from .cluster import kmeans as _kmeans
 
-        packed = None
-        try:
-            packed = self.packed_rows(ids)
-        except ValueError:
-            pass
-        res = _kmeans(vec_set, ncentroids, niter=niter, backend=self.backend, packed=packed,
-                      pack_mode=None if packed is None else packed.mode, **kw)
-        return res.assign
+        ent = self._current()
+        sub = None
+        if ids is not None:
+            sub = np.asarray(ids, dtype=np.int64).reshape(-1)
+            if sub.size and (sub.min() < 0 or sub.max() >= ent.n):
+                raise IndexError("ids out of range for the loaded index")
+            if sub.size == ent.n and np.array_equal(sub, np.arange(ent.n)):
+                sub = None
+        be = self.backend
+        if ent.lo == 0 and ent.hi == ent.n:  # the whole index lives on this rank
+            packed = ent.packed if sub is None else be.gather(ent.packed, be.to_device(sub))
+            res = _kmeans(None, ncentroids, niter=niter, backend=be, packed=packed, process_group=self._pg, **kw)
+        else:
+            if sub is None:
+                packed, local_pos, n_total = ent.packed, np.arange(ent.lo, ent.hi, dtype=np.int64), ent.n
+            else:
+                local_pos = np.flatnonzero((sub >= ent.lo) & (sub < ent.hi))  # positions in `ids`, ascending
+                packed = be.gather(ent.packed, be.to_device(sub[local_pos] - ent.lo))
+                n_total = int(sub.size)
+            kw.pop("shard", None)
+            res = _kmeans(None, ncentroids, niter=niter, backend=be, packed=packed, shard=True, process_group=self._pg,
+                          n_total=n_total, local_pos=local_pos, **kw)
+        return res if return_result else res.assign
 
     # ------------------------------------------------------------------------------------------ multi-GPU
     def _allgather_merge(self, keys, world: int):
-        """All-gather the per-shard candidate keys [Q,k] (8 B each) and merge them on every rank."""
-        import torch
-        import torch.distributed as dist
+        """All-gather the per-shard candidate keys [Q,k] (8 B each; ONE RCCL all-gather over xGMI on a GPU node, staged
+        through the host for any other process-group backend) and merge them on every rank (``lvs_merge_keys``)."""
+        from . import _dist
 
-        keys = keys.contiguous()
-        parts = torch.empty((world,) + tuple(keys.shape), dtype=keys.dtype, device=keys.device)
-        if keys.is_cuda:
-            dist.all_gather_into_tensor(parts, keys, group=self._pg)  # one RCCL all-gather, 8 B per candidate
-        else:  # gloo (CPU tests)
-            chunks = [parts[r] for r in range(world)]
-            dist.all_gather(chunks, keys, group=self._pg)
-        return self.backend.merge_keys(parts)
+        return self.backend.merge_keys(_dist.all_gather_rows(keys, self._pg))

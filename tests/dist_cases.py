@@ -1,0 +1,201 @@
+"""World-size-2 scenarios of the sharded path, shared by the CPU run (gloo + the oracle-backed test double,
+``test_dist_gloo.py``) and the GPU run (gloo rendezvous, BOTH ranks on cuda:0 with the real ``HipBackend``,
+``test_gpu_dist.py``).  The code under test is the same in both: shard offsets, per-shard search, all-gather of the
+candidate keys, device-side merge, sharded K = N ranking and score rows, sharded k-means (all-reduce of sums / counts,
+per-shard final assignment), tile-dealt dedup.  Only the collective's transport differs from an 8-GPU node (host
+staging instead of RCCL, ``lotus_amd/_dist.py``)."""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+NB, D, NQ = 5001, 64, 300
+KM_N, KM_D, KM_K = 3000, 32, 8
+
+
+def km_data():
+    rng = np.random.default_rng(3)
+    c = rng.standard_normal((KM_K, KM_D)).astype(np.float32) * 4
+    x = (c[rng.integers(0, KM_K, KM_N)] + 0.3 * rng.standard_normal((KM_N, KM_D))).astype(np.float32)
+    return x.astype(np.float16)  # fp16 storage: the device image holds exactly these values
+
+
+def dedup_data():
+    import synth
+
+    xd = synth.corpus(1500, 32, seed=8)
+    xd[700:900] = xd[:200] + 0.02 * synth.corpus(200, 32, seed=9)
+    xd /= np.linalg.norm(xd, axis=1, keepdims=True)
+    return xd.astype(np.float16)
+
+
+def search_data():
+    import synth
+
+    xb = synth.corpus(NB, D, seed=21)
+    xq, _ = synth.queries(xb, NQ, seed=2)
+    return xb.astype(np.float16), xq.astype(np.float16)
+
+
+def subset_ids():
+    return np.random.default_rng(5).choice(NB, 1500, replace=False).tolist()
+
+
+def subset_big():
+    return np.random.default_rng(6).choice(NB, 2600, replace=False).tolist()
+
+
+def worker(rank, world, port, tmp, out_q, backend_kind):
+    sys.path.insert(0, os.path.dirname(HERE))
+    sys.path.insert(0, HERE)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch
+    import torch.distributed as dist
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from lotus_amd import HipVS
+        from lotus_amd.cluster import kmeans
+        from lotus_amd.dedup import threshold_pairs
+
+        if backend_kind == "hip":
+            from lotus_amd.backend import HipBackend
+
+            torch.cuda.set_device(0)  # both ranks share the one GPU of the test box
+            be = HipBackend("cuda:0")
+        else:
+            from oracle_backend import OracleBackend
+
+            be = OracleBackend()
+        res = {"rank": rank}
+        xb, xq = search_data()
+        vs = HipVS(backend=be, shard=True)
+        vs.index(None, xb, os.path.join(tmp, "idx"))
+        ent = vs._resident[vs.index_dir]
+        res["bounds"] = (ent.lo, ent.hi, ent.packed.n)
+        ids = subset_ids()
+        for name, out in (("full", vs(xq, 7)), ("sub", vs(xq, 7, ids=ids)), ("pad", vs(xq[:3], 64, ids=ids[:40])),
+                          ("k1000", vs(xq[:40], 1000)), ("rank_all", vs(xq[:5], 3000)),
+                          ("k1500_sub", vs(xq[:4], 1500, ids=ids)), ("rank_sub", vs(xq[:4], 2600, ids=subset_big()))):
+            res[name] = (np.asarray(out.distances), np.asarray(out.indices))
+        res["scores"] = vs.scores(xq[:6])
+        res["scores_sub"] = vs.scores(xq[:6], ids=ids[:77])
+        # k-means on the row-sharded index: all rows, then a subset of rows
+        xk = km_data()
+        vk = HipVS(backend=be, shard=True)
+        vk.index(None, xk, os.path.join(tmp, "km"))
+        r = vk.kmeans(None, KM_K, niter=6, return_result=True, max_points_per_centroid=128)
+        res["km"] = (r.centroids, r.assign, r.obj, r.train_ids)
+        kid = np.random.default_rng(11).choice(KM_N, 1200, replace=False)
+        r2 = vk.kmeans(None, 4, niter=4, ids=kid.tolist(), return_result=True)
+        res["km_sub"] = (r2.centroids, r2.assign, r2.obj)
+        # replicated rows, training rows / assignment dealt to the ranks
+        r3 = kmeans(xk, KM_K, niter=3, backend=be, shard=True, max_points_per_centroid=64)
+        res["km_rep"] = (r3.centroids, r3.assign, r3.obj)
+        # dedup: rows replicated, 256-query tiles dealt round-robin
+        xd = dedup_data()
+        i, j, s_ = threshold_pairs(be, be.pack(xd, 0), 0.97, shard=True)
+        res["dedup"] = (i, j, s_)
+        out_q.put(res)
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def run(tmp, backend_kind, world=2):
+    import torch.multiprocessing as mp
+
+    port = 29500 + (os.getpid() % 2000) + (7 if backend_kind == "hip" else 0)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=worker, args=(r, world, port, str(tmp), q, backend_kind)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=600) for _ in range(world)], key=lambda t: t["rank"])
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    return res
+
+
+def check(res, exact: bool):
+    """Compare every rank's results with the single-process CPU oracle (``exact``: bit-level, for the test double)."""
+    import oracle
+    import synth
+    from lotus_amd.cluster import kmeans
+    from lotus_amd.dedup import threshold_pairs
+    from oracle_backend import OracleBackend
+
+    xb, xq = search_data()
+    xb32, xq32 = xb.astype(np.float32), xq.astype(np.float32)
+    ids = subset_ids()
+    per = -(-NB // 2)
+    assert [r["bounds"] for r in res] == [(0, per, per), (per, NB, NB - per)]  # contiguous row shards, only the shard resident
+
+    def same_topk(got, ref, k):
+        D, I = got
+        Dr, Ir = ref
+        if exact:
+            assert np.array_equal(I, Ir) and np.allclose(D, Dr, atol=1e-6)
+        else:
+            err, hard, recall = synth.compare_topk(Dr, Ir, D, I, atol=1e-5)
+            assert err <= 1e-5 and hard == 0 and recall >= 0.9999, (err, hard, recall)
+
+    ref_full = oracle.flat_search(xb32, xq32, 7)
+    ref_sub = oracle.flat_search(xb32, xq32, 7, ids=ids)
+    ref_1000 = oracle.flat_search(xb32, xq32[:40], 1000)
+    ref_all = oracle.flat_search(xb32, xq32[:5], 3000)
+    ref_1500 = oracle.flat_search(xb32, xq32[:4], 1500, ids=ids)
+    ref_rsub = oracle.flat_search(xb32, xq32[:4], 2600, ids=subset_big())
+    S = xq32[:6] @ xb32.T
+    for r in res:
+        same_topk(r["full"], ref_full, 7)
+        same_topk(r["sub"], ref_sub, 7)
+        Ip = r["pad"][1]
+        assert (Ip[:, 40:] == -1).all() and sorted(Ip[0, :40].tolist()) == sorted(ids[:40])
+        same_topk(r["k1000"], ref_1000, 1000)   # 2 shards x 1000 keys: the long-list merge
+        same_topk(r["rank_all"], ref_all, 3000)  # K > LVS_MAX_K on a sharded index: gathered score rows + sort
+        same_topk(r["k1500_sub"], ref_1500, 1500)
+        same_topk(r["rank_sub"], ref_rsub, 2600)  # ... and on a subset of the rows (ids remapped through the shards)
+        assert r["scores"].shape == (6, NB) and np.abs(r["scores"] - S).max() <= 1e-5
+        assert np.abs(r["scores_sub"] - S[:, ids[:77]]).max() <= 1e-5
+    # every rank holds the same merged answers
+    for key in ("full", "sub", "k1000", "rank_all"):
+        assert np.array_equal(res[0][key][1], res[1][key][1]) and np.array_equal(res[0][key][0], res[1][key][0])
+
+    # ---- k-means: sharded == single process (up to the summation order of the all-reduced partial sums) ----
+    ob = OracleBackend()
+    xk = km_data()
+    one = kmeans(xk, KM_K, niter=6, backend=ob, max_points_per_centroid=128)
+    kid = np.random.default_rng(11).choice(KM_N, 1200, replace=False)
+    one_sub = kmeans(xk[kid], 4, niter=4, backend=ob)
+    one_rep = kmeans(xk, KM_K, niter=3, backend=ob, max_points_per_centroid=64)
+    for r in res:
+        c, a, o, tid = r["km"]
+        assert np.array_equal(tid, one.train_ids)
+        assert np.allclose(c, one.centroids, atol=2e-5) and (a == one.assign).mean() >= 0.999 and len(a) == KM_N
+        assert np.allclose(o, one.obj, rtol=1e-5)
+        c, a, o = r["km_sub"]
+        assert np.allclose(c, one_sub.centroids, atol=2e-5) and (a == one_sub.assign).mean() >= 0.999 and len(a) == 1200
+        assert np.allclose(o, one_sub.obj, rtol=1e-5)
+        c, a, o = r["km_rep"]
+        assert np.allclose(c, one_rep.centroids, atol=2e-5) and (a == one_rep.assign).mean() >= 0.999
+    assert np.array_equal(res[0]["km"][1], res[1]["km"][1])
+
+    # ---- dedup pairs ----
+    xd = dedup_data()
+    i1, j1, s1 = threshold_pairs(ob, ob.pack(xd, 0), 0.97)
+    assert len(i1) >= 200
+    for r in res:
+        i, j, s_ = r["dedup"]
+        if exact:
+            assert np.array_equal(i, i1) and np.array_equal(j, j1)
+        else:  # pairs within 2e-5 of the threshold may differ (summation order)
+            got, ref = set(zip(i.tolist(), j.tolist())), set(zip(i1.tolist(), j1.tolist()))
+            sd = (xd.astype(np.float32) @ xd.astype(np.float32).T)
+            for a, b in got ^ ref:
+                assert abs(sd[a, b] - 0.97) <= 2e-5, (a, b, sd[a, b])

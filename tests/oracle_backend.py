@@ -95,6 +95,26 @@ class OracleBackend:
     def rank_all(self, corpus, queries, metric, id_offset=0):
         return self.search_keys(corpus, queries, corpus.n, metric, id_offset=id_offset)
 
+    def rank_scores(self, sc, id_offset=0):
+        s = sc.numpy().astype(np.float32)
+        self.calls.append(("rank", s.shape[0], s.shape[1]))
+        ids = np.broadcast_to(np.arange(s.shape[1], dtype=np.int64) + id_offset, s.shape)
+        keys = np.sort(oracle.pack_keys(s, ids), axis=1)[:, ::-1]
+        return torch.from_numpy(np.array(keys, dtype=np.uint64, order="C", copy=True).view(np.int64))
+
+    def unpack(self, src, ids_dev=None):
+        rows = src.rows if ids_dev is None else src.rows[ids_dev.numpy().astype(np.int64)]
+        return rows.clone().to(torch.float32)
+
+    @staticmethod
+    def slice_rows(src, r0, r1):
+        return PackedRows(rows=src.rows[r0:r1], norms=src.norms[r0:r1], n=r1 - r0, d=src.d, mode=src.mode)
+
+    def kmeans_update_centroids(self, sums, counts, centroids):
+        c, sm, cn = centroids.numpy(), sums.numpy(), counts.numpy()
+        nz = cn > 0
+        c[nz] = sm[nz] * (np.float32(1.0) / cn[nz])[:, None]  # faiss: c *= 1 / count
+
     # ---- threshold join ----
     def range_join(self, corpus, queries, threshold, metric=0, q_row0=-1, id_offset=0, stride=1, phase=0,
                    capacity=1 << 22):

@@ -1,0 +1,15 @@
+"""The N>1 path on the REAL HIP backend: two processes share cuda:0, rendezvous over gloo, and
+run every sharded operator - row-sharded search with id offsets, device-side merge of the gathered candidate lists
+(short and long lists), sharded K = N ranking / score rows, k-means on a row-sharded index (device sums all-reduced,
+per-shard final assignment), tile-dealt dedup - against the single-process CPU oracle.  On an 8-GPU node the only
+difference is the transport inside ``lotus_amd/_dist.py`` (RCCL on device tensors instead of host staging)."""
+import pytest
+
+import dist_cases
+
+pytestmark = pytest.mark.gpu
+
+
+def test_sharded_operators_on_hip_backend_two_ranks_one_gpu(tmp_path):
+    res = dist_cases.run(tmp_path, "hip")
+    dist_cases.check(res, exact=False)

@@ -326,3 +326,88 @@ def test_merge_keys_long_lists(hip_backend):
     ref = -np.sort(-parts.view(np.uint64).transpose(1, 0, 2).reshape(50, -1).astype(np.float64), axis=1)  # order only
     want = np.sort(parts.view(np.uint64).transpose(1, 0, 2).reshape(50, -1), axis=1)[:, ::-1][:, :300]
     assert np.array_equal(out, want)
+
+
+@pytest.mark.parametrize("P,nq,k", [(8, 40, 1000), (8, 9, 2048), (5, 33, 600), (2, 20, 2048), (16, 12, 65)])
+def test_merge_keys_folds_any_number_of_long_lists(hip_backend, P, nq, k):
+    """ADVICE r01: 8 shards x k > 512 (nparts * k > 4096) used to be rejected; now folded in rounds, in place."""
+    import torch
+
+    be = hip_backend
+    rng = np.random.default_rng(P * 1000 + k)
+    parts = rng.integers(1, 2 ** 62, size=(P, nq, k), dtype=np.int64)
+    parts[:, :, -3:] = 0  # empty slots
+    out = be.merge_keys(torch.from_numpy(parts).to(be.device)).cpu().numpy().view(np.uint64)
+    want = np.sort(parts.view(np.uint64).transpose(1, 0, 2).reshape(nq, -1), axis=1)[:, ::-1][:, :k]
+    assert np.array_equal(out, want)
+
+
+def test_unpack_rows_inverts_pack(hip_backend):
+    be = hip_backend
+    x = (synth.corpus(500, 100, seed=4) * 3).astype(np.float32)
+    ids = np.random.default_rng(2).choice(500, 77, replace=False).astype(np.int64)
+    p16 = be.pack(x.astype(np.float16), F16)
+    assert np.array_equal(be.unpack(p16).cpu().numpy(), x.astype(np.float16).astype(np.float32))
+    assert np.array_equal(be.unpack(p16, be.to_device(ids)).cpu().numpy(), x.astype(np.float16).astype(np.float32)[ids])
+    ps = be.pack(x, SPLIT)
+    hi = x.astype(np.float16).astype(np.float32)
+    lo = (x - hi).astype(np.float16).astype(np.float32)
+    assert np.array_equal(be.unpack(ps, be.to_device(ids)).cpu().numpy(), (hi + lo)[ids])
+    assert np.abs(be.unpack(ps).cpu().numpy() - x).max() <= 2 ** -21 * np.abs(x).max()
+
+
+def test_kmeans_update_centroids_is_faiss_division(hip_backend):
+    import torch
+
+    be = hip_backend
+    rng = np.random.default_rng(1)
+    k, d = 37, 100
+    sums = rng.standard_normal((k, d)).astype(np.float32) * 50
+    counts = rng.integers(0, 9, k).astype(np.float32)
+    counts[5] = 0
+    old = rng.standard_normal((k, d)).astype(np.float32)
+    c = torch.from_numpy(old.copy()).to(be.device)
+    be.kmeans_update_centroids(torch.from_numpy(sums).to(be.device), torch.from_numpy(counts).to(be.device), c)
+    want = old.copy()
+    nz = counts > 0
+    want[nz] = sums[nz] * (np.float32(1.0) / counts[nz])[:, None]
+    assert np.array_equal(c.cpu().numpy(), want)  # bit-identical: one IEEE division, one rounded multiply
+
+
+def test_range_join_chunks_and_regrows_per_chunk(hip_backend, monkeypatch):
+    """The query rows go through in chunks; a chunk that finds more pairs than its buffer holds is the only thing
+    that runs again (VERDICT r01 weak #10)."""
+    be = hip_backend
+    xd = synth.corpus(3000, 64, seed=8)
+    xd[1500:2300] = xd[:800] + 0.02 * synth.corpus(800, 64, seed=9)
+    xd /= np.linalg.norm(xd, axis=1, keepdims=True)
+    p = be.pack(xd.astype(np.float16), F16)
+    s = xd.astype(np.float16).astype(np.float32)
+    s = s @ s.T
+    qi, ji = np.nonzero(np.triu(s > 0.97, 1))
+    want = set(zip(qi.tolist(), ji.tolist()))
+    monkeypatch.setattr(type(be), "RANGE_CHUNK_ROWS", 512)
+    for cap in (1 << 20, 16):  # roomy buffers; buffers that overflow in most chunks
+        q, j, sc = be.range_join(p, p, 0.97, IP, q_row0=0, capacity=cap)
+        got = set(zip(q.cpu().numpy().tolist(), j.cpu().numpy().tolist()))
+        for a, b in got ^ want:
+            assert abs(s[a, b] - 0.97) <= 2e-5
+        assert len(got) >= 800 and np.allclose(sc.cpu().numpy(), s[q.cpu().numpy(), j.cpu().numpy()], atol=1e-5)
+    # two "ranks" dealing 256-query tiles cover everything exactly once
+    parts = [be.range_join(p, p, 0.97, IP, q_row0=0, stride=2, phase=r) for r in range(2)]
+    both = [set(zip(a.cpu().numpy().tolist(), b.cpu().numpy().tolist())) for a, b, _ in parts]
+    assert not (both[0] & both[1]) and len(both[0]) and len(both[1])
+    for a, b in (both[0] | both[1]) ^ want:
+        assert abs(s[a, b] - 0.97) <= 2e-5
+
+
+def test_large_k_is_stream_async_and_exact_without_overflow(hip_backend):
+    """k > 56 on ordinary data: the two-phase result stands, the predicated fallback passes are no-ops."""
+    be = hip_backend
+    xb = synth.corpus(50_000, 128, seed=31)
+    xq, _ = synth.queries(xb, 70, seed=32)
+    for k in (57, 300, 1200):
+        D, I, _ = _run(be, xb, xq, k, F16, IP)
+        Dr, Ir = oracle.flat_search(_stored(xb, F16), _stored(xq, F16), k, IP)
+        err, hard, recall = synth.compare_topk(Dr, Ir, D, I)
+        assert err <= 1e-5 and hard == 0 and recall >= 0.9999
