@@ -9,13 +9,22 @@ candidate keys (8 B each) and a merge + decode give every rank the final (D, I).
 the timed region; total work is fixed as N grows ("strong" scaling).
 
 Prints ONE JSON line on rank 0 (see the contract in the task statement): value = Q * steps / time in queries/s.
-Extra objects: "roofline" (dominant kernel vs the dense fp16 MFMA peak, timed with HIP events on the launch stream)
-and, at N=1, "cpu_baseline" (the CPU oracle timed on a bounded sample of the same workload on this host) and
-"recall_at_k" of the GPU result against that oracle sample.
+Extra objects:
+  "roofline"      dominant kernel vs the dense fp16 MFMA peak, timed with HIP events on the launch stream;
+                  `traffic` = HBM-side bytes per launch from the committed rocprofv3 PMC passes, reported only when the
+                  kernel sources are byte-identical to the ones the counters were collected on (else null);
+  "cpu_baseline"  (N=1) the CPU comparator (oracle/blas_twin.py: faiss's BLAS path on torch-CPU, all host cores) timed on a
+                  bounded sample of the same workload;
+  "recall_at_k" / "id_mismatches_outside_near_ties" / "max_abs_score_err": the GPU result of the LAST timed step checked
+                  against the CPU oracle (oracle/flat.py) on a query sample - at every N, rank 0;
+  "legs"          (N=1) short secondary measurements in the same process: BASELINE configs[1] (10k x 1M), the literal
+                  single-query sem_search (HBM-bound streaming kernel), the 8-GPU shard shape (100k x 125k) and T_call
+                  (`HipVS.__call__` host ndarray -> host (D, I), PCIe included) - each with kernel ms and roofline fraction.
 """
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -37,8 +46,10 @@ def parse():
     ap.add_argument("--corpus", type=int, default=1_000_000)
     ap.add_argument("--dim", type=int, default=768)
     ap.add_argument("--k", type=int, default=10)
-    ap.add_argument("--cpu-sample", type=int, default=2048, help="queries in the CPU-oracle sample (N=1 only)")
+    ap.add_argument("--cpu-sample", type=int, default=4096, help="queries timed on the CPU comparator (N=1 only)")
+    ap.add_argument("--check-sample", type=int, default=512, help="queries re-checked against the CPU oracle (rank 0)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-legs", action="store_true", help="skip the secondary legs (N=1)")
     return ap.parse_args()
 
 
@@ -57,6 +68,17 @@ def make_data(torch, device, n, d, nq):
     u = torch.nn.functional.normalize(torch.randn((nq, d), generator=g, device=device, dtype=torch.float32), dim=1)
     xq = torch.nn.functional.normalize(0.7 * xb[j].float() + 0.7 * u, dim=1).to(torch.float16)
     return xb, xq, j
+
+
+def csrc_hash() -> str:
+    """sha256 over the kernel sources + the C-ABI header: ties committed counter data to the binary that ran."""
+    h = hashlib.sha256()
+    base = os.path.join(ROOT, "lotus_amd", "csrc")
+    names = sorted(f for f in os.listdir(base) if f.endswith((".hip", ".h")))
+    for p in [os.path.join(base, f) for f in names] + [os.path.join(ROOT, "include", "lotus_hip.h")]:
+        with open(p, "rb") as f:
+            h.update(os.path.basename(p).encode() + b"\0" + f.read())
+    return h.hexdigest()[:16]
 
 
 def main():
@@ -81,7 +103,7 @@ def main():
     if world > 1:
         dist.init_process_group("nccl", device_id=device)  # RCCL
 
-    from lotus_amd import _capi
+    from lotus_amd import _capi, _dist
     from lotus_amd.backend import HipBackend
 
     be = HipBackend(device)
@@ -91,15 +113,13 @@ def main():
     lo, hi = min(n, rank * per), min(n, (rank + 1) * per)
     corpus = be.pack(xb[lo:hi], _capi.PACK_F16)  # this rank's shard, resident
     queries = be.pack(xq, _capi.PACK_F16)  # replicated
-    if world > 1:
-        del xb  # only the shard stays
-    parts = torch.empty((world, nq, k), dtype=torch.int64, device=device) if world > 1 else None
+    if world > 1 and rank != 0:
+        del xb  # only the shard stays (rank 0 keeps the rows for the oracle check after the timed region)
 
     def step():
         keys = be.search_keys(corpus, queries, k, _capi.METRIC_IP, id_offset=lo)
         if world > 1:
-            dist.all_gather_into_tensor(parts, keys)
-            keys = be.merge_keys(parts)
+            keys = be.merge_keys(_dist.all_gather_rows(keys))  # one RCCL all-gather of [Q,k] uint64 keys + merge
         return be.keys_to_result(keys, _capi.METRIC_IP)
 
     def barrier():
@@ -126,12 +146,12 @@ def main():
     # ---- sanity on the result (outside the timed region) ----
     planted_at_1 = float((I[:, 0] == planted).float().mean().item())
 
-    out = None
     if rank == 0:
         kernel_ms = ktot_ms / max(1, klaunches)
         flops_per_launch = 2.0 * nq * (hi - lo) * d  # 2*Q*N*d, N = rows of this rank's shard
         achieved = flops_per_launch / (kernel_ms * 1e-3) / 1e12
         alg_bytes = (hi - lo) * d * 2 + nq * d * 2 + nq * k * 12  # 8(d): every input once + outputs once
+        traffic, traffic_src = pmc_traffic(n, nq, world)
         out = {
             "metric": "sem_sim_join queries/sec (d=768, k=10, exact top-k, recall vs CPU oracle)",
             "value": nq * args.steps / dt,
@@ -146,18 +166,24 @@ def main():
             "dtype": "f16",
             "data": "synthetic",
             "config": {"workload": f"sem_sim_join: {nq} left x {n} right rows, d={d} fp16, k={k}, inner product; "
-                                   f"corpus row-sharded over {world} GPU(s), RCCL all-gather top-k merge",
+                                   f"corpus row-sharded over {world} GPU(s), RCCL all-gather top-k merge; "
+                                   "timed device-resident queries -> device-resident (D, I)",
                        "queries": nq, "corpus_rows": n, "dim": d, "k": k, "shard_rows": hi - lo},
             "planted_neighbour_at_rank1": planted_at_1,
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP16_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP16_MFMA_TFLOPS, "traffic": pmc_traffic(n, nq, world),
+                         "frac": achieved / PEAK_FP16_MFMA_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "lvs_tile_kernel<TOPK, 256x256>", "kernel_ms": kernel_ms, "launches": klaunches,
                          "algorithmic_flops_per_launch": flops_per_launch,
                          "algorithmic_bytes_per_launch": alg_bytes,
-                         "hbm_frac_secondary": alg_bytes / (kernel_ms * 1e-3) / 1e9 / PEAK_HBM_GBS},
+                         "hbm_frac_secondary": alg_bytes / (kernel_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                         "csrc_sha": csrc_hash()},
         }
+        if args.check_sample > 0:
+            out.update(oracle_check(np, xb, xq, D, I, args.check_sample, k))
         if world == 1 and not args.no_cpu_baseline:
-            out.update(cpu_baseline(np, torch, xb, xq, D, I, args.cpu_sample, k))
+            out["cpu_baseline"] = cpu_baseline(np, xb, xq, args.cpu_sample, k)
+        if world == 1 and not args.no_legs:
+            out["legs"] = secondary_legs(np, torch, be, _capi, xb, xq, corpus, queries, k)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
@@ -168,56 +194,131 @@ def pmc_traffic(n, nq, world):
     """HBM-side bytes per launch of the tile kernel from the committed rocprofv3 PMC passes of this same command
     (profiles/latest_pmc.json: FETCH_SIZE x 2 x 1024 per the gfx950 correction of MI355X_MICROARCH.md, + WRITE_SIZE x
     1024; separate --pmc runs, tools/pmc_summary.py).  Counters cannot be read from inside the timed process, so the
-    figure is only reported for the configuration it was collected on (1 GPU, default sizes); otherwise null."""
+    figure is a committed measurement - and it is only reported when (i) the configuration is the one it was
+    collected on (1 GPU, default sizes) and (ii) the kernel sources hash to the value stamped at collection time.
+    -> (bytes or None, provenance string)."""
     try:
         with open(os.path.join(ROOT, "profiles", "latest_pmc.json")) as f:
             pmc = json.load(f)
-        if world == 1 and n == 1_000_000 and nq == 100_000:
-            return pmc.get("traffic_bytes_per_launch")
     except Exception:
-        pass
-    return None
+        return None, "no committed PMC summary"
+    if not (world == 1 and n == 1_000_000 and nq == 100_000):
+        return None, "PMC passes exist for the 1-GPU default configuration only"
+    have, want = pmc.get("csrc_sha"), csrc_hash()
+    if have != want:
+        return None, f"profiles/latest_pmc.json was collected on csrc {have}, this build is {want}: stale, not reported"
+    return pmc.get("traffic_bytes_per_launch"), f"profiles/latest_pmc.json ({pmc.get('tag', '?')}, csrc {have})"
 
 
-def cpu_baseline(np, torch, xb, xq, D, I, sample, k):
-    """Time the CPU oracle (faiss-equivalent blocked sgemm + k-best collector, oracle/flat.py) on a bounded sample
-    of the same workload - the first `sample` queries against the WHOLE corpus - and check the GPU result on it."""
+def _near_tie_mismatches(np, Dr, Ir, Ig, k):
+    """ids must match wherever the oracle's neighbouring scores are > 2e-5 apart (near-ties may swap)."""
+    hard = 0
+    for q, r in zip(*np.nonzero(Ir != Ig)):
+        gaps = [abs(float(Dr[q, r]) - float(Dr[q, r - 1]))] if r > 0 else []
+        gaps.append(abs(float(Dr[q, r]) - float(Dr[q, r + 1])) if r + 1 < k else 0.0)
+        hard += min(gaps) > 2e-5
+    return int(hard)
+
+
+def oracle_check(np, xb, xq, D, I, sample, k):
+    """The GPU result of the last timed step against the CPU oracle (oracle/flat.py: 4096 x 1024 sgemm blocks + k-best
+    collector with faiss's tie rule) on the first `sample` queries x the WHOLE corpus.  Runs at every N on rank 0."""
     import oracle
-    from oracle import cbind
 
     sample = min(sample, xq.shape[0])
     xb_h = xb.cpu().numpy().astype(np.float32)  # the same fp16 values, upcast (SURVEY.md 8(c))
     xq_h = xq[:sample].cpu().numpy().astype(np.float32)
-    threads = os.cpu_count() or 1
-    try:
-        from threadpoolctl import threadpool_info
-
-        blas = [p.get("num_threads", 1) for p in threadpool_info() if p.get("user_api") == "blas"]
-        if blas:
-            threads = max(blas)
-    except Exception:
-        pass
-    t0 = time.perf_counter()
     Dr, Ir = oracle.flat_search(xb_h, xq_h, k)
-    dt = time.perf_counter() - t0
     Dg, Ig = D[:sample].cpu().numpy(), I[:sample].cpu().numpy()
     inter = sum(len(set(a.tolist()) & set(b.tolist())) for a, b in zip(Ir, Ig))
-    # ids must match wherever the oracle's neighbouring scores are > 2e-5 apart (near-ties may swap)
-    mism = Ir != Ig
-    hard = 0
-    for q, r in zip(*np.nonzero(mism)):
-        gaps = [abs(float(Dr[q, r]) - float(Dr[q, r - 1]))] if r > 0 else []
-        gaps.append(abs(float(Dr[q, r]) - float(Dr[q, r + 1])) if r + 1 < k else 0.0)
-        hard += min(gaps) > 2e-5
-    return {
-        "cpu_baseline": {"value": sample / dt, "unit": "queries/s", "cores": int(threads), "kind": "port",
-                         "sample": f"first {sample} queries x full {xb_h.shape[0]}-row corpus, d={xb_h.shape[1]}, k={k} "
-                                   f"(oracle/flat.py: 4096x1024 sgemm blocks + C k-best collector), {dt:.1f} s",
-                         "host_cpus": os.cpu_count(), "c_helper_threads": cbind.num_threads() if cbind.available() else 0},
-        "recall_at_k": inter / float(Ir.size),
-        "max_abs_score_err": float(np.abs(Dr - Dg).max()),
-        "id_mismatches_outside_near_ties": int(hard),
-    }
+    return {"recall_at_k": inter / float(Ir.size), "max_abs_score_err": float(np.abs(Dr - Dg).max()),
+            "id_mismatches_outside_near_ties": _near_tie_mismatches(np, Dr, Ir, Ig, k), "oracle_check_queries": sample}
+
+
+def cpu_baseline(np, xb, xq, sample, k):
+    """Time the CPU comparator (oracle/blas_twin.py: query blocks x 65536-row database blocks, one MKL sgemm each,
+    torch.topk as the k-best collector, all host cores) on a bounded sample of the same workload - the first `sample`
+    queries against the WHOLE corpus."""
+    from oracle import blas_twin
+
+    sample = min(sample, xq.shape[0])
+    xb_h = xb.cpu().numpy().astype(np.float32)
+    xq_h = xq[:sample].cpu().numpy().astype(np.float32)
+    t0 = time.perf_counter()
+    _, _, threads = blas_twin.flat_search_blas(xb_h, xq_h, k)
+    dt = time.perf_counter() - t0
+    flops = 2.0 * sample * xb_h.shape[0] * xb_h.shape[1]
+    return {"value": sample / dt, "unit": "queries/s", "cores": int(threads), "kind": "port",
+            "sample": f"first {sample} queries x full {xb_h.shape[0]}-row corpus, d={xb_h.shape[1]}, k={k} "
+                      f"(oracle/blas_twin.py: faiss's BLAS path on torch-CPU, {blas_twin.QUERY_BLOCK} x {blas_twin.DB_BLOCK} sgemm "
+                      f"blocks + topk collector), {dt:.1f} s",
+            "gflops": flops / dt / 1e9, "host_cpus": os.cpu_count()}
+
+
+def secondary_legs(np, torch, be, _capi, xb, xq, corpus, queries, k):
+    """Short measurements of the other regimes of the same path, same process, same resident data (N=1)."""
+    legs = {}
+    d = int(xb.shape[1])
+
+    def kernel_leg(cb, cq, reps, kk=k):
+        for _ in range(2):
+            be.search_keys(cb, cq, kk, _capi.METRIC_IP)
+        be.synchronize()
+        be.timing_enable(True)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            keys = be.search_keys(cb, cq, kk, _capi.METRIC_IP)
+            be.keys_to_result(keys, _capi.METRIC_IP)
+        be.synchronize()
+        wall = (time.perf_counter() - t0) / reps
+        tot, cnt = be.timing_read()
+        be.timing_enable(False)
+        return tot / max(cnt, 1), wall * 1e3
+
+    # BASELINE configs[1]: 10k queries x 1M rows, MFMA-bound
+    q10k = be.slice_rows(queries, 0, min(10_000, queries.n))
+    kms, wms = kernel_leg(corpus, q10k, 5)
+    fl = 2.0 * q10k.n * corpus.n * d
+    legs["cfg2_10k_x_1M"] = {"kernel_ms": kms, "ms_per_call": wms, "queries_per_s": q10k.n / (wms * 1e-3), "bound": "mfma",
+                             "achieved_tflops": fl / (kms * 1e-3) / 1e12, "frac": fl / (kms * 1e-3) / 1e12 / PEAK_FP16_MFMA_TFLOPS}
+    # the literal sem_search: ONE query per call (sem_search.py:121-122) -> lvs_stream_kernel, HBM-bound
+    q1 = be.slice_rows(queries, 0, 1)
+    kms, wms = kernel_leg(corpus, q1, 20)
+    by = corpus.n * int(corpus.rows.shape[1]) * 2.0  # every corpus byte exactly once
+    legs["sem_search_1_x_1M"] = {"kernel_ms": kms, "ms_per_call": wms, "bound": "hbm", "kernel": "lvs_stream_kernel",
+                                 "achieved_gbs": by / (kms * 1e-3) / 1e9, "frac": by / (kms * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                                 "algorithmic_bytes_per_launch": by}
+    q32 = be.slice_rows(queries, 0, 32)
+    kms, wms = kernel_leg(corpus, q32, 20)
+    legs["stream_32_x_1M"] = {"kernel_ms": kms, "ms_per_call": wms, "bound": "hbm", "kernel": "lvs_stream_kernel",
+                              "achieved_gbs": by / (kms * 1e-3) / 1e9, "frac": by / (kms * 1e-3) / 1e9 / PEAK_HBM_GBS}
+    # the 8-GPU shard shape of BASELINE configs[2]: 100k queries x 125k rows per GPU
+    shard = be.slice_rows(corpus, 0, min(corpus.n, 125_000))
+    kms, wms = kernel_leg(shard, queries, 5)
+    fl = 2.0 * queries.n * shard.n * d
+    legs["shard_100k_x_125k"] = {"kernel_ms": kms, "ms_per_call": wms, "bound": "mfma",
+                                 "achieved_tflops": fl / (kms * 1e-3) / 1e12,
+                                 "frac": fl / (kms * 1e-3) / 1e12 / PEAK_FP16_MFMA_TFLOPS,
+                                 "node_queries_per_s_if_8_gpus": queries.n / (kms * 1e-3)}
+    # T_call (SURVEY.md 8(d)): VS.__call__(host ndarray) -> host (D, I), corpus resident; includes packing the queries,
+    # the H2D copy of 154 MB and the D2H copy of the results
+    from lotus_amd.vs import HipVS, _Resident
+
+    vs = HipVS(backend=be, storage="fp16")
+    vs._resident["bench"] = _Resident(vecs=None, packed=corpus, n=corpus.n, d=d, lo=0, hi=corpus.n)
+    vs.index_dir = "bench"
+    xq_h = xq.cpu().numpy()
+    vs(xq_h[:1000], k)
+    ts = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        out = vs(xq_h, k)
+        ts.append(time.perf_counter() - t0)
+    tcall = sorted(ts)[1]
+    assert out.indices.shape == (xq_h.shape[0], k)
+    legs["t_call_host_to_host"] = {"ms_per_call": tcall * 1e3, "queries_per_s": xq_h.shape[0] / tcall,
+                                   "note": "HipVS.__call__(numpy fp16 [Q,d]) -> numpy (D, I); pageable host memory, PCIe included"}
+    return legs
 
 
 if __name__ == "__main__":

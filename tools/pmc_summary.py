@@ -8,6 +8,8 @@ import collections, csv, glob, json, os, sys
 
 src, tag = sys.argv[1], sys.argv[2]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, root)
+from bench import csrc_hash  # noqa: E402
 out_dir = os.path.join(root, "profiles")
 os.makedirs(out_dir, exist_ok=True)
 KERNEL = "lvs_tile_kernel"
@@ -57,5 +59,9 @@ if "SQ_WAVE_CYCLES" in avg:
     for c in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY"):
         if c in avg:
             summary[c.lower() + "_frac"] = avg[c] / avg["SQ_WAVE_CYCLES"]
+summary["tag"] = tag
+summary["csrc_sha"] = csrc_hash()  # bench.py reports `traffic` only while the kernel sources still hash to this
 json.dump(summary, open(os.path.join(out_dir, f"{tag}_pmc.json"), "w"), indent=1)
+if "traffic_bytes_per_launch" in summary:
+    json.dump(summary, open(os.path.join(out_dir, "latest_pmc.json"), "w"), indent=1)
 print(json.dumps(summary, indent=1))

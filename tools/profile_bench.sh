@@ -11,7 +11,7 @@ tag=${1:-prof}
 cd "${GRAFT_REPO_ROOT:-.}"; export TMPDIR=/tmp
 out=gpurun_out/$tag; mkdir -p $out
 python bench.py > $out/bench.json 2> $out/bench.err; tail -c 600 $out/bench.json; echo
-B="python bench.py --steps 3 --warmup 1 --no-cpu-baseline"
+B="python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-legs --check-sample 0"
 timeout -k 5 200 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_stats -o b -- $B > $out/prof_stats.log 2>&1
 for c in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" \
          "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS" \
