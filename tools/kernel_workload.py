@@ -90,9 +90,10 @@ scenario("top1_kmeans_2M_x_1024_fp16c", "lvs_tile_kernel<2, 4>", lambda: be.sear
 # ---- HBM-bound helpers ----
 scenario("km_reduce_4M_x_1024", "km_reduce_kernel", lambda: be.kmeans_accumulate(p4m, assign, 1024), 3, warm=1,
          bytes_per_call=N4 * ld(p4m) * 2)
-scenario("pack_f16_4M", "pack_rows_vec_kernel<_Float16, 0>", lambda: be.pack(x16, F16), 3, warm=1,
+# (rocprofv3 leaves kernels with _Float16 template arguments mangled: match the mangled fragment)
+scenario("pack_f16_4M", "pack_rows_vec_kernelIDF16_Li0", lambda: be.pack(x16, F16), 3, warm=1,
          bytes_per_call=N4 * (D * 2 + ld(p4m) * 2 + 4))
-scenario("pack_f32_hilo_1M", "pack_rows_vec_kernel<float, 1>", lambda: be.pack(x32, SPLIT), 3, warm=1,
+scenario("pack_f32_hilo_1M", "pack_rows_vec_kernelIfLi1", lambda: be.pack(x32, SPLIT), 3, warm=1,
          bytes_per_call=1_000_000 * (D * 4 + 2 * ld(p4m) * 2 + 4))
 scenario("gather_1M_rows", "gather_rows_kernel", lambda: be.gather(p4m, ids1m), 3, warm=1,
          bytes_per_call=1_000_000 * 2 * ld(p4m) * 2)
