@@ -7,6 +7,7 @@ raises if ``liblotus_hip.so`` or a GPU is missing.
 """
 from .compat import RM, VS, RMOutput, HAVE_LOTUS  # noqa: F401
 from .vs import HipVS, METRIC_INNER_PRODUCT, METRIC_L2  # noqa: F401
+from .rm import DeviceRM  # noqa: F401
 
 
 
@@ -31,5 +32,5 @@ def uninstall() -> None:
     _accessor_patch.uninstall()
 
 
-__all__ = ["HipVS", "VS", "RM", "RMOutput", "METRIC_INNER_PRODUCT", "METRIC_L2", "HAVE_LOTUS", "install", "uninstall"]
+__all__ = ["HipVS", "DeviceRM", "VS", "RM", "RMOutput", "METRIC_INNER_PRODUCT", "METRIC_L2", "HAVE_LOTUS", "install", "uninstall"]
 __version__ = "0.1.0"

@@ -1,7 +1,13 @@
 """Opt-in monkey-patch of the reference's pandas accessors (``lotus/sem_ops/sem_sim_join.py:84``,
 ``sem_search.py:91``, ``sem_dedup.py:32``) so that ``df.sem_sim_join(...)`` etc. run the loop-free
 implementations of :mod:`lotus_amd.ops`.  Only active when the configured vector store is a ``HipVS``; any other
-store falls through to the original accessor."""
+store falls through to the original accessor.
+
+The cascade callers reach the hot path THROUGH these accessors - ``sem_filter``'s embedding proxy calls
+``df.sem_search(col, instruction, K=len(df), return_scores=True)`` (``sem_filter.py:491-497``), ``sem_join``'s helper
+calls ``l1_df.sem_sim_join(l2_df, K=len(l2), keep_index=True)`` (``sem_join.py:343-373``), ``sem_topk``'s "quick-sem"
+sorts with ``sem_search(K=len(df))`` (``sem_topk.py:786-788``) - so patching the three accessors is what wires them to
+``HipVS.scores()`` (K = all live rows: one score row, no top-k) and to the full-ranking path."""
 from __future__ import annotations
 
 _saved: dict = {}
@@ -45,9 +51,15 @@ def install() -> None:
             return _saved[SemDedupByDataframe](self, col_name, threshold)
         return ops.sem_dedup(self._obj, col_name, threshold)
 
-    SemSimJoinDataframe.__call__ = sim_join
-    SemSearchDataframe.__call__ = search
-    SemDedupByDataframe.__call__ = dedup
+    # the reference wraps these three in @operator_cache (lotus/cache.py:33): keep that behaviour
+    try:
+        from lotus.cache import operator_cache
+    except Exception:  # pragma: no cover - older checkouts
+        def operator_cache(f):
+            return f
+    SemSimJoinDataframe.__call__ = operator_cache(sim_join)
+    SemSearchDataframe.__call__ = operator_cache(search)
+    SemDedupByDataframe.__call__ = operator_cache(dedup)
 
 
 def uninstall() -> None:

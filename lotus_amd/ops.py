@@ -12,6 +12,11 @@ import pandas as pd
 from . import dedup as _dedup
 
 
+def _is_vectors(x) -> bool:
+    """ndarray or device tensor of ready-made vectors (``rm.py:77-78`` passes ndarrays through; so do we for tensors)."""
+    return isinstance(x, np.ndarray) or (hasattr(x, "is_cuda") and hasattr(x, "data_ptr"))
+
+
 def _settings(rm, vs):
     if rm is None or vs is None:
         try:
@@ -47,10 +52,19 @@ def sem_search(df: pd.DataFrame, col_name: str, query, K: int, rm=None, vs=None,
     if vs.index_dir != col_index_dir:
         vs.load_index(col_index_dir)
     K = min(int(K), len(df))
-    qv = query if isinstance(query, np.ndarray) else rm.convert_query_to_query_vector(query)
-    out = vs(qv, K, ids=df.index.tolist())
-    idx = np.asarray(out.indices)[0]
-    sc = np.asarray(out.distances)[0]
+    qv = query if _is_vectors(query) else rm.convert_query_to_query_vector(query)
+    live = np.asarray(df.index)
+    if K >= len(df) > 0 and hasattr(vs, "scores") and getattr(vs, "metric", 0) == 0:
+        # every live row is wanted (the cascade callers: sem_filter.py:491-497 proxy scores, sem_topk.py:786-788): one
+        # score row without any top-k machinery, ordered on the host exactly as the search would (score best-first,
+        # lower row id first among equals) - SURVEY.md 8(f).4
+        sc_all = vs.scores(qv, ids=live.tolist())[0]
+        order = np.lexsort((live, -sc_all.astype(np.float64)))
+        idx, sc = live[order], sc_all[order]
+    else:
+        out = vs(qv, K, ids=live.tolist())
+        idx = np.asarray(out.indices)[0]
+        sc = np.asarray(out.distances)[0]
     ok = idx >= 0
     new_df = df.loc[idx[ok]]
     new_df.attrs["index_dirs"] = df.attrs.get("index_dirs", None)
@@ -84,7 +98,7 @@ def sem_sim_join(df1: pd.DataFrame, df2: pd.DataFrame, left_on: str, right_on: s
         raise ValueError(f"Index directory for column {right_on} not found in DataFrame")
     if vs.index_dir != col_index_dir:
         vs.load_index(col_index_dir)
-    qv = queries if isinstance(queries, np.ndarray) else rm.convert_query_to_query_vector(queries)
+    qv = queries if _is_vectors(queries) else rm.convert_query_to_query_vector(queries)
     right_index = np.asarray(df2.index)
     out = vs(qv, K, ids=right_index.tolist())
     I = np.asarray(out.indices)
@@ -107,8 +121,15 @@ def sem_sim_join(df1: pd.DataFrame, df2: pd.DataFrame, left_on: str, right_on: s
 
 def sem_dedup(df: pd.DataFrame, col_name: str, threshold: float, rm=None, vs=None, shard: bool = False) -> pd.DataFrame:
     """``df.sem_dedup`` (``sem_dedup.py:32-91``) through the GPU threshold self-join: O(pairs) memory instead of
-    O(N^2).  Survivor of each duplicate group = its first value in frame order."""
+    O(N^2).  Survivor of each duplicate group = its first value in frame order.
+
+    ``threshold`` is compared with the similarity score exactly as the reference does (``_scores > threshold``,
+    ``sem_dedup.py:46``).  That only means something for a similarity metric: with an L2 vector store the reference's
+    ``_scores`` are squared distances (larger = farther) and its dedup keeps the wrong side; here an L2 store is
+    refused instead of silently thresholding the negated distance."""
     rm, vs = _settings(rm, vs)
+    if getattr(vs, "metric", 0) != 0:
+        raise ValueError("sem_dedup thresholds a similarity: configure the vector store with METRIC_INNER_PRODUCT")
     col_index_dir = df.attrs["index_dirs"][col_name]
     if vs.index_dir != col_index_dir:
         vs.load_index(col_index_dir)

@@ -1,0 +1,115 @@
+"""On-disk side of the index directory (``lotus/vector_store/faiss_vs.py:27-41``).
+
+The reference keeps two files per index: ``{dir}/vecs`` (a Python pickle of the embeddings, re-read IN FULL by every
+``get_vectors_from_index`` and every ``ids``-branch search, ``faiss_vs.py:38-41,59``) and ``{dir}/index`` (faiss binary).
+Both are still written, so a directory built here loads in stock LOTUS and vice versa.  On top of that:
+
+* rows are served from a memory map, never from an unpickle: float32 embeddings are mapped in place inside
+  ``{dir}/index`` (its code section IS the row-major matrix); other storage types (fp16, fp64) get a raw
+  ``{dir}/rows.f16`` / ``rows.f64`` written next to it, described by ``{dir}/rows.json``;
+* a rank that owns rows ``[lo, hi)`` touches only those pages (per-rank partial load);
+* ``signature()`` = (size, mtime) of the files an index was loaded from, so a directory rewritten by another
+  process is noticed instead of served stale.
+"""
+from __future__ import annotations
+
+import json
+import os
+import pickle
+
+import numpy as np
+
+from . import faiss_io
+
+RAW_VERSION = 1
+_DTYPES = {"f16": np.float16, "f32": np.float32, "f64": np.float64}
+
+
+def _dtype_tag(dt) -> str:
+    for tag, t in _DTYPES.items():
+        if np.dtype(dt) == np.dtype(t):
+            return tag
+    raise ValueError(f"unsupported storage dtype {dt}")
+
+
+def write_dir(index_dir: str, embeddings, host: np.ndarray, metric: int, raw: bool = True) -> None:
+    """Persist an index: the reference's two files + (``raw``) the mappable row store.  ``embeddings`` is what the caller
+    handed to ``index()`` (pickled as is when it is an ndarray, exactly as ``faiss_vs.py:27-28``), ``host`` its 2-D host
+    image."""
+    os.makedirs(index_dir, exist_ok=True)
+    meta_path = os.path.join(index_dir, "rows.json")
+    if os.path.exists(meta_path):
+        os.remove(meta_path)  # never leave a description of rows that are being replaced
+    with open(os.path.join(index_dir, "vecs"), "wb") as fp:
+        pickle.dump(embeddings if isinstance(embeddings, np.ndarray) else host, fp)
+    faiss_io.write_index_flat(os.path.join(index_dir, "index"), host, metric)
+    if not raw:
+        return
+    tag = _dtype_tag(host.dtype)
+    meta = {"version": RAW_VERSION, "n": int(host.shape[0]), "d": int(host.shape[1]), "dtype": tag, "metric": int(metric)}
+    if tag == "f32":
+        meta["file"] = "index"  # mapped in place: the faiss file's code section is the float32 matrix
+    else:
+        meta["file"] = f"rows.{tag}"
+        np.ascontiguousarray(host).tofile(os.path.join(index_dir, meta["file"]))
+    tmp = meta_path + ".tmp"
+    with open(tmp, "w") as fp:
+        json.dump(meta, fp)
+    os.replace(tmp, meta_path)  # the description appears only once the rows are complete
+
+
+def signature(index_dir: str):
+    sig = []
+    for name in ("rows.json", "index", "vecs"):
+        try:
+            st = os.stat(os.path.join(index_dir, name))
+            sig.append((name, st.st_size, st.st_mtime_ns))
+        except FileNotFoundError:
+            sig.append((name, -1, -1))
+    return tuple(sig)
+
+
+def _described_rows(index_dir: str):
+    """The memmap ``rows.json`` describes, or None."""
+    meta_path = os.path.join(index_dir, "rows.json")
+    if not os.path.exists(meta_path):
+        return None
+    with open(meta_path) as fp:
+        meta = json.load(fp)
+    n, d, tag = int(meta["n"]), int(meta["d"]), meta["dtype"]
+    if meta.get("version") != RAW_VERSION or tag not in _DTYPES:
+        return None
+    if meta["file"] == "index":
+        rows, _ = faiss_io.mmap_index_flat(os.path.join(index_dir, "index"))
+        return rows if rows.shape == (n, d) else None
+    path = os.path.join(index_dir, meta["file"])
+    if not os.path.exists(path) or os.path.getsize(path) != n * d * np.dtype(_DTYPES[tag]).itemsize:
+        return None
+    if n == 0:
+        return np.zeros((0, d), _DTYPES[tag])
+    return np.memmap(path, dtype=_DTYPES[tag], mode="r", shape=(n, d))
+
+
+def open_stored_rows(index_dir: str):
+    """-> (rows [n, d] in the STORED dtype, how).  What ``get_vectors_from_index`` serves (``faiss_vs.py:38-41``): a
+    read-only memmap when the directory carries the row store ("raw" / "index-mmap"), else the unpickled ``vecs`` of a
+    directory written by stock LOTUS ("pickle")."""
+    rows = _described_rows(index_dir)
+    if rows is not None:
+        return rows, "mmap"
+    with open(os.path.join(index_dir, "vecs"), "rb") as fp:
+        return np.asarray(pickle.load(fp)), "pickle"
+
+
+def open_device_rows(index_dir: str):
+    """-> (rows [n, d], how) to build the device image from; always mappable: the row store when present, else the code
+    section of ``{dir}/index`` - the float32 cast of the embeddings, i.e. exactly the values faiss itself searches
+    (``faiss_vs.py:34,75``).  A rank slices ``rows[lo:hi]`` and reads only those pages; nothing is unpickled."""
+    rows = _described_rows(index_dir)
+    if rows is not None:
+        return rows, "mmap"
+    idx = os.path.join(index_dir, "index")
+    if os.path.exists(idx):
+        return faiss_io.mmap_index_flat(idx)[0], "index-mmap"
+    with open(os.path.join(index_dir, "vecs"), "rb") as fp:  # neither: only the pickle exists
+        return np.asarray(pickle.load(fp)), "pickle"

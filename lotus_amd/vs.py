@@ -26,7 +26,7 @@ from typing import Any
 
 import numpy as np
 
-from . import _capi, faiss_io
+from . import _capi, store
 from .compat import VS, RMOutput
 
 METRIC_INNER_PRODUCT = _capi.METRIC_IP  # == faiss.METRIC_INNER_PRODUCT (0)
@@ -37,14 +37,15 @@ FLT_MAX = np.float32(3.4028234663852886e38)
 
 @dataclass
 class _Resident:
-    """One loaded index: host copy (what ``get_vectors_from_index`` serves) + its device image."""
+    """One loaded index: its device image + where ``get_vectors_from_index`` gets the stored rows from."""
 
-    vecs: np.ndarray | None  # full host matrix in its stored dtype ({dir}/vecs); None until first needed
+    vecs: Any  # [n,d] rows in their stored dtype: the caller's ndarray, a read-only memmap, or None (opened on demand)
     packed: Any  # backend PackedRows of this rank's shard
     n: int  # rows in the whole index
     d: int
     lo: int  # first global row of this rank's shard
     hi: int
+    sig: Any = None  # store.signature() of the directory when it was loaded (None: never persisted)
 
 
 class HipVS(VS):
@@ -125,7 +126,9 @@ class HipVS(VS):
             x = x.astype(np.float32)
         return x
 
-    def _install(self, index_dir: str, vecs: np.ndarray) -> _Resident:
+    def _install(self, index_dir: str, vecs, stored=None, sig=None) -> _Resident:
+        """Build the device image of this rank's shard from ``vecs`` ([n,d] ndarray / memmap / CUDA tensor; only rows
+        [lo, hi) are touched).  ``stored``: what ``get_vectors_from_index`` serves (None = open on demand)."""
         n, d = int(vecs.shape[0]), int(vecs.shape[1])
         rank, world = self._dist()
         per = -(-n // world) if n else 0
@@ -133,7 +136,7 @@ class HipVS(VS):
         is_dev = self._is_device_tensor(vecs)
         dtype = np.float16 if (is_dev and str(vecs.dtype) == "torch.float16") else (np.float32 if is_dev else vecs.dtype)
         packed = self.backend.pack(vecs[lo:hi], self._pack_mode(dtype))
-        ent = _Resident(vecs=None if is_dev else vecs, packed=packed, n=n, d=d, lo=lo, hi=hi)
+        ent = _Resident(vecs=stored, packed=packed, n=n, d=d, lo=lo, hi=hi, sig=sig)
         self._resident[index_dir] = ent
         self._resident.move_to_end(index_dir)
         while len(self._resident) > self._max_resident:
@@ -149,43 +152,60 @@ class HipVS(VS):
     def index(self, docs, embeddings, index_dir: str, **kwargs: dict[str, Any]) -> None:
         """Build the index from ``embeddings`` and persist it (``faiss_vs.py:22-30``).  ``docs`` is unused, as in
         ``FaissVS``.  ``embeddings`` may also be a CUDA tensor straight from an encoder (no host round trip for the
-        device image); ``persist=False`` skips writing ``vecs`` / ``index`` to disk."""
+        device image).  Rank 0 writes the reference's two files plus the mappable row store (``lotus_amd/store.py``);
+        ``persist=False`` skips the disk entirely, ``raw=False`` writes the reference's files only."""
         emb = self._as_matrix(embeddings, "embeddings")
-        os.makedirs(index_dir, exist_ok=True)
-        rank, _ = self._dist()
-        if rank == 0 and kwargs.get("persist", True):
-            host = emb.cpu().numpy() if self._is_device_tensor(emb) else emb
-            with open(os.path.join(index_dir, "vecs"), "wb") as fp:
-                pickle.dump(embeddings if isinstance(embeddings, np.ndarray) else host, fp)
-            faiss_io.write_index_flat(os.path.join(index_dir, "index"), host, self.metric)
-        self._install(index_dir, emb)
+        rank, world = self._dist()
+        persist = bool(kwargs.get("persist", True))
+        is_dev = self._is_device_tensor(emb)
+        if persist:
+            if rank == 0:
+                host = emb.cpu().numpy() if is_dev else emb
+                store.write_dir(index_dir, embeddings, host, self.metric, raw=bool(kwargs.get("raw", True)))
+            if world > 1:  # the other ranks may open the directory right after this call
+                from . import _dist
+
+                _dist.barrier(self._pg)
+        self._install(index_dir, emb, stored=None if is_dev else emb,
+                      sig=store.signature(index_dir) if persist else None)
         self.index_dir = index_dir
 
     def load_index(self, index_dir: str) -> None:
-        """Make ``index_dir`` the current index (``faiss_vs.py:32-36``); served from HBM when already resident."""
-        if index_dir in self._resident:
+        """Make ``index_dir`` the current index (``faiss_vs.py:32-36``).  Served from HBM when the directory is already
+        resident AND unchanged on disk since it was loaded; otherwise this rank's rows are read through a memory map
+        (nothing is unpickled, ``lotus_amd/store.py``) and packed."""
+        ent = self._resident.get(index_dir)
+        if ent is not None and (ent.sig is None or ent.sig == store.signature(index_dir)):
             self._resident.move_to_end(index_dir)
             self.index_dir = index_dir
             return
-        vecs_path = os.path.join(index_dir, "vecs")
-        if os.path.exists(vecs_path):
-            with open(vecs_path, "rb") as fp:
-                vecs = pickle.load(fp)
-            vecs = self._as_matrix(vecs, "stored vectors")
-        else:  # index written by stock LOTUS without the pickle is not possible; accept a bare faiss file
-            vecs = faiss_io.read_index_flat(os.path.join(index_dir, "index"))[0]
-        self._install(index_dir, vecs)
+        sig = store.signature(index_dir)
+        rows, _ = store.open_device_rows(index_dir)
+        rows = self._as_matrix(rows, "stored vectors")
+        self._install(index_dir, rows, stored=None, sig=sig)
         self.index_dir = index_dir
 
     def get_vectors_from_index(self, index_dir: str, ids) -> np.ndarray:
-        """``vecs[ids]`` in the stored dtype (``faiss_vs.py:38-41``); ``ids`` may be a list or a pandas Index."""
+        """``vecs[ids]`` in the stored dtype (``faiss_vs.py:38-41``); ``ids`` may be a list or a pandas Index.  Rows
+        come from the caller's array (same process), from the row store's memory map (only the touched pages are read)
+        or - for an index that was never persisted - from the device image."""
         ent = self._resident.get(index_dir)
+        sel = ids if isinstance(ids, slice) else np.asarray(ids, dtype=np.int64)
+        if ent is not None and ent.vecs is None and ent.sig is None:  # persist=False / device tensors: HBM is the store
+            if ent.lo != 0 or ent.hi != ent.n:
+                raise NotImplementedError("vectors of a sharded index that was never persisted")  # sem_sim_join.py:114-117
+            be = self.backend
+            if isinstance(sel, slice):
+                sel = np.arange(ent.n, dtype=np.int64)[sel]
+            out = be.unpack(ent.packed, be.to_device(sel)).cpu().numpy()
+            return out.astype(np.float16) if ent.packed.mode == _capi.PACK_F16 else out
         if ent is not None and ent.vecs is not None:
             vecs = ent.vecs
         else:
-            with open(os.path.join(index_dir, "vecs"), "rb") as fp:
-                vecs = np.asarray(pickle.load(fp))
-        return vecs[np.asarray(ids, dtype=np.int64) if not isinstance(ids, slice) else ids]
+            vecs, _ = store.open_stored_rows(index_dir)
+            if ent is not None:
+                ent.vecs = vecs
+        return np.asarray(vecs[sel])
 
     def __call__(self, query_vectors, K: int, ids: list[int] | None = None, **kwargs: dict[str, Any]) -> RMOutput:
         """Top-``K`` rows for every query vector (``faiss_vs.py:43-77``)."""

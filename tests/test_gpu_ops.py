@@ -154,3 +154,68 @@ def test_device_resident_embeddings_in_and_out(hip_backend, tmp_path):
     fresh = HipVS(backend=hip_backend)
     fresh.load_index(str(tmp_path / "dev2"))
     assert np.array_equal(fresh(xq, 5).indices, host.indices)
+
+
+def test_device_rm_to_index_to_search_without_host_copies(hip_backend, tmp_path):
+    """DeviceRM (lotus_amd/rm.py): encoder output stays a CUDA tensor through sem_index, sem_search (K = all live rows,
+    served by the score-row path) and sem_sim_join; frames equal those of the ndarray RM."""
+    import torch
+
+    from lotus_amd import DeviceRM
+
+    dev = hip_backend.device
+    rm_h = fake_rm.make_rm(RM)
+    rm_d = DeviceRM(lambda b: torch.from_numpy(fake_rm.embed(b)).to(dev), max_batch_size=50, normalize_embeddings=False)
+    rng = np.random.default_rng(4)
+    words = sum(fake_rm.TOPICS.values(), [])
+    right = [" ".join(rng.choice(words, 3)) for _ in range(700)]
+    left = [" ".join(rng.choice(words, 2)) for _ in range(90)]
+    outs = []
+    for tag, rm in (("h", rm_h), ("d", rm_d)):
+        vs = HipVS(backend=hip_backend)
+        df2 = ops.sem_index(pd.DataFrame({"R": right, "keep": np.arange(700) % 3 != 1}), "R", str(tmp_path / tag), rm=rm, vs=vs)
+        live = df2[df2["keep"]]
+        s_all = ops.sem_search(live, "R", "geometry cooking history", len(live), rm=rm, vs=vs, return_scores=True)
+        j = ops.sem_sim_join(pd.DataFrame({"L": left}), live, "L", "R", 3, rm=rm, vs=vs)
+        outs.append((s_all, j))
+        if tag == "d":
+            assert torch.is_tensor(rm(["a"])) and rm(["a"]).is_cuda
+    (s0, j0), (s1, j1) = outs
+    assert len(s0) == int((np.arange(700) % 3 != 1).sum()) and s0["vec_scores_sim_score"].is_monotonic_decreasing
+    # ranking of ALL live rows from one score row == the search kernels' ranking (ties: lower row id first)
+    vs = HipVS(backend=hip_backend)
+    vs.load_index(str(tmp_path / "h"))
+    ref = vs(fake_rm.embed(["geometry cooking history"]), len(s0), ids=s0.index.sort_values().tolist())
+    assert np.allclose(np.asarray(ref.distances)[0], s0["vec_scores_sim_score"].to_numpy(), atol=1e-5)
+    same = np.asarray(ref.indices)[0] == s0.index.to_numpy()
+    assert same.mean() > 0.98  # near-ties (summation order differs between the two kernels) may swap neighbours
+    check(s0, s1, {"vec_scores_sim_score"})
+    check(j0, j1, {"_scores"})
+
+
+def test_partial_load_from_the_row_store(hip_backend, tmp_path, monkeypatch):
+    """store.py on the real backend: a rank packs only its rows out of the memory map; search results carry global ids."""
+    import pickle
+
+    xb = synth.corpus(4001, 96, seed=12).astype(np.float16)
+    xq, _ = synth.queries(xb.astype(np.float32), 30, seed=2)
+    d = str(tmp_path / "i")
+    HipVS(backend=hip_backend).index(None, xb, d)
+    monkeypatch.setattr(pickle, "load", lambda *a, **k: (_ for _ in ()).throw(AssertionError("unpickled")))
+    Dr, Ir = oracle.flat_search(xb.astype(np.float32), xq.astype(np.float16).astype(np.float32), 6)
+    parts = []
+    for rank in range(2):
+        vs = HipVS(backend=hip_backend, shard=True)
+        monkeypatch.setattr(vs, "_dist", lambda r=rank: (r, 2))
+        vs.load_index(d)
+        ent = vs._resident[d]
+        assert ent.packed.n == (2001 if rank == 0 else 2000) and ent.vecs is None
+        q = hip_backend.pack(xq.astype(np.float16), _capi.PACK_F16)
+        parts.append(hip_backend.search_keys(ent.packed, q, 6, 0, id_offset=ent.lo))
+        assert np.array_equal(vs.get_vectors_from_index(d, [4000, 3]), xb[[4000, 3]])
+    import torch
+
+    keys = hip_backend.merge_keys(torch.stack(parts))
+    D, I = hip_backend.keys_to_result(keys, 0)
+    err, hard, recall = synth.compare_topk(Dr, Ir, D.cpu().numpy(), I.cpu().numpy())
+    assert err <= 1e-5 and hard == 0 and recall == 1.0

@@ -1,0 +1,116 @@
+"""On-disk side of the index directory: reference-compatible files, mappable row store, per-rank
+partial loads, stale-directory detection, byte-level faiss layout."""
+import os
+import pickle
+
+import numpy as np
+import pytest
+
+import synth
+from lotus_amd import HipVS, _capi, faiss_io, store
+from oracle_backend import OracleBackend
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def test_faiss_flat_layout_against_hand_packed_bytes(tmp_path):
+    """Reader and writer against bytes assembled WITHOUT them (tests/golden/make_faiss_fixture.py)."""
+    from golden.make_faiss_fixture import IP_ROWS, L2_ROWS
+
+    for name, rows, metric in (("faiss_flat_ip_3x4.index", IP_ROWS, 0), ("faiss_flat_l2_2x3.index", L2_ROWS, 1)):
+        path = os.path.join(GOLDEN, name)
+        x, m = faiss_io.read_index_flat(path)
+        assert m == metric and x.dtype == np.float32 and np.array_equal(x, np.asarray(rows, np.float32))
+        mm, m2 = faiss_io.mmap_index_flat(path)
+        assert m2 == metric and np.array_equal(np.asarray(mm), x) and not mm.flags.writeable
+        out = tmp_path / name
+        faiss_io.write_index_flat(str(out), np.asarray(rows, np.float64), metric)  # fp64 in: cast like faiss's wrapper
+        assert out.read_bytes() == open(path, "rb").read()  # byte for byte
+    blob = open(os.path.join(GOLDEN, "faiss_flat_ip_3x4.index"), "rb").read()
+    assert blob[:4] == b"IxFI" and len(blob) == 45 + 3 * 4 * 4  # 45-byte header, then the row-major float32 matrix
+    bad = tmp_path / "bad.index"
+    bad.write_bytes(b"IwFl" + blob[4:])
+    with pytest.raises(ValueError):
+        faiss_io.read_index_flat(str(bad))
+
+
+@pytest.mark.parametrize("dtype,file,how", [(np.float32, "index", "mmap"), (np.float16, "rows.f16", "mmap"),
+                                            (np.float64, "rows.f64", "mmap")])
+def test_row_store_is_mapped_not_unpickled(tmp_path, dtype, file, how, monkeypatch):
+    x = synth.corpus(300, 24, seed=1).astype(dtype)
+    d = str(tmp_path / "i")
+    store.write_dir(d, x, x, 0)
+    assert sorted(os.listdir(d)) == sorted({"vecs", "index", "rows.json", file})
+    with open(os.path.join(d, "vecs"), "rb") as fp:
+        assert np.array_equal(pickle.load(fp), x)  # the reference's pickle, as given (faiss_vs.py:27-28)
+    assert np.array_equal(faiss_io.read_index_flat(os.path.join(d, "index"))[0], x.astype(np.float32))
+    monkeypatch.setattr(pickle, "load", lambda *a, **k: (_ for _ in ()).throw(AssertionError("unpickled")))
+    rows, h = store.open_stored_rows(d)
+    assert h == how and isinstance(rows, np.memmap) and rows.dtype == dtype and np.array_equal(np.asarray(rows), x)
+    rows, h = store.open_device_rows(d)
+    assert isinstance(rows, np.memmap) and np.array_equal(np.asarray(rows[100:200]), x[100:200])
+
+
+def test_directory_written_by_stock_lotus_loads_without_unpickling_for_the_device_image(tmp_path, monkeypatch):
+    """FaissVS.index leaves `vecs` (pickle) + `index` (faiss): the device image comes from the faiss file's code
+    section (the float32 values faiss itself searches), the pickle is only read if the stored rows are asked for."""
+    x = synth.corpus(200, 16, seed=2).astype(np.float64)  # LiteLLM-style fp64 embeddings (litellm_rm.py:69)
+    d = str(tmp_path / "stock")
+    os.makedirs(d)
+    with open(os.path.join(d, "vecs"), "wb") as fp:
+        pickle.dump(x, fp)
+    faiss_io.write_index_flat(os.path.join(d, "index"), x, 0)
+    real_load = pickle.load
+    monkeypatch.setattr(pickle, "load", lambda *a, **k: (_ for _ in ()).throw(AssertionError("unpickled")))
+    vs = HipVS(backend=OracleBackend())
+    vs.load_index(d)
+    out = vs(x[:5], 3)
+    assert out.indices[:, 0].tolist() == [0, 1, 2, 3, 4]
+    monkeypatch.setattr(pickle, "load", real_load)
+    got = vs.get_vectors_from_index(d, [3, 1])
+    assert got.dtype == np.float64 and np.array_equal(got, x[[3, 1]])  # stored dtype, from the pickle, on demand
+
+
+def test_each_rank_reads_and_packs_only_its_rows(tmp_path, monkeypatch):
+    x = synth.corpus(1001, 8, seed=3).astype(np.float16)
+    d = str(tmp_path / "i")
+    HipVS(backend=OracleBackend()).index(None, x, d)
+    for rank, (lo, hi) in enumerate(((0, 501), (501, 1001))):
+        vs = HipVS(backend=OracleBackend(), shard=True)
+        monkeypatch.setattr(vs, "_dist", lambda r=rank: (r, 2))
+        vs.load_index(d)
+        ent = vs._resident[d]
+        assert (ent.lo, ent.hi, ent.packed.n) == (lo, hi, hi - lo)
+        assert vs.backend.calls[0] == ("pack", (hi - lo, 8), _capi.PACK_F16)  # only the shard went to the device
+        assert np.array_equal(ent.packed.rows.numpy(), x[lo:hi].astype(np.float32))
+        assert ent.vecs is None  # no host copy of the matrix is kept
+        assert np.array_equal(vs.get_vectors_from_index(d, [1000, 0]), x[[1000, 0]])  # served from the memory map
+
+
+def test_rewritten_directory_is_noticed(tmp_path):
+    """a resident index must not be served stale after another process re-ran sem_index on its directory."""
+    a, b = synth.corpus(50, 8, seed=4), synth.corpus(60, 8, seed=5)
+    d = str(tmp_path / "i")
+    vs = HipVS(backend=OracleBackend())
+    vs.index(None, a, d)
+    assert vs(a[7:8], 1).indices[0, 0] == 7
+    other = HipVS(backend=OracleBackend())
+    other.index(None, b, d)  # "another process" rewrites the directory
+    os.utime(os.path.join(d, "index"), ns=(1, 1))  # even with a clock that went backwards: the signature differs
+    vs.load_index(d)
+    assert vs._resident[d].n == 60 and vs(b[55:56], 1).indices[0, 0] == 55
+    n_packs = len(vs.backend.calls)
+    vs.load_index(d)  # unchanged: served from HBM
+    assert len([c for c in vs.backend.calls[n_packs:] if c[0] == "pack"]) == 0
+
+
+def test_never_persisted_index_serves_vectors_from_the_device_image(tmp_path):
+    x = synth.corpus(40, 8, seed=6).astype(np.float16)
+    vs = HipVS(backend=OracleBackend())
+    d = str(tmp_path / "nowhere")
+    vs.index(None, x, d, persist=False)
+    assert not os.path.exists(os.path.join(d, "vecs"))
+    vs._resident[d].vecs = None  # e.g. the embeddings were a device tensor: no host array to fall back on
+    got = vs.get_vectors_from_index(d, [5, 2])
+    assert got.dtype == np.float16 and np.array_equal(got, x[[5, 2]])
+    assert vs(x[:3], 1).indices[:, 0].tolist() == [0, 1, 2]

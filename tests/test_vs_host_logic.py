@@ -29,7 +29,7 @@ def indexed(tmp_path):
 def test_is_a_vs_subclass_and_sets_index_dir(indexed):
     vs, xb, d = indexed
     assert isinstance(vs, VS) and vs.index_dir == d
-    assert sorted(os.listdir(d)) == ["index", "vecs"]
+    assert sorted(os.listdir(d)) == ["index", "rows.json", "vecs"]  # the reference's two files + the row-store description
     with open(os.path.join(d, "vecs"), "rb") as fp:
         assert np.array_equal(pickle.load(fp), xb)  # same pickle the reference writes (faiss_vs.py:27-29)
     x, metric = faiss_io.read_index_flat(os.path.join(d, "index"))
