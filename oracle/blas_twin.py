@@ -1,4 +1,6 @@
-"""CPU timing comparator: faiss's BLAS search path rebuilt on torch-CPU (MKL sgemm + ``topk``), all host cores.
+"""CPU timing comparator: faiss's BLAS search path rebuilt (a) in C + OpenMP with an AVX-512 sgemm micro-kernel fused with
+the k-best collector (``oracle/c/lvs_blas_twin.c`` -> ``flat_search_c``, the one ``bench.py`` times) and (b) on torch-CPU
+(MKL sgemm + ``topk`` -> ``flat_search_blas``), all host cores.
 TEST / MEASUREMENT INFRASTRUCTURE ONLY - used by ``bench.py``'s ``cpu_baseline`` leg and checked against
 ``oracle/flat.py`` in ``tests/test_oracle.py``.
 
@@ -60,4 +62,37 @@ def flat_search_blas(xb, xq, k: int, metric: int = 0, threads: int | None = None
         D = np.where(I >= 0, -D, FLT_MAX).astype(np.float32)
     else:
         D = np.where(I >= 0, D, -FLT_MAX).astype(np.float32)
+    return D, I, threads
+
+
+# ---- the C + OpenMP comparator ----------------------------------------------------------------------------------------
+import ctypes  # noqa: E402
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_TWIN_PATH = os.path.join(_HERE, "liblvs_blas_twin.so")
+_twin = None
+
+
+def c_available() -> bool:
+    return os.path.exists(_TWIN_PATH)
+
+
+def flat_search_c(xb, xq, k: int, metric: int = 0, threads: int = 0):
+    """-> (D float32 [nq,k], I int64 [nq,k], threads).  Same key order as the oracle (score best-first, id ascending)."""
+    global _twin
+    from .flat import _finish
+
+    if _twin is None:
+        lib = ctypes.CDLL(_TWIN_PATH)
+        lib.twin_flat_search.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32,
+                                         ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int32]
+        lib.twin_flat_search.restype = None
+        _twin = lib
+    xb = np.ascontiguousarray(xb, dtype=np.float32)
+    xq = np.ascontiguousarray(xq, dtype=np.float32)
+    keys = np.zeros((xq.shape[0], k), np.uint64)
+    threads = int(threads or os.cpu_count() or 1)
+    _twin.twin_flat_search(xb.ctypes.data, xb.shape[0], xq.ctypes.data, xq.shape[0], xb.shape[1], k, metric,
+                           keys.ctypes.data, threads)
+    D, I = _finish(keys, metric, None)
     return D, I, threads

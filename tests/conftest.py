@@ -18,7 +18,8 @@ def _built():
     """Make sure the HIP library and the oracle's C twin exist (both build without a GPU)."""
     lib = os.path.join(ROOT, "lotus_amd", "liblotus_hip.so")
     olib = os.path.join(ROOT, "oracle", "liblvs_oracle.so")
-    if not (os.path.exists(lib) and os.path.exists(olib)):
+    tlib = os.path.join(ROOT, "oracle", "liblvs_blas_twin.so")
+    if not (os.path.exists(lib) and os.path.exists(olib) and os.path.exists(tlib)):
         import __graft_entry__ as g
 
         g.build()

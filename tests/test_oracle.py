@@ -165,3 +165,25 @@ def test_dedup_restatement():
     assert oracle.dedup_keep_mask(vals, X, 0.9999).tolist() == [True] * 5
     lab = oracle.dedup_components(6, np.array([0, 4, 5]), np.array([3, 5, 2]))
     assert lab.tolist() == [0, 1, 2, 0, 2, 2]
+
+
+@pytest.mark.parametrize("which", ["c", "torch"])
+def test_cpu_timing_comparators_agree_with_the_oracle(which):
+    """bench.py's cpu_baseline times oracle/blas_twin (C + OpenMP AVX-512 twin, torch-CPU fallback): both must return
+    the oracle's answers (ids outside near-ties, scores to 1e-5 / 4e-5), padding included."""
+    import synth
+    from oracle import blas_twin
+
+    fn = blas_twin.flat_search_c if which == "c" else blas_twin.flat_search_blas
+    if which == "c" and not blas_twin.c_available():
+        pytest.skip("C comparator not built")
+    xb = synth.corpus(7001, 200, seed=1)
+    xq, _ = synth.queries(xb, 333, seed=2)
+    for metric, scale, atol in ((0, 1.0, 1e-5), (1, 1.4, 4e-5)):
+        D, I, threads = fn(xb * scale, xq, 9, metric)
+        Dr, Ir = oracle.flat_search(xb * scale, xq, 9, metric)
+        err, hard, recall = synth.compare_topk(Dr, Ir, D, I, atol=atol)
+        assert threads >= 1 and err <= atol and hard == 0 and recall >= 0.9999
+    D, I, _ = fn(xb[:5], xq[:3], 8)
+    assert (I[:, 5:] == -1).all() and (np.sort(I[:, :5], axis=1) == np.arange(5)).all()
+    assert np.all(D[:, 5:] == -np.float32(3.4028234663852886e38))
