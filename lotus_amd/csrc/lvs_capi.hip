@@ -497,7 +497,9 @@ int make_plan(int64_t nq, int64_t nb, int32_t d, int32_t xb_pack, int32_t xq_pac
     off += lvs_round_up((int64_t)p.nslab * nq * p.kpass * 8, 256);
     p.off_pass = off;  // [nq][kpass] merged keys of one pass (multi-pass only)
     off += p.npass > 1 ? lvs_round_up(nq * p.kpass * 8, 256) : 0;
-    off += (int64_t)LVS_STREAM_MAXWG * LVS_STREAM_MAXQ * LVS_KPASS * 8;  // candidates of the small-batch kernel
+    // candidates of the small-batch kernel: one k-list per (workgroup, query), written from off_partial onwards
+    if (nq <= LVS_STREAM_MAXQ && k <= LVS_KPASS)
+        off += (int64_t)(lvs_tune_set("LVS_STREAM_WGS") ? LVS_STREAM_MAXWG : 256) * (nq > 0 ? nq : 1) * (k > 0 ? k : 1) * 8;
     p.total = off;
     return LVS_OK;
 }
@@ -821,9 +823,10 @@ extern "C" int32_t lvs_flat_search_keys(const void* xb, int32_t xb_pack, int64_t
     {
         const int nqseg = xq_pack == LVS_PACK_SPLIT ? 2 : 1;
         const int jper = p.dpad / 16;
-        const bool fits = lvs_stream_lds_bytes(nqseg * jper) <= 150 * 1024;
+        int kcap = 0;
+        const bool fits = lvs_stream_plan(nq, k, nqseg * jper, &kcap) > 0;
         const bool want = lvs_tune("LVS_STREAM", 1) != 0;
-        if (want && fits && nq <= LVS_STREAM_MAXQ && k <= LVS_KPASS && nb >= 4096) {
+        if (want && fits && nb >= 4096) {
             LvsStreamArgs sa;
             memset(&sa, 0, sizeof(sa));
             sa.xb = xb;
@@ -844,6 +847,7 @@ extern "C" int32_t lvs_flat_search_keys(const void* xb, int32_t xb_pack, int64_t
             sa.nseg = p.nseg;
             sa.nj = p.nseg * jper;
             sa.nbfrag = nqseg * jper;
+            sa.kcap = kcap;
             for (int i = 0; i < 3; ++i) {
                 sa.seg_q[i] = p.seg_q[i];
                 sa.seg_c[i] = p.seg_c[i];

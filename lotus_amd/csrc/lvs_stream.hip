@@ -1,27 +1,31 @@
-// Small-batch search kernel: up to 32 queries against the whole corpus shard - the HBM-bound regime of the path
-// (the literal `sem_search` operator issues ONE query per call: lotus/sem_ops/sem_search.py:121-122 -> faiss_vs.py:75).
+// Small-batch search kernel: up to 96 queries against the whole corpus shard - the HBM-bound regime of the path
+// (the literal `sem_search` operator issues ONE query per call: lotus/sem_ops/sem_search.py:121-122 -> faiss_vs.py:75;
+// small sim-joins and batched searches send a few dozen).
 //
 // Roofline: HBM.  Algorithmic bytes per launch = nb * ld * 2 (every corpus byte exactly once) + O(nq * ld);
 // at 1 M x 768 fp16 that is 1.536 GB -> 0.19 ms at 8 TB/s.  Nothing is staged through LDS except the queries:
-//   * the <= 32 queries live in LDS for the whole kernel, laid out as ready-made MFMA B fragments
-//     ([K/16][64 lanes][16 B], lane-linear -> conflict-free ds_read_b128);
+//   * the queries live in LDS for the whole kernel, laid out as ready-made MFMA B fragments, one set per block of 32
+//     queries ([NQB][K/16][64 lanes][16 B], lane-linear -> conflict-free ds_read_b128); NQB = 1, 2 or 3 blocks, as many
+//     as LDS holds (d = 768 fp16: 48 KB per block);
 //   * corpus rows stream from HBM straight into registers as A fragments (lane (r, h) reads 16 B of row r; the two
-//     half-wave lanes of a row cover 32 contiguous bytes, four consecutive K-slices one 128-B line), 16 loads
-//     (16 KB per wave) in flight ahead of the MFMAs;
-//   * each wave owns 32-row blocks: 32 x 32 x K product on v_mfma_f32_32x32x16_f16, operands swapped as in the tile
-//     kernels (corpus = A, queries = B) so that a lane owns one query column and its threshold is a register;
-//   * hits go through the same wave-cooperative sorted insertion into per-query lists (LDS, 32 x 64 slots, one lock
-//     per query because the 4 waves of a workgroup share the queries); thresholds are shared across workgroups
+//     half-wave lanes of a row cover 32 contiguous bytes, four consecutive K-slices one 128-B line), UNROLL loads
+//     (1 KB each per wave) in flight ahead of the MFMAs; every fragment feeds NQB MFMAs (one per query block), so up to
+//     96 queries ride on ONE pass over the corpus;
+//   * each wave owns 32-row blocks: 32 x 32 x K product per query block on v_mfma_f32_32x32x16_f16, operands swapped as
+//     in the tile kernels (corpus = A, queries = B) so that a lane owns one query column and its threshold is a register;
+//   * hits go through the same wave-cooperative sorted insertion into per-query lists (LDS, a.kcap slots per query, one
+//     lock per query because the 4 waves of a workgroup share the queries); thresholds are shared across workgroups
 //     through the global per-query word; every workgroup writes its k candidates and lvs_merge_keys finishes.
 #include "lvs_common.h"
 #include "lvs_tile.h"
 
 namespace {
 
-constexpr int SQ = 32;          // queries per launch
+constexpr int SQ = 32;          // queries per query block (MFMA N)
 constexpr int WAVES = 4;        // waves per workgroup
-constexpr int KCAP = 64;        // list slots per query = lanes of the cooperative insertion (k <= LVS_KPASS = 56)
-constexpr int UNROLL = 16;      // A-fragment loads in flight per wave (16 x 1 KB)
+// UNROLL = A-fragment loads in flight per wave (1 KB each) = fragments per inner-loop iteration: a template parameter so
+// that the branch-free fast path exists for every row length whose fragment count per K segment is a multiple of 8:
+//   16 (d = 256, 512, 768, 1024, ...), 24 (d = 384 - BASELINE configs[0]'s dimension -, 1152), 8 (d = 128, 640, ...)
 
 __device__ inline float tau_float(uint32_t ord) { return ord == 0 ? -INFINITY : lvs_unord32(ord); }
 
@@ -35,39 +39,52 @@ __device__ inline float max16(const f32x16& v) {
 
 }  // namespace
 
+template <int UNROLL, int NQB>
 __global__ __launch_bounds__(WAVES * 64, 2) void lvs_stream_kernel(const LvsStreamArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    half8* bfrag = (half8*)smem;                                       // [nbfrag][64]
-    u64* lists = (u64*)(smem + (size_t)a.nbfrag * 1024);               // [SQ][KCAP]
-    uint32_t* locks = (uint32_t*)(smem + (size_t)a.nbfrag * 1024 + SQ * KCAP * 8);  // [SQ]
+    constexpr int NQ = NQB * SQ;
+    const int KCAP = a.kcap;  // list slots per query (>= k, <= 64 = lanes of the cooperative insertion)
+    half8* bfrag = (half8*)smem;                                              // [NQB][nbfrag][64]
+    u64* lists = (u64*)(smem + (size_t)NQB * a.nbfrag * 1024);                // [NQ][KCAP]
+    uint32_t* locks = (uint32_t*)((char*)lists + (size_t)NQ * KCAP * 8);      // [NQ]
     const int k = a.k;
 
-    // ---- queries -> LDS as B fragments: fragment j, lane l = query (l & 31), halfs seg_q + jj*16 + (l>>5)*8 .. +8
+    // ---- queries -> LDS as B fragments: block qb, fragment f, lane l = query qb*32 + (l & 31), halfs .. + (l>>5)*8
     const _Float16* xq = (const _Float16*)a.xq;
-    for (int idx = tid; idx < a.nbfrag * 64; idx += WAVES * 64) {
-        const int f = idx >> 6, l = idx & 63;
+    for (int idx = tid; idx < NQB * a.nbfrag * 64; idx += WAVES * 64) {
+        const int l = idx & 63, fq = idx >> 6;
+        const int qb = fq / a.nbfrag, f = fq - qb * a.nbfrag;
         const int part = f / a.jper, jj = f - part * a.jper;  // part 0: columns [0, dpad), part 1: [dpad, 2 dpad)
-        int qrow = l & 31;
+        int qrow = qb * SQ + (l & 31);
         if (qrow > a.nq - 1) qrow = a.nq - 1;
         bfrag[idx] = *(const half8*)(xq + (long long)qrow * a.ldq + part * a.jper * 16 + jj * 16 + (l >> 5) * 8);
     }
-    for (int i = tid; i < SQ * KCAP; i += WAVES * 64) lists[i] = 0;
-    if (tid < SQ) locks[tid] = 0;
+    for (int i = tid; i < NQ * KCAP; i += WAVES * 64) lists[i] = 0;
+    for (int i = tid; i < NQ; i += WAVES * 64) locks[i] = 0;
     __syncthreads();
 
-    const int q = lane & 31;  // this lane's query
-    const bool qvalid = q < a.nq;
-    float tauf = -INFINITY;
-    uint32_t gord = 0;
-    const float qnv = (a.metric == LVS_METRIC_L2 && qvalid) ? a.qn[q] : 0.f;
+    // per query block: this lane's query, its validity, running threshold, shared threshold, |q|^2
+    int qi[NQB];
+    bool qvalid[NQB];
+    float tauf[NQB], qnv[NQB];
+    uint32_t gord[NQB];
+#pragma unroll
+    for (int qb = 0; qb < NQB; ++qb) {
+        qi[qb] = qb * SQ + (lane & 31);
+        qvalid[qb] = qi[qb] < a.nq;
+        tauf[qb] = -INFINITY;
+        gord[qb] = 0;
+        qnv[qb] = (a.metric == LVS_METRIC_L2 && qvalid[qb]) ? a.qn[qi[qb]] : 0.f;
+    }
 
     const _Float16* xb = (const _Float16*)a.xb;
     const long long nblocks = (a.nb + 31) / 32;
     const long long b0 = (long long)blockIdx.x * a.blocks_per_wg;
     const long long b1 = b0 + a.blocks_per_wg < nblocks ? b0 + a.blocks_per_wg : nblocks;
     const int nj = a.nj, jper = a.jper;
+    const long long qbstride = (long long)a.nbfrag * 64;  // half8 elements between the fragment sets of two query blocks
 
     // ---- fragment stream: one continuous software pipeline over ALL of this wave's row blocks --------------------
     // The A-fragment loads run UNROLL fragments ahead of the MFMAs and cross block boundaries (the first fragments of
@@ -110,10 +127,10 @@ __global__ __launch_bounds__(WAVES * 64, 2) void lvs_stream_kernel(const LvsStre
         }  // else: padding step, repeat the last fragment
         return v;
     };
-    // the common shapes (fragments per K segment a multiple of UNROLL: d = 256, 512, 768, 1024, ..., fp16 or hi|lo rows)
-    // have a branch-free inner loop: a block is 1..3 runs of jper contiguous fragments, the 16 loads of an iteration
-    // share one base pointer (the same run 16 fragments on, the next run's start, or the next block's first run) and
-    // differ by immediate offsets, like the 16 B-fragment reads
+    // the common shapes (fragments per K segment a multiple of UNROLL, fp16 or hi|lo rows) have a branch-free inner loop:
+    // a block is 1..3 runs of jper contiguous fragments, the UNROLL loads of an iteration
+    // share one base pointer (the same run UNROLL fragments on, the next run's start, or the next block's first run) and
+    // differ by immediate offsets, like the B-fragment reads
     const bool simple = jper % UNROLL == 0;
     half8 abuf[UNROLL];
     if (b0 + wave < b1) {
@@ -129,9 +146,11 @@ __global__ __launch_bounds__(WAVES * 64, 2) void lvs_stream_kernel(const LvsStre
 
     for (long long blk = b0 + wave; blk < b1; blk += WAVES) {
         const long long row0 = blk * 32;
-        f32x16 acc;
+        f32x16 acc[NQB];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        for (int qb = 0; qb < NQB; ++qb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[qb][r] = 0.f;
         if (simple) {
             const _Float16* ap_cur = row_ptr(blk);
             const _Float16* ap_nxt = row_ptr(blk + WAVES < b1 ? blk + WAVES : blk) + segc0;
@@ -148,11 +167,13 @@ __global__ __launch_bounds__(WAVES * 64, 2) void lvs_stream_kernel(const LvsStre
                         abuf[u] = *(const half8*)(nsrc + u * 16);
 #ifdef LVS_TUNING
                         if (a.debug == 1) {  // timing ablation: no MFMA / B reads (results are wrong)
-                            acc[0] += (float)av[0];
+                            acc[0][0] += (float)av[0];
                             continue;
                         }
 #endif
-                        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bsrc[u * 64], acc, 0, 0, 0);
+#pragma unroll
+                        for (int qb = 0; qb < NQB; ++qb)
+                            acc[qb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bsrc[qb * qbstride + u * 64], acc[qb], 0, 0, 0);
                     }
                 }
             }
@@ -164,8 +185,11 @@ __global__ __launch_bounds__(WAVES * 64, 2) void lvs_stream_kernel(const LvsStre
                 const half8 av = abuf[u];
                 abuf[u] = next_load();  // the fragment UNROLL steps ahead (possibly of the next block)
                 if (j0 + u < nj) {
-                    const half8 bv = bfrag[c_b * 64 + lane];
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bv, acc, 0, 0, 0);
+#pragma unroll
+                    for (int qb = 0; qb < NQB; ++qb) {
+                        const half8 bv = bfrag[qb * qbstride + c_b * 64 + lane];
+                        acc[qb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bv, acc[qb], 0, 0, 0);
+                    }
                     if (++c_jj == jper) {
                         c_jj = 0;
                         ++c_seg;
@@ -177,93 +201,99 @@ __global__ __launch_bounds__(WAVES * 64, 2) void lvs_stream_kernel(const LvsStre
             }
         }
         }
-        // ---- block epilogue: 32 rows x 32 queries; lane holds query q, rows row0 + (r&3) + 8*(r>>2) + 4*(lane>>5)
+        // ---- block epilogue: 32 rows x NQ queries; lane holds queries qi[*], rows row0 + (r&3) + 8*(r>>2) + 4*(lane>>5)
 #ifdef LVS_TUNING
         if (a.debug == 2) continue;  // timing ablation: no block epilogue (results are wrong)
 #endif
         const long long rbase = row0 + 4 * (lane >> 5);
-        if (a.metric == LVS_METRIC_L2) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const long long row = rbase + (r & 3) + 8 * (r >> 2);
-                const float bnv = row < a.nb ? a.bn[row] : 0.f;
-                acc[r] = -fmaxf((qnv + bnv) - 2.0f * acc[r], 0.f);
-            }
-        }
-        {
-            const uint32_t lo = (uint32_t)(lists[q * KCAP + k - 1] >> 32);
-            tauf = fmaxf(tauf, tau_float(lo));
-        }
-        const bool th = qvalid && (max16(acc) >= tauf);
-        if (__any(th)) {
+        for (int qb = 0; qb < NQB; ++qb) {
+            const int q = qi[qb];
+            if (a.metric == LVS_METRIC_L2) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float s = acc[r];
-                bool pending = false;
-                u64 key = 0;
-                if (th && s >= tauf) {
+                for (int r = 0; r < 16; ++r) {
                     const long long row = rbase + (r & 3) + 8 * (r >> 2);
-                    if (row < a.nb) {
-                        const uint32_t id = a.row_ids ? a.row_ids[row] : (uint32_t)(row + a.id_offset);
-                        key = lvs_pack_key(s, id);
-                        pending = (uint32_t)(key >> 32) >= gord;
-                    }
+                    const float bnv = row < a.nb ? a.bn[row] : 0.f;
+                    acc[qb][r] = -fmaxf((qnv[qb] + bnv) - 2.0f * acc[qb][r], 0.f);
                 }
-                unsigned long long pm = __ballot(pending);
-                while (pm) {  // wave-cooperative sorted insertion (see lvs_tile.hip)
-                    const int src = __ffsll((long long)pm) - 1;
-                    pm &= pm - 1;
-                    const uint32_t klo = __builtin_amdgcn_readlane((uint32_t)key, src);
-                    const uint32_t khi = __builtin_amdgcn_readlane((uint32_t)(key >> 32), src);
-                    const u64 ukey = ((u64)khi << 32) | klo;
-                    const int uq = __builtin_amdgcn_readlane(q, src);
-                    u64* UL = lists + uq * KCAP;
-                    u64 mine = 0, prev = ~0ull;
-                    for (;;) {
-                        uint32_t seen = 0;
-                        if (lane == 0)
-                            __hip_atomic_compare_exchange_strong(&locks[uq], &seen, 1u, __ATOMIC_RELAXED,
-                                                                 __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        asm volatile("" ::: "memory");
-                        if (lane < k) {
-                            mine = UL[lane];
-                            if (lane > 0) prev = UL[lane - 1];
+            }
+            {
+                const uint32_t lo = (uint32_t)(lists[q * KCAP + k - 1] >> 32);
+                tauf[qb] = fmaxf(tauf[qb], tau_float(lo));
+            }
+            const bool th = qvalid[qb] && (max16(acc[qb]) >= tauf[qb]);
+            if (__any(th)) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float s = acc[qb][r];
+                    bool pending = false;
+                    u64 key = 0;
+                    if (th && s >= tauf[qb]) {
+                        const long long row = rbase + (r & 3) + 8 * (r >> 2);
+                        if (row < a.nb) {
+                            const uint32_t id = a.row_ids ? a.row_ids[row] : (uint32_t)(row + a.id_offset);
+                            key = lvs_pack_key(s, id);
+                            pending = (uint32_t)(key >> 32) >= gord[qb];
                         }
-                        if (__builtin_amdgcn_readfirstlane(seen) == 0) break;
                     }
-                    u64 newv = 0;
-                    if (lane < k) newv = mine > ukey ? mine : (prev > ukey ? ukey : prev);
-                    __builtin_amdgcn_wave_barrier();
-                    if (lane < k) UL[lane] = newv;
-                    const uint32_t ntau = __builtin_amdgcn_readlane((uint32_t)(newv >> 32), k - 1);
-                    asm volatile("" ::: "memory");  // slot writes stay ahead of the unlock (LDS is in-order per wave)
-                    if (lane == 0) __hip_atomic_store(&locks[uq], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    if (q == uq) tauf = fmaxf(tauf, tau_float(ntau));
+                    unsigned long long pm = __ballot(pending);
+                    while (pm) {  // wave-cooperative sorted insertion (see lvs_tile.hip)
+                        const int src = __ffsll((long long)pm) - 1;
+                        pm &= pm - 1;
+                        const uint32_t klo = __builtin_amdgcn_readlane((uint32_t)key, src);
+                        const uint32_t khi = __builtin_amdgcn_readlane((uint32_t)(key >> 32), src);
+                        const u64 ukey = ((u64)khi << 32) | klo;
+                        const int uq = __builtin_amdgcn_readlane(q, src);
+                        u64* UL = lists + uq * KCAP;
+                        u64 mine = 0, prev = ~0ull;
+                        for (;;) {
+                            uint32_t seen = 0;
+                            if (lane == 0)
+                                __hip_atomic_compare_exchange_strong(&locks[uq], &seen, 1u, __ATOMIC_RELAXED,
+                                                                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            asm volatile("" ::: "memory");
+                            if (lane < k) {
+                                mine = UL[lane];
+                                if (lane > 0) prev = UL[lane - 1];
+                            }
+                            if (__builtin_amdgcn_readfirstlane(seen) == 0) break;
+                        }
+                        u64 newv = 0;
+                        if (lane < k) newv = mine > ukey ? mine : (prev > ukey ? ukey : prev);
+                        __builtin_amdgcn_wave_barrier();
+                        if (lane < k) UL[lane] = newv;
+                        const uint32_t ntau = __builtin_amdgcn_readlane((uint32_t)(newv >> 32), k - 1);
+                        asm volatile("" ::: "memory");  // slot writes stay ahead of the unlock (LDS is in-order per wave)
+                        if (lane == 0) __hip_atomic_store(&locks[uq], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        if (q == uq) tauf[qb] = fmaxf(tauf[qb], tau_float(ntau));
+                    }
                 }
             }
         }
         // exchange thresholds with the other workgroups every 32 blocks of this wave (the global load drains the
         // in-flight fragment loads - vmcnt is in-order - so this must stay rare)
-        if ((((blk - b0) / WAVES) & 31) == 31 && qvalid && lane < 32) {
-            const uint32_t lo = (uint32_t)(lists[q * KCAP + k - 1] >> 32);
-            if (lo > gord) atomicMax(&a.gtau[q], lo);
-            const uint32_t g = a.gtau[q];
-            gord = g > gord ? g : gord;
+        const bool exch = (((blk - b0) / WAVES) & 31) == 31;
+#pragma unroll
+        for (int qb = 0; qb < NQB; ++qb) {
+            if (exch && qvalid[qb] && lane < 32) {
+                const uint32_t lo = (uint32_t)(lists[qi[qb] * KCAP + k - 1] >> 32);
+                if (lo > gord[qb]) atomicMax(&a.gtau[qi[qb]], lo);
+                const uint32_t g = a.gtau[qi[qb]];
+                gord[qb] = g > gord[qb] ? g : gord[qb];
+            }
+            const uint32_t gl = __shfl(gord[qb], lane & 31, 64);  // lanes l and l+32 share the query
+            gord[qb] = gl > gord[qb] ? gl : gord[qb];
+            tauf[qb] = fmaxf(tauf[qb], tau_float(gord[qb]));
         }
-        {
-            const uint32_t gl = __shfl(gord, lane & 31, 64);  // lanes l and l+32 share the query
-            gord = gl > gord ? gl : gord;
-        }
-        tauf = fmaxf(tauf, tau_float(gord));
     }
     __syncthreads();
     for (int i = tid; i < a.nq * k; i += WAVES * 64) {
         const int qq = i / k, j = i - qq * k;
         a.out[((long long)blockIdx.x * a.nq + qq) * k + j] = lists[qq * KCAP + j];
     }
-    if (tid < a.nq) {
-        const uint32_t lo = (uint32_t)(lists[tid * KCAP + k - 1] >> 32);
-        if (lo) atomicMax(&a.gtau[tid], lo);
+    for (int qq = tid; qq < a.nq; qq += WAVES * 64) {
+        const uint32_t lo = (uint32_t)(lists[qq * KCAP + k - 1] >> 32);
+        if (lo) atomicMax(&a.gtau[qq], lo);
     }
 }
 
@@ -278,7 +308,48 @@ int lvs_stream_blocks(int64_t nb) {
     return (int)wgs;
 }
 
-size_t lvs_stream_lds_bytes(int nbfrag) { return (size_t)nbfrag * 1024 + SQ * KCAP * 8 + SQ * 4; }
+size_t lvs_stream_lds_bytes(int nbfrag, int nqb, int kcap) {
+    return (size_t)nqb * nbfrag * 1024 + (size_t)nqb * SQ * kcap * 8 + (size_t)nqb * SQ * 4;
+}
+
+// how many 32-query blocks ride on one corpus pass, and with how many list slots per query; 0 = this call does not fit
+// the streaming kernel (too many queries / k for the LDS left beside the query fragments)
+int lvs_stream_plan(int64_t nq, int k, int nbfrag, int* out_kcap) {
+    if (nq < 1 || nq > LVS_STREAM_MAXQ || k < 1 || k > LVS_KPASS) return 0;
+    const int nqb = (int)((nq + SQ - 1) / SQ);
+    // one block keeps the full 64 slots (any k <= 56 costs the same insertion step); more blocks trade slots for queries
+    int kcap = nqb == 1 ? 64 : (k <= 16 ? 16 : (k <= 32 ? 32 : 64));
+    if (lvs_stream_lds_bytes(nbfrag, nqb, kcap) > 150 * 1024) return 0;
+    if (out_kcap) *out_kcap = kcap;
+    return nqb;
+}
+
+template <int U, int NQB>
+static hipError_t stream_launch_one(const LvsStreamArgs& a, int grid, size_t lds, hipStream_t stream) {
+    static LvsPerDeviceOnce attr;  // the attribute is a per-device property (one per instantiation)
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (!attr.done(dev, lds)) {
+        e = hipFuncSetAttribute((const void*)lvs_stream_kernel<U, NQB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr.set(dev, lds);
+    }
+    hipLaunchKernelGGL((lvs_stream_kernel<U, NQB>), dim3(grid), dim3(WAVES * 64), lds, stream, a);
+    return hipGetLastError();
+}
+
+template <int NQB>
+static hipError_t stream_launch_nqb(const LvsStreamArgs& a, int grid, size_t lds, hipStream_t stream) {
+    // fragments in flight: the largest of 16 / 24 / 8 that divides the fragments per K segment gives the branch-free
+    // inner loop; anything else runs the general state machine with 16
+    if (a.jper % 16 == 0) return stream_launch_one<16, NQB>(a, grid, lds, stream);
+    if constexpr (NQB == 1) {  // 24 fragment registers + 2..3 accumulator sets would spill: several blocks use 8
+        if (a.jper % 24 == 0) return stream_launch_one<24, NQB>(a, grid, lds, stream);
+    }
+    if (a.jper % 8 == 0) return stream_launch_one<8, NQB>(a, grid, lds, stream);
+    return stream_launch_one<16, NQB>(a, grid, lds, stream);
+}
 
 hipError_t lvs_stream_launch(LvsStreamArgs& a, hipStream_t stream) {
     const int64_t nblocks = (a.nb + 31) / 32;
@@ -286,16 +357,10 @@ hipError_t lvs_stream_launch(LvsStreamArgs& a, hipStream_t stream) {
     a.blocks_per_wg = (int)((nblocks + wgs - 1) / wgs);
     a.debug = (int)lvs_tune("LVS_STREAM_DEBUG", 0);
     const int grid = (int)((nblocks + a.blocks_per_wg - 1) / a.blocks_per_wg);
-    const size_t lds = (size_t)a.nbfrag * 1024 + SQ * KCAP * 8 + SQ * 4;
-    static LvsPerDeviceOnce attr;  // the attribute is a per-device property
-    int dev = 0;
-    hipError_t e = hipGetDevice(&dev);
-    if (e != hipSuccess) return e;
-    if (!attr.done(dev, lds)) {
-        e = hipFuncSetAttribute((const void*)lvs_stream_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attr.set(dev, lds);
-    }
-    hipLaunchKernelGGL(lvs_stream_kernel, dim3(grid), dim3(WAVES * 64), lds, stream, a);
-    return hipGetLastError();
+    const int nqb = (a.nq + SQ - 1) / SQ;
+    if (nqb < 1 || nqb > 3 || a.kcap < a.k || a.kcap > 64) return hipErrorInvalidValue;
+    const size_t lds = lvs_stream_lds_bytes(a.nbfrag, nqb, a.kcap);
+    if (nqb == 1) return stream_launch_nqb<1>(a, grid, lds, stream);
+    if (nqb == 2) return stream_launch_nqb<2>(a, grid, lds, stream);
+    return stream_launch_nqb<3>(a, grid, lds, stream);
 }

@@ -68,8 +68,8 @@ struct LvsTileArgs {
 int lvs_tile_grid_blocks(int nqt, int nslab, int gq, int lead_slabs);
 hipError_t lvs_tile_launch(int mode, const LvsTileArgs& a, hipStream_t stream);
 
-// ---- small-batch streaming kernel (lvs_stream.hip): nq <= 32, k <= LVS_KPASS ----
-#define LVS_STREAM_MAXQ 32
+// ---- small-batch streaming kernel (lvs_stream.hip): nq <= 96 (1..3 blocks of 32 queries per corpus pass), k <= LVS_KPASS ----
+#define LVS_STREAM_MAXQ 96
 #define LVS_STREAM_MAXWG 768   // most workgroups (= partial candidate lists) a launch may use
 struct LvsStreamArgs {
     const void* xb;
@@ -88,9 +88,11 @@ struct LvsStreamArgs {
     int seg_b[3];            // first B-fragment index of each K segment (segments sharing query columns share fragments)
     int nbfrag;              // B fragments held in LDS
     int blocks_per_wg;       // 32-row blocks per workgroup (contiguous)
+    int kcap;                // list slots per query in LDS (k <= kcap <= 64), from lvs_stream_plan
     int debug;               // -DLVS_TUNING builds only (env LVS_STREAM_DEBUG): 1 no MFMA / B reads, 2 no block epilogue
 };
 
 int lvs_stream_blocks(int64_t nb);
-size_t lvs_stream_lds_bytes(int nbfrag);
+size_t lvs_stream_lds_bytes(int nbfrag, int nqb, int kcap);
+int lvs_stream_plan(int64_t nq, int k, int nbfrag, int* out_kcap);
 hipError_t lvs_stream_launch(LvsStreamArgs& a, hipStream_t stream);

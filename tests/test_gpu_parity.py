@@ -99,9 +99,16 @@ def test_mixed_precision_operands(hip_backend, cmode, qmode, k):
     (1, 100_000, 768, 40, F16, L2),
     (3, 20_000, 768, 1, F16, L2),
     (20, 40_000, 256, 10, SPLIT, L2),
+    (64, 50_000, 768, 10, F16, IP),    # two blocks of 32 queries on one corpus pass
+    (96, 30_000, 384, 15, F16, L2),    # three blocks, d = 384 (24 fragments per row: the 8-deep pipeline)
+    (33, 20_000, 256, 16, F16, IP),    # second block nearly empty; k = 16 fills the 16-slot lists exactly
+    (50, 20_000, 128, 30, F16, IP),    # 32-slot lists
+    (90, 12_000, 100, 56, F16, IP),    # 64-slot lists, three blocks (short rows leave the LDS for them)
+    (70, 9_000, 768, 5, SPLIT, IP),    # fp32-accurate queries do not fit twice: falls to the tile kernel
 ])
 def test_small_batch_streaming_kernel(hip_backend, nq, nb, d, k, mode, metric):
-    """nq <= 32 takes the HBM-streaming kernel (lvs_stream.hip): same results as the tile kernels / the oracle."""
+    """nq <= 96 takes the HBM-streaming kernel (lvs_stream.hip) when the query fragments fit the LDS: same results as
+    the tile kernels / the oracle."""
     xb = synth.corpus(nb, d, seed=nb % 89)
     xq, _ = synth.queries(xb, nq, seed=13)
     if metric == L2:
