@@ -115,6 +115,22 @@ __device__ inline bool wave_any(bool p) { return __builtin_amdgcn_ballot_w64(p) 
 
 __device__ inline float tau_float(uint32_t ord) { return ord == 0 ? -INFINITY : lvs_unord32(ord); }
 
+// Every lane's first candidate (lowest accumulator register r with v[r] >= tf) of one 32 x 32 block, in straight-line
+// code: per register one compare, two selects and two scalar mask operations - no per-row branch.  any_m = lanes with at
+// least one candidate, multi_m = lanes with more than one (they need the row-by-row pass for the rest).
+__device__ __forceinline__ void first_hit(const f32x16& v, float tf, bool qv, float& cs, int& cr, u64& any_m, u64& multi_m) {
+    const float tfe = qv ? tf : INFINITY;  // lanes without a query never match
+#pragma unroll
+    for (int r = 15; r >= 0; --r) {
+        const bool hit = v[r] >= tfe;
+        const u64 m = __builtin_amdgcn_ballot_w64(hit);
+        multi_m |= m & any_m;
+        any_m |= m;
+        cs = hit ? v[r] : cs;
+        cr = hit ? r : cr;
+    }
+}
+
 // blockIdx -> (query tile, slab).  Blocks are dealt to the XCDs round-robin (b % 8, observed; used for speed only) and an
 // XCD runs 32 of them at a time, so 32 consecutive blocks of one XCD form a "group" that shares operands through that
 // XCD's L2: gq query tiles x 32/gq slabs.  Groups walk the query tiles first, then the slabs, so a query's later slabs
@@ -541,25 +557,92 @@ __global__ __launch_bounds__(512, 2) void lvs_tile_kernel(const LvsTileArgs a) {
         c_filter += tm1 - tm0;
 #endif
         {
+            // Wave-cooperative insertion of the wave's pending hits (at most one per lane), one at a time: the hit is
+            // broadcast, lane j < 16 owns slot j of that query's sorted list and computes its new content in ONE step
+            // (new[j] = L[j] if L[j] > key, else key if L[j-1] > key, else L[j-1]) - cost independent of k.
+            // The list's lock is taken by lane 0 only (waves wm = 0, 1 share queries).
+            auto insert_pending = [&](bool pending, u64 key, int q, float& tf) __attribute__((always_inline)) {
+                unsigned long long pm = __ballot(pending);
+#ifdef LVS_TUNING
+                if (a.debug_hot == 3) pm = 0;  // tuning aid: scan for hits but skip the insertions
+#endif
+                while (pm) {
+#ifdef LVS_COUNT_EVENTS
+                    ++n_ins;
+                    const unsigned long long ti0 = __builtin_amdgcn_s_memtime();
+#endif
+                    const int src = __ffsll((long long)pm) - 1;
+                    pm &= pm - 1;
+                    const uint32_t klo = __builtin_amdgcn_readlane((uint32_t)key, src);
+                    const uint32_t khi = __builtin_amdgcn_readlane((uint32_t)(key >> 32), src);
+                    const u64 ukey = ((u64)khi << 32) | klo;
+                    const int uq = __builtin_amdgcn_readlane(q, src);
+                    // Lock + slot reads under ONE wait: lane 0 issues the compare-and-swap, lanes < k issue their
+                    // slot reads right behind it.  LDS executes a wave's DS instructions in order, so when the
+                    // swap succeeded the reads saw the list under the lock; otherwise everything is retried.
+                    u64* UL = lists + uq * KCAP;
+                    u64 mine = 0, prev = ~0ull;
+                    for (;;) {
+                        uint32_t seen = 0;
+                        if (lane == 0) {
+                            __hip_atomic_compare_exchange_strong(&locks[uq], &seen, 1u, __ATOMIC_RELAXED,
+                                                                 __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        }
+                        asm volatile("" ::: "memory");  // keep the reads behind the swap in program order
+                        if (lane < k) {
+                            mine = UL[lane];
+                            if (lane > 0) prev = UL[lane - 1];
+                        }
+                        if (__builtin_amdgcn_readfirstlane(seen) == 0) break;  // lock word was 0: we own it
+                    }
+                    u64 newv = 0;
+                    if (lane < k) newv = mine > ukey ? mine : (prev > ukey ? ukey : prev);
+                    __builtin_amdgcn_wave_barrier();
+                    if (lane < k) UL[lane] = newv;
+                    const uint32_t ntau = __builtin_amdgcn_readlane((uint32_t)(newv >> 32), k - 1);
+                    // unlock: the LDS executes one wave's DS instructions in issue order, so a plain (relaxed)
+                    // store issued after the slot writes is observed after them - no wait for the writes needed
+                    asm volatile("" ::: "memory");
+                    if (lane == 0)
+                        __hip_atomic_store(&locks[uq], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (q == uq) tf = fmaxf(tf, tau_float(ntau));
+#ifdef LVS_COUNT_EVENTS
+                    c_ins += __builtin_amdgcn_s_memtime() - ti0;
+#endif
+                }
+            };
+            // key of a candidate (score s at accumulator register r of the 32 x 32 block whose first row is rbase) and
+            // whether it takes part: inside the shard, below this pass's upper bound, not below the shared threshold
+            auto make_key = [&](float s, int r, long long rbase, u64 ubq, uint32_t go, u64& key) __attribute__((always_inline)) {
+                const long long row = rbase + (r & 3) + 8 * (r >> 2);
+                if (row >= a.nb) return false;
+                const uint32_t id = a.row_ids ? a.row_ids[row] : (uint32_t)(row + a.id_offset);
+                key = lvs_pack_key(s, id);
+                return key < ubq && (uint32_t)(key >> 32) >= go;  // re-checked under the lock
+            };
+
             while (hitmask) {  // rare path: only blocks with candidates are visited
                 const int tsel = __builtin_ctz(hitmask);
                 hitmask &= hitmask - 1;
                 const int mi = tsel >> 1, ni = tsel & 1;
-                f32x16 tv;
-                switch (tsel) {  // wave-uniform: a branch table + 16 moves (a select chain would cost 7 x 16 VALU)
-                    case 0: tv = acc[0][0]; break;
-                    case 1: tv = acc[0][1]; break;
-                    case 2: tv = acc[1][0]; break;
-                    case 3: tv = acc[1][1]; break;
-                    case 4: tv = acc[2 % MI][0]; break;  // cases >= 2 * MI are never taken
-                    case 5: tv = acc[2 % MI][1]; break;
-                    case 6: tv = acc[3 % MI][0]; break;
-                    default: tv = acc[3 % MI][1]; break;
-                }
                 float tf = ni ? tauf[1] : tauf[0];
                 const bool qv = ni ? qvalid[1] : qvalid[0];
-                const bool th = qv && (max16(tv) >= tf);
-                if (!wave_any(th)) continue;
+                // ---- fast extraction: every lane's FIRST candidate of the block in straight-line code (no copy of the
+                // block, no per-row wave-uniform branch); `multi` = lanes holding more than one
+                float cs = 0.f;
+                int cr = -1;
+                u64 anym = 0, multi = 0;
+                switch (tsel) {  // wave-uniform branch table; cases >= 2 * MI are never taken
+                    case 0: first_hit(acc[0][0], tf, qv, cs, cr, anym, multi); break;
+                    case 1: first_hit(acc[0][1], tf, qv, cs, cr, anym, multi); break;
+                    case 2: first_hit(acc[1][0], tf, qv, cs, cr, anym, multi); break;
+                    case 3: first_hit(acc[1][1], tf, qv, cs, cr, anym, multi); break;
+                    case 4: first_hit(acc[2 % MI][0], tf, qv, cs, cr, anym, multi); break;
+                    case 5: first_hit(acc[2 % MI][1], tf, qv, cs, cr, anym, multi); break;
+                    case 6: first_hit(acc[3 % MI][0], tf, qv, cs, cr, anym, multi); break;
+                    default: first_hit(acc[3 % MI][1], tf, qv, cs, cr, anym, multi); break;
+                }
+                if (anym == 0) continue;  // the thresholds rose since the filter looked
 #ifdef LVS_COUNT_EVENTS
                 ++n_visit;
 #endif
@@ -570,79 +653,41 @@ __global__ __launch_bounds__(512, 2) void lvs_tile_kernel(const LvsTileArgs a) {
                 // the visiting wave is on the workgroup's critical path (the next barrier waits for it): let its
                 // instructions win the issue arbitration against the other wave's MFMAs
                 __builtin_amdgcn_s_setprio(3);
-#pragma unroll
-                for (int g4 = 0; g4 < 4; ++g4) {  // rows 8g .. 8g+3: skip the group when none of its four scores can enter
-                    const float m4 = max4(tv[4 * g4], tv[4 * g4 + 1], tv[4 * g4 + 2], tv[4 * g4 + 3]);
-                    if (!wave_any(th && m4 >= tf)) continue;
-#pragma unroll
-                for (int e4 = 0; e4 < 4; ++e4) {
-                    const int r = 4 * g4 + e4;
-                    const float s = tv[r];
-                    if (!wave_any(th && s >= tf)) continue;  // wave-uniform skip before any per-lane work
-                    bool pending = false;
+                {
                     u64 key = 0;
-                    if (th && s >= tf) {
-                        const long long row = rbase + (r & 3) + 8 * (r >> 2);
-                        if (row < a.nb) {
-                            const uint32_t id = a.row_ids ? a.row_ids[row] : (uint32_t)(row + a.id_offset);
-                            key = lvs_pack_key(s, id);
-                            pending = key < ubq && (uint32_t)(key >> 32) >= go;  // re-checked under the lock
-                        }
+                    const bool pending = cr >= 0 && make_key(cs, cr, rbase, ubq, go, key);
+                    insert_pending(pending, key, q, tf);
+                }
+                if (multi) {
+                    // some lane holds two or more candidates in this block (cold lists, duplicate-heavy data): the
+                    // row-by-row pass takes the rest against the thresholds the first candidates just raised
+                    f32x16 tv;
+                    switch (tsel) {  // a branch table + 16 moves (a select chain would cost 7 x 16 VALU)
+                        case 0: tv = acc[0][0]; break;
+                        case 1: tv = acc[0][1]; break;
+                        case 2: tv = acc[1][0]; break;
+                        case 3: tv = acc[1][1]; break;
+                        case 4: tv = acc[2 % MI][0]; break;
+                        case 5: tv = acc[2 % MI][1]; break;
+                        case 6: tv = acc[3 % MI][0]; break;
+                        default: tv = acc[3 % MI][1]; break;
                     }
-                    // Wave-cooperative insertion, one pending hit at a time: the hit is broadcast, lane j < 16 owns
-                    // slot j of that query's sorted list and computes its new content in ONE step
-                    // (new[j] = L[j] if L[j] > key, else key if L[j-1] > key, else L[j-1]) - cost independent of k.
-                    // The list's lock is taken by lane 0 only (waves wm = 0, 1 share queries).
-                    unsigned long long pm = __ballot(pending);
-#ifdef LVS_TUNING
-                    if (a.debug_hot == 3) pm = 0;  // tuning aid: scan for hits but skip the insertions
-#endif
-                    while (pm) {
-#ifdef LVS_COUNT_EVENTS
-                        ++n_ins;
-                        const unsigned long long ti0 = __builtin_amdgcn_s_memtime();
-#endif
-                        const int src = __ffsll((long long)pm) - 1;
-                        pm &= pm - 1;
-                        const uint32_t klo = __builtin_amdgcn_readlane((uint32_t)key, src);
-                        const uint32_t khi = __builtin_amdgcn_readlane((uint32_t)(key >> 32), src);
-                        const u64 ukey = ((u64)khi << 32) | klo;
-                        const int uq = __builtin_amdgcn_readlane(q, src);
-                        // Lock + slot reads under ONE wait: lane 0 issues the compare-and-swap, lanes < k issue their
-                        // slot reads right behind it.  LDS executes a wave's DS instructions in order, so when the
-                        // swap succeeded the reads saw the list under the lock; otherwise everything is retried.
-                        u64* UL = lists + uq * KCAP;
-                        u64 mine = 0, prev = ~0ull;
-                        for (;;) {
-                            uint32_t seen = 0;
-                            if (lane == 0) {
-                                __hip_atomic_compare_exchange_strong(&locks[uq], &seen, 1u, __ATOMIC_RELAXED,
-                                                                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                            }
-                            asm volatile("" ::: "memory");  // keep the reads behind the swap in program order
-                            if (lane < k) {
-                                mine = UL[lane];
-                                if (lane > 0) prev = UL[lane - 1];
-                            }
-                            if (__builtin_amdgcn_readfirstlane(seen) == 0) break;  // lock word was 0: we own it
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) {  // rows 8g .. 8g+3: skip the group when none of its four scores can enter
+                        const float m4 = max4(tv[4 * g4], tv[4 * g4 + 1], tv[4 * g4 + 2], tv[4 * g4 + 3]);
+                        if (!wave_any(qv && m4 >= tf)) continue;
+#pragma unroll
+                        for (int e4 = 0; e4 < 4; ++e4) {
+                            const int r = 4 * g4 + e4;
+                            const float s = tv[r];
+                            const bool cand = qv && s >= tf && r != cr;  // (lane, cr) went through the fast path
+                            if (!wave_any(cand)) continue;               // wave-uniform skip before any per-lane work
+                            u64 key = 0;
+                            const bool pending = cand && make_key(s, r, rbase, ubq, go, key);
+                            insert_pending(pending, key, q, tf);
                         }
-                        u64 newv = 0;
-                        if (lane < k) newv = mine > ukey ? mine : (prev > ukey ? ukey : prev);
-                        __builtin_amdgcn_wave_barrier();
-                        if (lane < k) UL[lane] = newv;
-                        const uint32_t ntau = __builtin_amdgcn_readlane((uint32_t)(newv >> 32), k - 1);
-                        // unlock: the LDS executes one wave's DS instructions in issue order, so a plain (relaxed)
-                        // store issued after the slot writes is observed after them - no wait for the writes needed
-                        asm volatile("" ::: "memory");
-                        if (lane == 0)
-                            __hip_atomic_store(&locks[uq], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        if (q == uq) tf = fmaxf(tf, tau_float(ntau));
-#ifdef LVS_COUNT_EVENTS
-                        c_ins += __builtin_amdgcn_s_memtime() - ti0;
-#endif
                     }
                 }
-                }  // g4
                 if (wave >= 4) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
                 if (ni) tauf[1] = fmaxf(tauf[1], tf); else tauf[0] = fmaxf(tauf[0], tf);
             }
