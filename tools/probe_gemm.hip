@@ -271,6 +271,217 @@ __global__ __launch_bounds__(WM * WN * 64, WPE) void gemm_probe(const _Float16* 
     for (int ni = 0; ni < NI; ++ni) out[((long long)blockIdx.x * NW + wave) * 64 * NI + ni * 64 + lane] = best[ni];
 }
 
+
+// ---- role-split ("ping-pong") K-step: the two waves of a SIMD alternate between a LOAD section (LDS fragment reads of
+// the next quadrant + staging loads of the next K-step) and an MFMA section (one quadrant: 2 corpus blocks x 1 query block
+// x K = 64 -> 8 MFMAs), separated by workgroup barriers; waves 4-7 run one section behind waves 0-3, so on every SIMD one
+// wave computes while its partner loads.  Same tile geometry, LDS image and swizzle as the product kernel (2 x 4 waves,
+// 128 x 64 per wave).  Quadrant order per K-step: (A01,B0) (A01,B1) (A23,B1) (A23,B0); B0 keeps its own registers, so a
+// K-step reads 24 fragments as before.  VARIANT bit 0: s_setprio(1) around the MFMA sections; bit 1: no stagger (all
+// waves in lockstep - the control); bit 2: staging loads in LOAD(0)/(1) instead of (1)/(2).
+template <int VARIANT>
+__global__ __launch_bounds__(512, 2) void gemm_pingpong(const _Float16* __restrict__ xb, const _Float16* __restrict__ xq,
+                                                        float* __restrict__ out, int ntiles, int nk, long long ld, int qmod,
+                                                        unsigned* __restrict__ simd_ids) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / 4, wn = wave % 4;
+    const int grp = (VARIANT & 2) ? 0 : wm;  // waves 4-7 = second group
+    if (simd_ids && blockIdx.x == 0 && lane == 0) simd_ids[wave] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));  // HW_ID
+    const int xcd = blockIdx.x & 7, li = (blockIdx.x >> 3) & 31, gen = blockIdx.x >> 8;
+    const int gq = qmod;
+    const int qt = (gen * 8 + xcd) * gq + (li % gq);
+    const int slab = li / gq, nsl = 32 / gq;
+    const int tile0 = slab * (ntiles / nsl);
+    const long long q0 = (long long)qt * BQ;
+    constexpr int RPW = 64, GL = 8;  // staged rows / glds per wave per K-step
+    unsigned loff[GL];
+    const char* sbase[GL];
+#pragma unroll
+    for (int i = 0; i < GL; ++i) {
+        int row = wave * RPW + i * 8 + (lane >> 3);
+        int col = ((lane & 7) ^ ((row >> 1) & 7)) * 8;
+        bool isq = row >= BC;
+        long long grow = isq ? q0 + (row - BC) : row;
+        loff[i] = (unsigned)((grow * ld + col) * 2);
+        sbase[i] = (const char*)(isq ? xq : xb);
+    }
+    int foff[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk)
+        foff[kk] = (lane & 31) * ROWB + ((((kk * 2) + (lane >> 5)) ^ (((lane & 31) >> 1) & 7)) << 4);
+    const int a_base = wm * 4 * 32 * ROWB;
+    const int b_base = BC * ROWB + wn * 2 * 32 * ROWB;
+    f32x16 acc[4][2];
+    float best[2] = {-1e30f, -1e30f};
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+    const int T = ntiles * nk;
+    auto glds_part = [&](int t, int buf, int i0, int i1) {  // staging loads i0..i1-1 of K-step t into buffer buf
+        int ti = t / nk, ks = t - ti * nk;
+        ti = (ti + tile0) % ntiles;
+#pragma unroll
+        for (int i = 0; i < GL; ++i) {
+            if (i < i0 || i >= i1) continue;
+            int row = wave * RPW + i * 8;
+            bool isq = row >= BC;
+            long long tile_off = isq ? 0 : (long long)ti * BC * ld * 2;
+            glds16(sbase[i] + tile_off + loff[i] + ks * BK * 2, smem + buf * STAGE + row * ROWB);
+        }
+    };
+    glds_part(0, 0, 0, 8);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (grp == 1) __builtin_amdgcn_s_barrier();  // the second group runs one section behind
+    half8 A[2][4], B0[4], B1[4];
+    int ksin = 0;
+    constexpr int G0 = (VARIANT & 4) ? 0 : 1;  // LOAD section that issues the first half of the staging loads
+    for (int t = 0; t < T; ++t) {
+        if (simd_ids && blockIdx.x == 1001 && lane == 0 && (t == 200 || t == 1224)) {  // cycles per K-step (wave-level clock)
+            unsigned long long c = __builtin_amdgcn_s_memtime();
+            simd_ids[16 + wave * 4 + (t == 200 ? 0 : 2)] = (unsigned)c;
+            simd_ids[16 + wave * 4 + (t == 200 ? 1 : 3)] = (unsigned)(c >> 32);
+        }
+        const unsigned sbu = (unsigned)(unsigned long long)(smem + (t & 1) * STAGE);
+        const int tn = t + 1 < T ? t + 1 : T - 1;
+        // ---------------- LOAD(0): A blocks 0,1 and B block 0 ----------------
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) lds_read16(B0[kk], sbu + b_base + foff[kk]);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            lds_read16(A[0][kk], sbu + a_base + foff[kk]);
+            lds_read16(A[1][kk], sbu + a_base + 32 * ROWB + foff[kk]);
+        }
+        if (G0 == 0 && !(VARIANT & 8)) glds_part(tn, (t & 1) ^ 1, 0, 4);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        if (VARIANT & 1) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[0][kk], B0[kk], acc[0][0], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[1][kk], B0[kk], acc[1][0], 0, 0, 0);
+            if (VARIANT & 8) {  // staging loads inside the MFMA section, one per MFMA pair (as the product loop does)
+                __builtin_amdgcn_sched_barrier(0);
+                glds_part(tn, (t & 1) ^ 1, kk, kk + 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (VARIANT & 1) __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        // ---------------- LOAD(1): B block 1 ----------------
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) lds_read16(B1[kk], sbu + b_base + 32 * ROWB + foff[kk]);
+        if (!(VARIANT & 8)) glds_part(tn, (t & 1) ^ 1, G0 == 0 ? 4 : 0, G0 == 0 ? 8 : 4);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        if (VARIANT & 1) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[0][kk], B1[kk], acc[0][1], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[1][kk], B1[kk], acc[1][1], 0, 0, 0);
+            if (VARIANT & 8) {
+                __builtin_amdgcn_sched_barrier(0);
+                glds_part(tn, (t & 1) ^ 1, 4 + kk, 5 + kk);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (VARIANT & 1) __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        // ---------------- LOAD(2): A blocks 2,3 ----------------
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            lds_read16(A[0][kk], sbu + a_base + 64 * ROWB + foff[kk]);
+            lds_read16(A[1][kk], sbu + a_base + 96 * ROWB + foff[kk]);
+        }
+        if (G0 == 1 && !(VARIANT & 8)) glds_part(tn, (t & 1) ^ 1, 4, 8);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        if (VARIANT & 1) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            acc[2][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[0][kk], B1[kk], acc[2][1], 0, 0, 0);
+            acc[3][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[1][kk], B1[kk], acc[3][1], 0, 0, 0);
+        }
+        if (VARIANT & 1) __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        // ---------------- LOAD(3): nothing to read (B0 is still in registers); the second group's staging loads must
+        // have landed before the barrier that lets the first group start the next K-step ----------------
+        if (grp == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        if (VARIANT & 1) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            acc[2][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[0][kk], B0[kk], acc[2][0], 0, 0, 0);
+            acc[3][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[1][kk], B0[kk], acc[3][0], 0, 0, 0);
+        }
+        if (VARIANT & 1) __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (grp == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // ... and the first group's, same barrier
+        __builtin_amdgcn_s_barrier();
+        if (++ksin < nk) continue;
+        ksin = 0;
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) best[ni] = fmaxf(best[ni], acc[mi][ni][r]);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+            }
+    }
+    if (grp == 0) __builtin_amdgcn_s_barrier();  // even out the barrier count of the two groups
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) out[((long long)blockIdx.x * 8 + wave) * 64 * 2 + ni * 64 + lane] = best[ni];
+}
+
+template <int VARIANT>
+void run_pp(const char* name, const _Float16* xb, const _Float16* xq, float* out, int nqt, int ntiles, int nk, long long ld,
+            const float* ref_out, unsigned* simd_ids) {
+    auto k = gemm_pingpong<VARIANT>;
+    CHECK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE));
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0));
+    CHECK(hipEventCreate(&e1));
+    float best = 1e30f;
+    for (int it = 0; it < 4; ++it) {
+        CHECK(hipEventRecord(e0));
+        hipLaunchKernelGGL(k, dim3(nqt), dim3(512), 2 * STAGE, 0, xb, xq, out, ntiles, nk, ld, 32, simd_ids);
+        CHECK(hipEventRecord(e1));
+        CHECK(hipEventSynchronize(e1));
+        float ms;
+        CHECK(hipEventElapsedTime(&ms, e0, e1));
+        if (it > 0 && ms < best) best = ms;
+    }
+    double fl = 2.0 * nqt * 256.0 * ntiles * 256.0 * nk * 64.0;
+    // same maxima as the reference kernel?  (the reduction order inside a dot product is identical: K ascending)
+    size_t n = (size_t)nqt * 8 * 128, bad = 0;
+    std::vector<float> a(n), b(n);
+    CHECK(hipMemcpy(a.data(), out, n * 4, hipMemcpyDeviceToHost));
+    CHECK(hipMemcpy(b.data(), ref_out, n * 4, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < n; ++i) bad += a[i] != b[i];
+    unsigned hs[64];
+    CHECK(hipMemcpy(hs, simd_ids, sizeof(hs), hipMemcpyDeviceToHost));
+    auto u64of = [&](int i) { return ((unsigned long long)hs[i + 1] << 32) | hs[i]; };
+    double cyc0 = (double)(u64of(16 + 2) - u64of(16)) / 1024.0, cyc4 = (double)(u64of(16 + 16 + 2) - u64of(16 + 16)) / 1024.0;
+    double us_per_kstep = best * 1e3 / ((double)ntiles * nk * (nqt / 256.0));
+    printf("%-44s %8.2f ms  %7.1f TFLOP/s   cyc/K-step wave0 %.0f wave4 %.0f  clock %.2f GHz   mismatches: %zu\n", name, best,
+           fl / (best * 1e-3) / 1e12, cyc0, cyc4, cyc0 / us_per_kstep / 1e3, bad);
+    fflush(stdout);
+}
+
 template <int WM, int WN, int MI, int NI, int WPE, int DEPTH, int BPOS, int PRIO, int SPREAD, int ABL = 0>
 void run(const char* name, const _Float16* xb, const _Float16* xq, float* out, int nqt, int ntiles, int nk, long long ld, unsigned long long* stamps = nullptr, int qmod = 32) {
     auto k = gemm_probe<WM, WN, MI, NI, WPE, DEPTH, BPOS, PRIO, SPREAD, 0, ABL>;
@@ -325,26 +536,43 @@ void clock_of(const char* name, const _Float16* xb, const _Float16* xq, float* o
     fflush(stdout);
 }
 
-int main() {
+int main(int argc, char** argv) {
     const int d = 768, nk = d / 64;
-    const int nqt = 2048 * 2;             // 4096 query tiles of 256 = 1M queries (16 blocks per CU)
+    const int nqt = 2048;                 // 2048 query tiles of 256 = 512k queries (8 blocks per CU)
     const int ntiles = 256;               // 65 536 corpus rows per block
     const long long nq = (long long)nqt * 256, nb = (long long)ntiles * 256;
     std::vector<_Float16> h((size_t)(nq > nb ? nq : nb) * d);
     srand(1);
     for (auto& v : h) v = (_Float16)((rand() % 2001 - 1000) / 1000.0f * 0.06f);
     _Float16 *xb, *xq;
-    float* out;
+    float *out, *ref;
+    unsigned* ids;
     CHECK(hipMalloc(&xb, nb * d * 2));
     CHECK(hipMalloc(&xq, nq * d * 2));
     CHECK(hipMalloc(&out, (size_t)nqt * 16 * 64 * 4 * 4));
+    CHECK(hipMalloc(&ref, (size_t)nqt * 16 * 64 * 4 * 4));
+    CHECK(hipMalloc(&ids, 1024));
     CHECK(hipMemcpy(xb, h.data(), nb * d * 2, hipMemcpyHostToDevice));
-    CHECK(hipMemcpy(xq, h.data(), nq * d * 2, hipMemcpyHostToDevice));
+    CHECK(hipMemcpy(xq, h.data() + 12345 * d, nq * d * 2 - 12345 * d * 2, hipMemcpyHostToDevice));
+    unsigned long long* stamps;
+    CHECK(hipMalloc(&stamps, 2 * 8 * 64 * 3 * 8));
     for (int rep = 0; rep < 2; ++rep) {
-        run<2, 4, 4, 2, 2, 2, 2, 1, 3>("8 waves 128x64, asm waits", xb, xq, out, nqt, ntiles, nk, d);
-        run<2, 2, 4, 4, 1, 2, 2, 0, 4>("4 waves 128x128, asm, depth 2, B at 2", xb, xq, out, nqt, ntiles, nk, d);
-        run<2, 2, 4, 4, 1, 3, 1, 0, 4>("4 waves 128x128, asm, depth 3, B at 1", xb, xq, out, nqt, ntiles, nk, d);
-        run<2, 2, 4, 4, 1, 2, 0, 0, 4>("4 waves 128x128, asm, depth 2, B at 0", xb, xq, out, nqt, ntiles, nk, d);
+        if (rep == 1) {  // the same binaries on zero-filled operands: no data-dependent switching power
+            CHECK(hipMemset(xb, 0, nb * d * 2));
+            CHECK(hipMemset(xq, 0, nq * d * 2));
+            printf("---- zero-filled operands ----\n");
+        }
+        clock_of<3, 0>("product loop (stamped)", xb, xq, ref, nqt, ntiles, nk, d, stamps);
+        run<2, 4, 4, 2, 2, 2, 2, 1, 3>("8 waves 128x64, asm waits (product loop)", xb, xq, ref, nqt, ntiles, nk, d);
+        run_pp<1>("ping-pong + setprio", xb, xq, out, nqt, ntiles, nk, d, ref, ids);
+        run_pp<8>("ping-pong, staging inside MFMA 0/1", xb, xq, out, nqt, ntiles, nk, d, ref, ids);
+        run_pp<9>("ping-pong + setprio, staging inside MFMA 0/1", xb, xq, out, nqt, ntiles, nk, d, ref, ids);
+        run_pp<10>("no stagger, staging inside MFMA 0/1", xb, xq, out, nqt, ntiles, nk, d, ref, ids);
     }
+    unsigned hid[8];
+    CHECK(hipMemcpy(hid, ids, 32, hipMemcpyDeviceToHost));
+    printf("wave -> SIMD of block 0:");
+    for (int w = 0; w < 8; ++w) printf(" %u:%u", w, (hid[w] >> 4) & 3);
+    printf("\n");
     return 0;
 }
