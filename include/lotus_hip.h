@@ -134,7 +134,22 @@ int32_t lvs_range_join(const void* xb, int32_t xb_pack, int64_t nb, const void* 
                        int64_t* out_q, int64_t* out_j, float* out_s, uint64_t* out_count, void* stream);
 
 /* ---- k-means pieces: replace faiss `Kmeans(d, k, niter).train(x)` (lotus/utils.py:61-62); the assignment step and
- * the final `kmeans.index.search(x, 1)` (utils.py:65) are lvs_flat_search_keys with k = 1 and LVS_METRIC_L2. ---- */
+ * the final `kmeans.index.search(x, 1)` (utils.py:65) are lvs_flat_search_keys with k = 1 and LVS_METRIC_L2 - or, in ONE
+ * MFMA pass whatever the pack modes, the certified pair below. ---- */
+/* Nearest corpus row of every query from the fp16 "hi" parts of both operands only (hi|lo rows are read at their own
+ * leading dimension, the lo halves are skipped), with the exact norms of the stored values: out_keys [nq] = winner key,
+ * out_second [nq] = runner-up score in the "larger = better" domain (-inf when there is none).  The true score of a
+ * (query, row) pair differs from this one by at most 2 |q| |lo_row| + 2 |lo_q| |row| (Cauchy-Schwarz), so a winner whose
+ * margin exceeds twice that bound is the exact winner; lvs_margin_select lists the queries that are NOT certified so
+ * that only those go through the exact (2-3 pass) search again. */
+int64_t lvs_nearest_hi_workspace_bytes(int64_t nq, int64_t nb, int32_t d);
+int32_t lvs_nearest_hi(const void* xb, int32_t xb_pack, int64_t nb, const void* xq, int32_t xq_pack, int64_t nq, int32_t d,
+                       int32_t metric, const float* xb_norms_sq, const float* xq_norms_sq, int64_t id_offset,
+                       uint64_t* out_keys, float* out_second, void* workspace, int64_t workspace_bytes, void* stream);
+/* out_idx [<= nq] (order unspecified) = queries with score(key) - second <= scale * sqrt(q_norms_sq) + slack;
+ * *out_count (device uint64, zeroed by the caller) += their number.  q_norms_sq NULL means |q| = 1. */
+int32_t lvs_margin_select(const uint64_t* keys, const float* second, const float* q_norms_sq, int64_t nq, float scale,
+                          float slack, int64_t* out_idx, uint64_t* out_count, void* stream);
 int64_t lvs_kmeans_accumulate_workspace_bytes(int64_t n, int32_t k);
 /* sums [k][d] float32 += packed rows of x grouped by assign[i] (int64, values outside [0,k) are skipped);
  * counts [k] float32 += group sizes.  Both must be initialised by the caller.  Rows of one centroid are added

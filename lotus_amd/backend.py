@@ -130,6 +130,54 @@ class HipBackend:
                 _ptr(keys), _ptr(ws), int(ws.numel()), self._stream())
         return keys
 
+    def nearest(self, corpus: PackedRows, queries: PackedRows, metric: int, id_offset: int = 0, stats: dict | None = None):
+        """Nearest corpus row of every query (k = 1) -> int64 key tensor [nq, 1], same winner as ``search_keys(.., 1, ..)``.
+
+        fp32-accurate operands (fp16 hi|lo rows) cost two or three MFMA passes in the exact search.  Here ONE pass over
+        the hi parts (``lvs_nearest_hi``) gives every query a winner and its margin over the runner-up; the true score
+        of a pair differs from the hi-only score by at most |q| |lo_row| + |lo_q| |row| (Cauchy-Schwarz), so a margin
+        above twice that bound certifies the winner.  Only the uncertified queries (``lvs_margin_select``: ties,
+        near-ties) are searched again exactly.  This is the k-means assignment step (``lotus/utils.py:62,65``) with
+        fp32-accurate centroids at the cost of fp16 ones."""
+        torch = self.torch
+        if corpus.mode == _capi.PACK_F16 and queries.mode == _capi.PACK_F16:
+            return self.search_keys(corpus, queries, 1, metric, id_offset=id_offset)  # nothing to certify: already exact
+        if corpus.d != queries.d:
+            raise ValueError("corpus / query dimension mismatch")
+        nq = queries.n
+        keys = torch.empty((nq, 1), dtype=torch.int64, device=self.device)
+        if nq == 0 or corpus.n == 0:
+            return self.search_keys(corpus, queries, 1, metric, id_offset=id_offset)
+        # error bound per unit of |q|: largest lo-part norm and largest norm over the corpus rows (a small matrix in the
+        # k-means use: the centroids)
+        dpad = int(corpus.rows.shape[1]) // (2 if corpus.mode == _capi.PACK_SPLIT else 1)
+        R = float(corpus.norms.max().sqrt().item())
+        E = 0.0
+        if corpus.mode == _capi.PACK_SPLIT:
+            E = float(corpus.rows[:, dpad:].float().square().sum(dim=1).max().sqrt().item())
+        per_q = E + (2.0 ** -11) * R * (1.0 if queries.mode == _capi.PACK_SPLIT else 0.0)
+        c = 2.0 if metric == _capi.METRIC_IP else 4.0
+        scale = c * (per_q + 8e-6 * R)          # + fp32 accumulation noise of both searches, relative to |q| |row|
+        slack = 1e-6 * (1.0 + R * R)
+        sec = torch.empty((nq,), dtype=torch.float32, device=self.device)
+        need = int(self.lib.lvs_nearest_hi_workspace_bytes(nq, corpus.n, corpus.d))
+        ws = self._workspace(need)
+        self._c("lvs_nearest_hi", _ptr(corpus.rows), corpus.mode, corpus.n, _ptr(queries.rows), queries.mode, nq, corpus.d,
+                metric, _ptr(corpus.norms), _ptr(queries.norms), int(id_offset), _ptr(keys), _ptr(sec), _ptr(ws),
+                int(ws.numel()), self._stream())
+        idx = torch.empty((nq,), dtype=torch.int64, device=self.device)
+        cnt = torch.zeros((1,), dtype=torch.int64, device=self.device)
+        self._c("lvs_margin_select", _ptr(keys), _ptr(sec), _ptr(queries.norms), nq, float(scale), float(slack), _ptr(idx),
+                _ptr(cnt), self._stream())
+        n_open = int(cnt.item())
+        if n_open:
+            sel = idx[:n_open]
+            keys[sel] = self.search_keys(corpus, self.gather(queries, sel), 1, metric, id_offset=id_offset)
+        if stats is not None:
+            stats["uncertified"] = stats.get("uncertified", 0) + n_open
+            stats["queries"] = stats.get("queries", 0) + nq
+        return keys
+
     def merge_keys(self, parts):
         """parts int64 [P, nq, k] -> [nq, k]."""
         torch = self.torch

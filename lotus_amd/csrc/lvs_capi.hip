@@ -327,6 +327,52 @@ __global__ __launch_bounds__(256) void keys_to_result_kernel(const u64* __restri
     I[i] = id_map ? id_map[id] : id;
 }
 
+// certified nearest-row search: combine the slabs' (winner key, runner-up score) pairs of every query
+__global__ __launch_bounds__(256) void merge_top2_kernel(const u64* __restrict__ keys, const float* __restrict__ sec,
+                                                         int nslab, long long nq, u64* __restrict__ out_keys,
+                                                         float* __restrict__ out_sec) {
+    const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nq) return;
+    u64 best = 0;
+    for (int p = 0; p < nslab; ++p) {
+        const u64 v = keys[(long long)p * nq + q];
+        best = v > best ? v : best;
+    }
+    float s2 = -INFINITY;
+    for (int p = 0; p < nslab; ++p) {
+        const u64 v = keys[(long long)p * nq + q];
+        const float cand = v == best ? sec[(long long)p * nq + q] : (v ? lvs_unord32((uint32_t)(v >> 32)) : -INFINITY);
+        s2 = fmaxf(s2, cand);
+    }
+    out_keys[q] = best;
+    out_sec[q] = s2;
+}
+
+// queries whose winner is NOT certified by its margin: (best score - runner-up score) <= scale * |q| + slack.
+// Their indices are appended to out_idx (order unspecified), *out_count counts them.
+__global__ __launch_bounds__(256) void margin_select_kernel(const u64* __restrict__ keys, const float* __restrict__ sec,
+                                                            const float* __restrict__ qn, long long nq, float scale,
+                                                            float slack, long long* __restrict__ out_idx,
+                                                            unsigned long long* __restrict__ out_count) {
+    const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    bool open = false;
+    if (q < nq) {
+        const u64 kq = keys[q];
+        if (kq) {
+            const float best = lvs_unord32((uint32_t)(kq >> 32));
+            const float bound = scale * sqrtf(qn ? qn[q] : 1.0f) + slack;
+            open = !((best - sec[q]) > bound);  // also true for NaN / inf - inf: never certify what cannot be compared
+        }
+    }
+    const unsigned long long m = __ballot(open);
+    if (m == 0) return;
+    const int lane = threadIdx.x & 63;
+    unsigned long long base = 0;
+    if (lane == 0) base = atomicAdd(out_count, (unsigned long long)__popcll(m));
+    base = lvs_shfl_u64(base, 0);
+    if (open) out_idx[base + __popcll(m & ((1ull << lane) - 1ull))] = q;
+}
+
 }  // namespace
 
 extern "C" int32_t lvs_pack_rows(const void* src, int32_t src_dtype, int64_t n, int32_t d, int32_t pack_mode,
@@ -916,6 +962,85 @@ extern "C" int32_t lvs_flat_search_keys(const void* xb, int32_t xb_pack, int64_t
                 (double)h[5] / (double)(h[2] ? h[2] : 1), (double)(h[4] - h[5]) / (double)(h[0] ? h[0] : 1),
                 (double)h[5] / (double)(h[1] ? h[1] : 1));
     }
+    return LVS_OK;
+}
+
+extern "C" int64_t lvs_nearest_hi_workspace_bytes(int64_t nq, int64_t nb, int32_t d) {
+    Plan p;
+    if (make_plan(nq, nb, d, LVS_PACK_F16, LVS_PACK_F16, 1, p, true) != LVS_OK) return LVS_EINVAL;
+    return 256 + lvs_round_up((int64_t)p.nslab * nq * 8, 256) + lvs_round_up((int64_t)p.nslab * nq * 4, 256);
+}
+
+extern "C" int32_t lvs_nearest_hi(const void* xb, int32_t xb_pack, int64_t nb, const void* xq, int32_t xq_pack, int64_t nq,
+                                  int32_t d, int32_t metric, const float* xb_norms_sq, const float* xq_norms_sq,
+                                  int64_t id_offset, uint64_t* out_keys, float* out_second, void* workspace,
+                                  int64_t workspace_bytes, void* stream) {
+    Plan p;
+    LVS_REQUIRE(make_plan(nq, nb, d, xb_pack, xq_pack, 1, p, true) == LVS_OK, "bad shape nq=%lld nb=%lld d=%d pack=%d/%d",
+                (long long)nq, (long long)nb, d, xb_pack, xq_pack);
+    LVS_REQUIRE(metric == LVS_METRIC_IP || metric == LVS_METRIC_L2, "bad metric %d", metric);
+    LVS_REQUIRE(id_offset >= 0 && id_offset + nb < 0xFFFFFFFFll, "ids must stay below 2^32-1");
+    if (nq == 0) return LVS_OK;
+    LVS_REQUIRE(out_keys && out_second, "NULL output");
+    LVS_REQUIRE(nb > 0 && xb && xq, "NULL rows / empty corpus");
+    LVS_REQUIRE(metric != LVS_METRIC_L2 || (xb_norms_sq && xq_norms_sq), "L2 needs both norm vectors");
+    const int64_t need = lvs_nearest_hi_workspace_bytes(nq, nb, d);
+    if (!workspace || workspace_bytes < need) {
+        lvs_set_error("workspace too small: need %lld bytes, got %lld", (long long)need, (long long)workspace_bytes);
+        return LVS_ENOMEM;
+    }
+    LVS_DEVICE_GUARD(stream);
+    hipStream_t st = (hipStream_t)stream;
+    char* ws = (char*)workspace + 256;
+    u64* pk = (u64*)ws;
+    float* ps = (float*)(ws + lvs_round_up((int64_t)p.nslab * nq * 8, 256));
+    LvsTileArgs a;
+    memset(&a, 0, sizeof(a));
+    a.xb = xb;
+    a.xq = xq;
+    a.bn = xb_norms_sq;
+    a.qn = xq_norms_sq;
+    a.nb = nb;
+    a.nq = nq;
+    a.ldb = p.ldb;  // SPLIT rows keep their leading dimension; only the fp16 "hi" half (columns [0, dpad)) is read
+    a.ldq = p.ldq;
+    a.nseg = 1;
+    a.id_offset = id_offset;
+    a.nkd = p.nkd;
+    a.nk = p.nkd;
+    a.metric = metric;
+    a.k = 1;
+    a.ntiles = p.ntiles;
+    a.tiles_per_slab = p.tiles_per_slab;
+    a.nslab = p.nslab;
+    a.nqt = p.nqt;
+    a.bq = LVS2_BQ;
+    a.gq = p.gq;
+    a.lead_slabs = p.lead_slabs;
+    a.out = p.nslab == 1 ? (u64*)out_keys : pk;
+    a.out_second = p.nslab == 1 ? out_second : ps;
+    {
+        ScopedKernelTimer timer(st);
+        LVS_HIP_CHECK(lvs_tile_launch(LVS_MODE_TOP2, a, st));
+    }
+    if (p.nslab > 1) {
+        hipLaunchKernelGGL(merge_top2_kernel, dim3((unsigned)lvs_ceil_div(nq, 256)), dim3(256), 0, st, pk, ps, p.nslab,
+                           (long long)nq, (u64*)out_keys, out_second);
+        LVS_HIP_CHECK(hipGetLastError());
+    }
+    return LVS_OK;
+}
+
+extern "C" int32_t lvs_margin_select(const uint64_t* keys, const float* second, const float* q_norms_sq, int64_t nq,
+                                     float scale, float slack, int64_t* out_idx, uint64_t* out_count, void* stream) {
+    LVS_REQUIRE(nq >= 0 && scale >= 0.f && slack >= 0.f, "bad arguments");
+    if (nq == 0) return LVS_OK;
+    LVS_REQUIRE(keys && second && out_idx && out_count, "NULL buffer");
+    LVS_DEVICE_GUARD(stream);
+    hipLaunchKernelGGL(margin_select_kernel, dim3((unsigned)lvs_ceil_div(nq, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const u64*)keys, second, q_norms_sq, (long long)nq, scale, slack, (long long*)out_idx,
+                       (unsigned long long*)out_count);
+    LVS_HIP_CHECK(hipGetLastError());
     return LVS_OK;
 }
 

@@ -16,6 +16,7 @@
 #define LVS_MODE_TOP1 2
 #define LVS_MODE_RANGE 3
 #define LVS_MODE_COLLECT 4
+#define LVS_MODE_TOP2 5     // TOP1 + the runner-up score per query (certified nearest-row search, lvs_nearest_hi)
 
 struct LvsTileArgs {
     const void* xb;           // [nb][ld] fp16 packed corpus shard
@@ -27,6 +28,7 @@ struct LvsTileArgs {
     long long ub_stride;      // stride of ub in u64 elements
     uint32_t* gtau;           // [nq] shared running thresholds (ord32 of the k-th best score), zero-initialised
     u64* out;                 // [nslab][nq][k] per-slab candidate keys
+    float* out_second;        // LVS_MODE_TOP2: [nslab][nq] runner-up score ("better" domain) of every slab
     float* scores;            // LVS_MODE_SCORES: [nq][ld_scores]
     // LVS_MODE_RANGE: emit (query, corpus row, score) for score > threshold
     long long* pair_q;

@@ -196,6 +196,7 @@ __global__ __launch_bounds__(512, 2) void lvs_tile_kernel(const LvsTileArgs a) {
     uint32_t* locks = (uint32_t*)(smem + OFF_LOCK);
     float* bnl = (float*)(smem + OFF_LIST);           // TOP1: |y|^2 of the current corpus tile [BC]
     u64* part = (u64*)(smem + OFF_LIST + BC * 4);     // TOP1: [BQ][4] per-lane partial best keys
+    float* psec = (float*)(smem + OFF_LIST + BC * 4 + BQ * 4 * 8);  // TOP2: [BQ][4] per-lane second-best scores
 
     const _Float16* __restrict__ xb = (const _Float16*)a.xb;
     const _Float16* __restrict__ xq = (const _Float16*)a.xq;
@@ -279,6 +280,7 @@ __global__ __launch_bounds__(512, 2) void lvs_tile_kernel(const LvsTileArgs a) {
         for (int i = tid; i < BQ; i += 512) locks[i] = 0;
     }
     float bestv[2] = {-INFINITY, -INFINITY};
+    float secv[2] = {-INFINITY, -INFINITY};  // TOP2: second-best score seen by this lane
     uint32_t besti[2] = {0xFFFFFFFFu, 0xFFFFFFFFu};
 
     f32x16 acc[MI][2];
@@ -466,9 +468,10 @@ __global__ __launch_bounds__(512, 2) void lvs_tile_kernel(const LvsTileArgs a) {
                         }
                     }
                 }
-        } else if constexpr (MODE == LVS_MODE_TOP1) {
+        } else if constexpr (MODE == LVS_MODE_TOP1 || MODE == LVS_MODE_TOP2) {
             // ---- k == 1: per-lane running best, no lists.  Rows are visited in increasing order, so a strict
-            // "greater" keeps the lowest row among equal scores (the oracle's tie rule). ----
+            // "greater" keeps the lowest row among equal scores (the oracle's tie rule).  TOP2 also keeps the
+            // second-best SCORE (an equal score counts: margin 0), from which the caller certifies the winner. ----
             if (a.metric == LVS_METRIC_L2) {
                 __syncthreads();
                 if (tid < BC) {
@@ -501,6 +504,7 @@ __global__ __launch_bounds__(512, 2) void lvs_tile_kernel(const LvsTileArgs a) {
                                 s = -fmaxf((qnv[ni] + bn4[e]) - 2.0f * s, 0.f);
                             else
                                 s = row < a.nb ? s : -INFINITY;
+                            if constexpr (MODE == LVS_MODE_TOP2) secv[ni] = fmaxf(secv[ni], fminf(s, bestv[ni]));
                             if (s > bestv[ni]) {
                                 bestv[ni] = s;
                                 besti[ni] = (uint32_t)row;
@@ -723,7 +727,7 @@ __global__ __launch_bounds__(512, 2) void lvs_tile_kernel(const LvsTileArgs a) {
     }
 #endif
     if constexpr (MODE == LVS_MODE_RANGE || MODE == LVS_MODE_SCORES || MODE == LVS_MODE_COLLECT) return;
-    if constexpr (MODE == LVS_MODE_TOP1) {
+    if constexpr (MODE == LVS_MODE_TOP1 || MODE == LVS_MODE_TOP2) {
         // four lanes (l, l+32 of waves wm = 0, 1) hold partial winners of each query: combine by key
         __syncthreads();
 #pragma unroll
@@ -731,6 +735,7 @@ __global__ __launch_bounds__(512, 2) void lvs_tile_kernel(const LvsTileArgs a) {
             u64 key = 0;
             if (besti[ni] != 0xFFFFFFFFu) key = lvs_pack_key(bestv[ni], (uint32_t)(besti[ni] + a.id_offset));
             part[qloc[ni] * 4 + wm * 2 + (lane >> 5)] = key;
+            if constexpr (MODE == LVS_MODE_TOP2) psec[qloc[ni] * 4 + wm * 2 + (lane >> 5)] = secv[ni];
         }
         __syncthreads();
         if (tid < BQ && q0 + tid < a.nq) {
@@ -738,6 +743,17 @@ __global__ __launch_bounds__(512, 2) void lvs_tile_kernel(const LvsTileArgs a) {
 #pragma unroll
             for (int j = 1; j < 4; ++j) b = part[tid * 4 + j] > b ? part[tid * 4 + j] : b;
             a.out[(long long)slab * a.nq + q0 + tid] = b;
+            if constexpr (MODE == LVS_MODE_TOP2) {
+                // runner-up score of the slab: the winner lane's own second best, every other lane's best
+                float sec = -INFINITY;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const u64 pj = part[tid * 4 + j];
+                    const float cand = pj == b ? psec[tid * 4 + j] : (pj ? lvs_unord32((uint32_t)(pj >> 32)) : -INFINITY);
+                    sec = fmaxf(sec, cand);
+                }
+                a.out_second[(long long)slab * a.nq + q0 + tid] = sec;
+            }
         }
         return;
     }
@@ -775,6 +791,7 @@ hipError_t lvs_tile_launch(int mode, const LvsTileArgs& a, hipStream_t stream) {
     }
     if (a.bq != LVS2_BQ || a.k > LVS2_KCAP) return hipErrorInvalidValue;
     if (mode == LVS_MODE_TOP1) return launch_one<LVS_MODE_TOP1, 4>(a, stream);
+    if (mode == LVS_MODE_TOP2) return a.out_second ? launch_one<LVS_MODE_TOP2, 4>(a, stream) : hipErrorInvalidValue;
     if (mode == LVS_MODE_RANGE) return launch_one<LVS_MODE_RANGE, 4>(a, stream);
     if (mode == LVS_MODE_SCORES) return launch_one<LVS_MODE_SCORES, 4>(a, stream);
     if (mode == LVS_MODE_COLLECT) return launch_one<LVS_MODE_COLLECT, 4>(a, stream);

@@ -134,3 +134,59 @@ def test_kmeans_scale_smoke(hip_backend):
         ids = r.assign[lab == b]
         agree += np.bincount(ids).max() / len(ids)
     assert agree / (K / 8) > 0.7
+
+
+@pytest.mark.parametrize("cmode,qmode,metric,nq,nb,d", [
+    (SPLIT, F16, L2, 20_000, 1024, 768),    # fp16 points x fp32-accurate centroids: the cfg5 assignment (2 passes -> 1)
+    (SPLIT, SPLIT, L2, 9_000, 300, 384),    # LOTUS's default fp32 embeddings on both sides (3 passes -> 1)
+    (F16, SPLIT, IP, 5_000, 2048, 128),
+    (SPLIT, F16, IP, 3_000, 70_000, 64),    # long corpus: several slabs -> merge_top2
+])
+def test_certified_nearest_equals_the_exact_search(hip_backend, cmode, qmode, metric, nq, nb, d):
+    """`nearest` = one MFMA pass over the hi parts + margin certificate + exact re-search of the uncertified queries;
+    its winners are those of the exact 2-3 pass search, key for key."""
+    be = hip_backend
+    rng = np.random.default_rng(nb + d)
+    xb = synth.corpus(nb, d, seed=4) * 1.3
+    xq = (xb[rng.integers(0, nb, nq)] + 0.25 * synth.corpus(nq, d, seed=8)).astype(np.float32)
+    cb = be.pack(xb.astype(np.float16) if cmode == F16 else xb, cmode)
+    cq = be.pack(xq.astype(np.float16) if qmode == F16 else xq, qmode)
+    stats = {}
+    got = be.nearest(cb, cq, metric, id_offset=7, stats=stats).cpu().numpy()
+    want = be.search_keys(cb, cq, 1, metric, id_offset=7).cpu().numpy()
+    assert np.array_equal(got, want)
+    assert stats["queries"] == nq and stats["uncertified"] <= 0.02 * nq  # the certificate does the work, not the fallback
+
+
+def test_certified_nearest_with_ties_and_lo_only_differences(hip_backend):
+    """Rows that tie exactly, and rows that differ only BELOW fp16 resolution (identical hi parts): the one-pass scores
+    cannot separate them, so those queries must come back uncertified and be decided by the exact search."""
+    be = hip_backend
+    d = 96
+    base = (synth.corpus(50, d, seed=2) * 1.1).astype(np.float32)
+    twin = base.copy()
+    twin[:, 0] += np.float32(3e-5) * np.sign(base[:, 0])  # changes the lo part only (|x| ~ 0.1: fp16 ulp ~ 6e-5 / 2)
+    dup = base[:10].copy()
+    xb = np.concatenate([base, twin, dup]).astype(np.float32)
+    assert np.array_equal(xb[:50].astype(np.float16), xb[50:100].astype(np.float16))
+    xq = (np.concatenate([base, twin]) + 0.01 * synth.corpus(100, d, seed=3)).astype(np.float32)
+    cb, cq = be.pack(xb, SPLIT), be.pack(xq.astype(np.float16), F16)
+    for metric in (L2, IP):
+        stats = {}
+        got = be.nearest(cb, cq, metric, stats=stats).cpu().numpy()
+        want = be.search_keys(cb, cq, 1, metric).cpu().numpy()
+        assert np.array_equal(got, want)
+        assert stats["uncertified"] >= 90  # (almost) every query has a twin or duplicate within the bound
+
+
+def test_kmeans_uses_the_certified_assignment(hip_backend):
+    """fp32 embeddings (hi|lo points AND centroids): the k-means result is unchanged by the one-pass assignment."""
+    from lotus_amd.cluster import kmeans
+
+    rng = np.random.default_rng(5)
+    c = rng.standard_normal((24, 128)).astype(np.float32) * 2
+    x = (c[rng.integers(0, 24, 30_000)] + 0.4 * rng.standard_normal((30_000, 128))).astype(np.float32)
+    r = kmeans(x, 24, niter=6, backend=hip_backend)
+    ref = oracle.kmeans_faiss(_stored(x, SPLIT), 24, niter=6)
+    assert (r.assign == ref.assign).mean() >= 1 - 1e-4
+    assert np.allclose(r.obj, ref.obj, rtol=1e-5)

@@ -93,6 +93,9 @@ scenario("top1_kmeans_2M_x_1024_hilo", "lvs_tile_kernel<2, 4>", lambda: be.searc
          note="k-means assignment, fp16 points x fp32-accurate (hi|lo) centroids: 2 K segments = 2x the MFMA work")
 scenario("top1_kmeans_2M_x_1024_fp16c", "lvs_tile_kernel<2, 4>", lambda: be.search_keys(pc16, pts, 1, L2), 3, warm=1,
          bound="mfma", flops_per_call=2.0 * 2_000_000 * 1024 * D, note="same with fp16 centroids (1 K segment)")
+scenario("nearest_hi_2M_x_1024", "lvs_tile_kernel<5, 4>", lambda: be.nearest(pc, pts, L2), 3, warm=1,
+         bound="mfma", flops_per_call=2.0 * 2_000_000 * 1024 * D,
+         note="certified k-means assignment: ONE pass over the hi parts + margin certificate (same winners as the hi|lo search)")
 # ---- HBM-bound helpers ----
 scenario("km_reduce_4M_x_1024", "km_reduce_kernel", lambda: be.kmeans_accumulate(p4m, assign, 1024), 3, warm=1,
          bytes_per_call=N4 * ld(p4m) * 2)
