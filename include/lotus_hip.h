@@ -146,6 +146,12 @@ int64_t lvs_nearest_hi_workspace_bytes(int64_t nq, int64_t nb, int32_t d);
 int32_t lvs_nearest_hi(const void* xb, int32_t xb_pack, int64_t nb, const void* xq, int32_t xq_pack, int64_t nq, int32_t d,
                        int32_t metric, const float* xb_norms_sq, const float* xq_norms_sq, int64_t id_offset,
                        uint64_t* out_keys, float* out_second, void* workspace, int64_t workspace_bytes, void* stream);
+/* keys [nq] in/out: the score inside every key is replaced by the exact fp32 score (hi + lo parts of both operands) of
+ * the pair (query q, the row the key names) - what the k-means objective sums (faiss Clustering: obj = sum of the
+ * assignment distances). */
+int32_t lvs_rescore_keys(const void* xb, int32_t xb_pack, const void* xq, int32_t xq_pack, int64_t nq, int32_t d,
+                         int32_t metric, const float* xb_norms_sq, const float* xq_norms_sq, int64_t id_offset,
+                         uint64_t* keys, void* stream);
 /* out_idx [<= nq] (order unspecified) = queries with score(key) - second <= scale * sqrt(q_norms_sq) + slack;
  * *out_count (device uint64, zeroed by the caller) += their number.  q_norms_sq NULL means |q| = 1. */
 int32_t lvs_margin_select(const uint64_t* keys, const float* second, const float* q_norms_sq, int64_t nq, float scale,

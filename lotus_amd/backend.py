@@ -170,6 +170,10 @@ class HipBackend:
         self._c("lvs_margin_select", _ptr(keys), _ptr(sec), _ptr(queries.norms), nq, float(scale), float(slack), _ptr(idx),
                 _ptr(cnt), self._stream())
         n_open = int(cnt.item())
+        # the winners are certified, their scores are still the one-pass approximations: put the exact scores in
+        # (one HBM-bound pass over the queries; the k-means objective sums them)
+        self._c("lvs_rescore_keys", _ptr(corpus.rows), corpus.mode, _ptr(queries.rows), queries.mode, nq, corpus.d, metric,
+                _ptr(corpus.norms), _ptr(queries.norms), int(id_offset), _ptr(keys), self._stream())
         if n_open:
             sel = idx[:n_open]
             keys[sel] = self.search_keys(corpus, self.gather(queries, sel), 1, metric, id_offset=id_offset)

@@ -348,6 +348,44 @@ __global__ __launch_bounds__(256) void merge_top2_kernel(const u64* __restrict__
     out_sec[q] = s2;
 }
 
+// one wave per query: the exact score (fp32, hi + lo parts of both operands) of the pair (query q, row named by keys[q])
+// replaces the approximate score inside the key
+template <int QSPLIT, int BSPLIT>
+__global__ __launch_bounds__(256) void rescore_keys_kernel(const _Float16* __restrict__ xb, long long ldb,
+                                                           const _Float16* __restrict__ xq, long long ldq, int dpad,
+                                                           int metric, const float* __restrict__ bn,
+                                                           const float* __restrict__ qn, long long id_offset, long long nq,
+                                                           u64* __restrict__ keys) {
+    const int lane = threadIdx.x & 63;
+    const long long q = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (q >= nq) return;
+    const u64 key = keys[q];
+    if (key == 0) return;
+    const uint32_t id = 0xFFFFFFFFu - (uint32_t)(key & 0xFFFFFFFFull);
+    const long long row = (long long)id - id_offset;
+    const _Float16* qr = xq + q * ldq;
+    const _Float16* br = xb + row * ldb;
+    float acc = 0.f;
+    for (int j = lane * 8; j < dpad; j += 512) {
+        const pk_half8 qh = *(const pk_half8*)(qr + j), bh = *(const pk_half8*)(br + j);
+        pk_half8 ql, bl;
+        if (QSPLIT) ql = *(const pk_half8*)(qr + dpad + j);
+        if (BSPLIT) bl = *(const pk_half8*)(br + dpad + j);
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const float a = (float)qh[t] + (QSPLIT ? (float)ql[t] : 0.f);
+            const float b = (float)bh[t] + (BSPLIT ? (float)bl[t] : 0.f);
+            acc += a * b;
+        }
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) {
+        float better = acc;
+        if (metric == LVS_METRIC_L2) better = -fmaxf((qn[q] + bn[row]) - 2.0f * acc, 0.f);
+        keys[q] = lvs_pack_key(better, id);
+    }
+}
+
 // queries whose winner is NOT certified by its margin: (best score - runner-up score) <= scale * |q| + slack.
 // Their indices are appended to out_idx (order unspecified), *out_count counts them.
 __global__ __launch_bounds__(256) void margin_select_kernel(const u64* __restrict__ keys, const float* __restrict__ sec,
@@ -1028,6 +1066,33 @@ extern "C" int32_t lvs_nearest_hi(const void* xb, int32_t xb_pack, int64_t nb, c
                            (long long)nq, (u64*)out_keys, out_second);
         LVS_HIP_CHECK(hipGetLastError());
     }
+    return LVS_OK;
+}
+
+extern "C" int32_t lvs_rescore_keys(const void* xb, int32_t xb_pack, const void* xq, int32_t xq_pack, int64_t nq, int32_t d,
+                                    int32_t metric, const float* xb_norms_sq, const float* xq_norms_sq, int64_t id_offset,
+                                    uint64_t* keys, void* stream) {
+    LVS_REQUIRE(nq >= 0 && d > 0, "bad shape");
+    LVS_REQUIRE(metric == LVS_METRIC_IP || metric == LVS_METRIC_L2, "bad metric %d", metric);
+    LVS_REQUIRE((xb_pack == LVS_PACK_F16 || xb_pack == LVS_PACK_SPLIT) && (xq_pack == LVS_PACK_F16 || xq_pack == LVS_PACK_SPLIT),
+                "bad pack mode %d/%d", xb_pack, xq_pack);
+    if (nq == 0) return LVS_OK;
+    LVS_REQUIRE(xb && xq && keys, "NULL buffer");
+    LVS_REQUIRE(metric != LVS_METRIC_L2 || (xb_norms_sq && xq_norms_sq), "L2 needs both norm vectors");
+    LVS_DEVICE_GUARD(stream);
+    const int dpad = (int)lvs_round_up(d, LVS_BK);
+    const long long ldb = xb_pack == LVS_PACK_SPLIT ? 2 * dpad : dpad, ldq = xq_pack == LVS_PACK_SPLIT ? 2 * dpad : dpad;
+    const dim3 grid((unsigned)lvs_ceil_div(nq, 4)), block(256);
+    hipStream_t st = (hipStream_t)stream;
+#define LVS_RESCORE(QS, BS)                                                                                              \
+    hipLaunchKernelGGL((rescore_keys_kernel<QS, BS>), grid, block, 0, st, (const _Float16*)xb, ldb, (const _Float16*)xq, ldq, \
+                       dpad, metric, xb_norms_sq, xq_norms_sq, (long long)id_offset, (long long)nq, (u64*)keys)
+    if (xq_pack == LVS_PACK_SPLIT && xb_pack == LVS_PACK_SPLIT) LVS_RESCORE(1, 1);
+    else if (xq_pack == LVS_PACK_SPLIT) LVS_RESCORE(1, 0);
+    else if (xb_pack == LVS_PACK_SPLIT) LVS_RESCORE(0, 1);
+    else LVS_RESCORE(0, 0);
+#undef LVS_RESCORE
+    LVS_HIP_CHECK(hipGetLastError());
     return LVS_OK;
 }
 
