@@ -83,7 +83,14 @@ class HipBackend:
             else:
                 c = x[r0:r1]
                 c = np.ascontiguousarray(c, dtype=np.float16 if c.dtype == np.float16 else np.float32)
-                chunk = torch.from_numpy(c).to(self.device)
+                if not c.flags.writeable:  # a read-only memory map (store.py): the host view is only read by the H2D copy
+                    import warnings
+
+                    with warnings.catch_warnings():
+                        warnings.simplefilter("ignore", UserWarning)
+                        chunk = torch.from_numpy(c).to(self.device)
+                else:
+                    chunk = torch.from_numpy(c).to(self.device)
             src_dtype = _capi.DTYPE_F16 if chunk.dtype == torch.float16 else _capi.DTYPE_F32
             self._c("lvs_pack_rows", _ptr(chunk), src_dtype, r1 - r0, d, mode, int(bool(normalize)), _ptr(rows[r0:r1]),
                     _ptr(norms[r0:r1]), self._stream())

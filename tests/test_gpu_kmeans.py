@@ -164,9 +164,10 @@ def test_certified_nearest_with_ties_and_lo_only_differences(hip_backend):
     cannot separate them, so those queries must come back uncertified and be decided by the exact search."""
     be = hip_backend
     d = 96
-    base = (synth.corpus(50, d, seed=2) * 1.1).astype(np.float32)
+    h16 = (synth.corpus(50, d, seed=2) * 1.1).astype(np.float16)
+    base = h16.astype(np.float32)                                     # exactly representable: lo part 0
     twin = base.copy()
-    twin[:, 0] += np.float32(3e-5) * np.sign(base[:, 0])  # changes the lo part only (|x| ~ 0.1: fp16 ulp ~ 6e-5 / 2)
+    twin[:, :8] += 0.3 * np.spacing(np.abs(h16[:, :8])).astype(np.float32)  # 0.3 ulp: same hi part, non-zero lo part
     dup = base[:10].copy()
     xb = np.concatenate([base, twin, dup]).astype(np.float32)
     assert np.array_equal(xb[:50].astype(np.float16), xb[50:100].astype(np.float16))
