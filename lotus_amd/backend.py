@@ -137,7 +137,8 @@ class HipBackend:
                 _ptr(keys), _ptr(ws), int(ws.numel()), self._stream())
         return keys
 
-    def nearest(self, corpus: PackedRows, queries: PackedRows, metric: int, id_offset: int = 0, stats: dict | None = None):
+    def nearest(self, corpus: PackedRows, queries: PackedRows, metric: int, id_offset: int = 0, stats: dict | None = None,
+                exact_scores: bool = True):
         """Nearest corpus row of every query (k = 1) -> int64 key tensor [nq, 1], same winner as ``search_keys(.., 1, ..)``.
 
         fp32-accurate operands (fp16 hi|lo rows) cost two or three MFMA passes in the exact search.  Here ONE pass over
@@ -145,7 +146,8 @@ class HipBackend:
         of a pair differs from the hi-only score by at most |q| |lo_row| + |lo_q| |row| (Cauchy-Schwarz), so a margin
         above twice that bound certifies the winner.  Only the uncertified queries (``lvs_margin_select``: ties,
         near-ties) are searched again exactly.  This is the k-means assignment step (``lotus/utils.py:62,65``) with
-        fp32-accurate centroids at the cost of fp16 ones."""
+        fp32-accurate centroids at the cost of fp16 ones.  ``exact_scores=False`` leaves the one-pass scores inside the
+        keys of certified queries (the ids are exact either way) and saves one pass over the queries."""
         torch = self.torch
         if corpus.mode == _capi.PACK_F16 and queries.mode == _capi.PACK_F16:
             return self.search_keys(corpus, queries, 1, metric, id_offset=id_offset)  # nothing to certify: already exact
@@ -179,8 +181,9 @@ class HipBackend:
         n_open = int(cnt.item())
         # the winners are certified, their scores are still the one-pass approximations: put the exact scores in
         # (one HBM-bound pass over the queries; the k-means objective sums them)
-        self._c("lvs_rescore_keys", _ptr(corpus.rows), corpus.mode, _ptr(queries.rows), queries.mode, nq, corpus.d, metric,
-                _ptr(corpus.norms), _ptr(queries.norms), int(id_offset), _ptr(keys), self._stream())
+        if exact_scores:
+            self._c("lvs_rescore_keys", _ptr(corpus.rows), corpus.mode, _ptr(queries.rows), queries.mode, nq, corpus.d,
+                    metric, _ptr(corpus.norms), _ptr(queries.norms), int(id_offset), _ptr(keys), self._stream())
         if n_open:
             sel = idx[:n_open]
             keys[sel] = self.search_keys(corpus, self.gather(queries, sel), 1, metric, id_offset=id_offset)

@@ -132,12 +132,16 @@ def kmeans(x, k: int, niter: int = 20, seed: int = 1234, max_points_per_centroid
         else:
             train = be.gather(packed, be.to_device(train_ids))
         objs = []
+        x2 = train.norms.double().sum()  # sum of |x_i|^2 over this rank's training rows (constant over the iterations)
         for it in range(niter):
             cpk = be.pack(centroids, cmode)
-            keys = be.nearest(cpk, train, _capi.METRIC_L2)
-            D, I = be.keys_to_result(keys, _capi.METRIC_L2)
+            keys = be.nearest(cpk, train, _capi.METRIC_L2, exact_scores=False)  # only the ids are needed ...
+            _, I = be.keys_to_result(keys, _capi.METRIC_L2)
             sums, counts = be.kmeans_accumulate(train, I.reshape(-1), k)
-            o = D.sum().reshape(1)
+            # ... because the objective (faiss: sum of the assignment distances) follows from the sums the update needs
+            # anyway:  sum_i |x_i - c_a(i)|^2 = sum_i |x_i|^2 - 2 sum_j c_j . S_j + sum_j n_j |c_j|^2   (float64, [k,d])
+            c64 = centroids.double()
+            o = (x2 - 2.0 * (c64 * sums.double()).sum() + (counts.double() * (c64 * c64).sum(dim=1)).sum()).float().reshape(1)
             if dist is not None:
                 _dist.all_reduce_sum_([sums, counts, o], process_group)
             objs.append(o)

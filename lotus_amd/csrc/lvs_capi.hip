@@ -583,7 +583,7 @@ int make_plan(int64_t nq, int64_t nb, int32_t d, int32_t xb_pack, int32_t xq_pac
     off += p.npass > 1 ? lvs_round_up(nq * p.kpass * 8, 256) : 0;
     // candidates of the small-batch kernel: one k-list per (workgroup, query), written from off_partial onwards
     if (nq <= LVS_STREAM_MAXQ && k <= LVS_KPASS)
-        off += (int64_t)(lvs_tune_set("LVS_STREAM_WGS") ? LVS_STREAM_MAXWG : 256) * (nq > 0 ? nq : 1) * (k > 0 ? k : 1) * 8;
+        off += (int64_t)((lvs_tune_set("LVS_STREAM_WGS") ? LVS_STREAM_MAXWG : 256) + 32 + 1) * (nq > 0 ? nq : 1) * (k > 0 ? k : 1) * 8;
     p.total = off;
     return LVS_OK;
 }
@@ -748,6 +748,13 @@ bool make_two_phase_plan(int64_t nq, int64_t nb, int32_t d, int32_t xb_pack, int
     tp.total = off;
     if (tp.total > (24ll << 30)) return false;  // lists + buckets beyond 24 GB: not worth it, use the selection passes
     return true;
+}
+
+// shared threshold of query q = score part of the k-th best key of its merged sample list (0 = fewer than k rows seen)
+__global__ __launch_bounds__(256) void seed_gtau_kernel(const u64* __restrict__ lists, long long nq, int k,
+                                                        uint32_t* __restrict__ gtau) {
+    const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q < nq) gtau[q] = (uint32_t)(lists[q * k + k - 1] >> 32);
 }
 
 __global__ void copy_pass_kernel(const u64* __restrict__ src, long long nq, int kp, u64* __restrict__ dst, int k,
@@ -939,6 +946,42 @@ extern "C" int32_t lvs_flat_search_keys(const void* xb, int32_t xb_pack, int64_t
             }
             LVS_HIP_CHECK(hipMemsetAsync(gtau, 0, (size_t)nq * 4, st));
             int nparts = 0;
+            // Every workgroup scans its own contiguous range, all at the same time: without help each of the 256 starts
+            // with empty lists and pays its own cold start (~k (1 + ln(range / k)) insertions per query and workgroup -
+            // with dozens of queries that, not HBM, sets the time).  So with several queries the first rows are scanned
+            // by a short SAMPLE pass, its lists are merged, and the k-th best key of the sample seeds the shared
+            // threshold of the main pass: a workgroup then only inserts rows that beat it (~k * nb / sample per query
+            // in total instead of per workgroup).  Exact: a threshold taken from real rows never excludes a top-k row.
+            const int64_t sample = lvs_round_up(nb / 64 > 8192 ? nb / 64 : 8192, 32);
+            if (nq >= 8 && nb >= 8 * sample && lvs_tune("LVS_STREAM_SEED", 1) != 0) {
+                LvsStreamArgs ss = sa;
+                ss.nb = sample;
+                ss.max_wgs = 32;
+                LVS_HIP_CHECK(lvs_stream_launch(ss, st));
+                const int sparts = (int)(((sample + 31) / 32 + ss.blocks_per_wg - 1) / ss.blocks_per_wg);
+                u64* seed_list = partial + (size_t)sparts * nq * k;  // [nq][k] merged sample candidates = part `sparts`
+                hipLaunchKernelGGL(merge_keys_kernel, dim3((unsigned)lvs_ceil_div(nq, 4)), dim3(256), 0, st, partial, sparts,
+                                   (long long)nq, k, seed_list, (long long)k, (const uint32_t*)nullptr);
+                hipLaunchKernelGGL(seed_gtau_kernel, dim3((unsigned)lvs_ceil_div(nq, 256)), dim3(256), 0, st, seed_list,
+                                   (long long)nq, k, gtau);
+                LVS_HIP_CHECK(hipGetLastError());
+                // main pass over the remaining rows; its parts follow the seed list
+                sa.xb = (const char*)xb + (size_t)sample * p.ldb * 2;
+                sa.bn = xb_norms_sq ? xb_norms_sq + sample : nullptr;
+                sa.row_ids = row_ids ? row_ids + sample : nullptr;
+                sa.id_offset = id_offset + sample;
+                sa.nb = nb - sample;
+                sa.out = seed_list + (size_t)nq * k;
+                {
+                    ScopedKernelTimer timer(st);
+                    LVS_HIP_CHECK(lvs_stream_launch(sa, st));
+                }
+                const int mparts = (int)(((sa.nb + 31) / 32 + sa.blocks_per_wg - 1) / sa.blocks_per_wg);
+                hipLaunchKernelGGL(merge_keys_kernel, dim3((unsigned)lvs_ceil_div(nq, 4)), dim3(256), 0, st, seed_list,
+                                   1 + mparts, (long long)nq, k, (u64*)out_keys, (long long)k, (const uint32_t*)nullptr);
+                LVS_HIP_CHECK(hipGetLastError());
+                return LVS_OK;
+            }
             {
                 ScopedKernelTimer timer(st);
                 LVS_HIP_CHECK(lvs_stream_launch(sa, st));

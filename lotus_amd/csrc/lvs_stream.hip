@@ -75,7 +75,9 @@ __global__ __launch_bounds__(WAVES * 64, 2) void lvs_stream_kernel(const LvsStre
         qi[qb] = qb * SQ + (lane & 31);
         qvalid[qb] = qi[qb] < a.nq;
         tauf[qb] = -INFINITY;
-        gord[qb] = 0;
+        // start from the shared threshold: zero on a fresh call, the k-th best of the sample pass on a seeded one
+        gord[qb] = qvalid[qb] ? a.gtau[qi[qb]] : 0u;
+        tauf[qb] = tau_float(gord[qb]);
         qnv[qb] = (a.metric == LVS_METRIC_L2 && qvalid[qb]) ? a.qn[qi[qb]] : 0.f;
     }
 
@@ -319,7 +321,7 @@ int lvs_stream_plan(int64_t nq, int k, int nbfrag, int* out_kcap) {
     const int nqb = (int)((nq + SQ - 1) / SQ);
     // one block keeps the full 64 slots (any k <= 56 costs the same insertion step); more blocks trade slots for queries
     int kcap = nqb == 1 ? 64 : (k <= 16 ? 16 : (k <= 32 ? 32 : 64));
-    if (lvs_stream_lds_bytes(nbfrag, nqb, kcap) > 150 * 1024) return 0;
+    if (lvs_stream_lds_bytes(nbfrag, nqb, kcap) > 160 * 1024) return 0;  // a workgroup may use the whole 160 KiB
     if (out_kcap) *out_kcap = kcap;
     return nqb;
 }
@@ -353,7 +355,8 @@ static hipError_t stream_launch_nqb(const LvsStreamArgs& a, int grid, size_t lds
 
 hipError_t lvs_stream_launch(LvsStreamArgs& a, hipStream_t stream) {
     const int64_t nblocks = (a.nb + 31) / 32;
-    const int wgs = lvs_stream_blocks(a.nb);
+    int wgs = lvs_stream_blocks(a.nb);
+    if (a.max_wgs > 0 && wgs > a.max_wgs) wgs = a.max_wgs;
     a.blocks_per_wg = (int)((nblocks + wgs - 1) / wgs);
     a.debug = (int)lvs_tune("LVS_STREAM_DEBUG", 0);
     const int grid = (int)((nblocks + a.blocks_per_wg - 1) / a.blocks_per_wg);

@@ -91,6 +91,7 @@ struct LvsStreamArgs {
     int nbfrag;              // B fragments held in LDS
     int blocks_per_wg;       // 32-row blocks per workgroup (contiguous)
     int kcap;                // list slots per query in LDS (k <= kcap <= 64), from lvs_stream_plan
+    int max_wgs;             // > 0: at most this many workgroups (the short sample pass)
     int debug;               // -DLVS_TUNING builds only (env LVS_STREAM_DEBUG): 1 no MFMA / B reads, 2 no block epilogue
 };
 

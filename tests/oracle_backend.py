@@ -72,7 +72,7 @@ class OracleBackend:
             keys = np.concatenate([keys, np.zeros((keys.shape[0], k - keys.shape[1]), np.uint64)], axis=1)
         return torch.from_numpy(np.array(keys, dtype=np.uint64, order="C", copy=True).view(np.int64))
 
-    def nearest(self, corpus, queries, metric, id_offset=0, stats=None):
+    def nearest(self, corpus, queries, metric, id_offset=0, stats=None, exact_scores=True):
         return self.search_keys(corpus, queries, 1, metric, id_offset=id_offset)
 
     def merge_keys(self, parts):

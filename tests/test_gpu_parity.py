@@ -105,6 +105,10 @@ def test_mixed_precision_operands(hip_backend, cmode, qmode, k):
     (50, 20_000, 128, 30, F16, IP),    # 32-slot lists
     (90, 12_000, 100, 56, F16, IP),    # 64-slot lists, three blocks (short rows leave the LDS for them)
     (70, 9_000, 768, 5, SPLIT, IP),    # fp32-accurate queries do not fit twice: falls to the tile kernel
+    (40, 200_000, 256, 10, F16, IP),   # long corpus + several queries: sample pass seeds the shared thresholds
+    (96, 150_000, 128, 15, F16, L2),
+    (8, 70_000, 768, 56, F16, IP),
+    (96, 90_000, 768, 10, F16, IP),    # three query blocks at d = 768 use (almost) the whole 160 KiB of LDS
 ])
 def test_small_batch_streaming_kernel(hip_backend, nq, nb, d, k, mode, metric):
     """nq <= 96 takes the HBM-streaming kernel (lvs_stream.hip) when the query fragments fit the LDS: same results as
@@ -418,3 +422,17 @@ def test_large_k_is_stream_async_and_exact_without_overflow(hip_backend):
         Dr, Ir = oracle.flat_search(_stored(xb, F16), _stored(xq, F16), k, IP)
         err, hard, recall = synth.compare_topk(Dr, Ir, D, I)
         assert err <= 1e-5 and hard == 0 and recall >= 0.9999
+
+
+def test_seeded_streaming_search_with_duplicates_across_the_sample_boundary(hip_backend):
+    """The sample pass covers the first rows, the seeded main pass the rest: rows that tie exactly across that boundary
+    (and rows equal to the threshold score) must all stay candidates - ids come back in the oracle's order."""
+    xb = synth.corpus(100_000, 64, seed=77)
+    xb[50_000:50_500] = xb[:500]          # duplicates of sample rows inside the main range
+    xb[99_000:99_200] = xb[60_000:60_200]  # duplicates inside the main range
+    xq = (xb[[3, 17, 250, 499, 60_010, 60_150, 70_000, 5, 9, 11, 13, 15]] * 1.0).astype(np.float32)
+    for k in (1, 3, 10):
+        D, I, _ = _run(hip_backend, xb, xq, k, F16, IP)
+        Dr, Ir = oracle.flat_search(_stored(xb, F16), _stored(xq, F16), k, IP)
+        assert np.array_equal(I, Ir)
+        assert np.abs(D - Dr).max() <= 1e-5

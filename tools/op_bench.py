@@ -49,33 +49,38 @@ with tempfile.TemporaryDirectory() as td:
     # literal single-query sem_search (HBM-bound regime)
     t = timed(lambda: vs(xq_h[:1], 10), reps=10); res["single_query_1M_ms"] = t * 1e3
     del vs
-    # cfg4: dedup threshold self-join with 100k planted near-duplicates (OPB_CFG4_ROWS=5000000 for the full size)
+    # cfg4: dedup threshold self-join with 100k planted near-duplicates (OPB_CFG4_ROWS=5000000 for the full size;
+    # OPB_CFG4_ROWS=0 skips it)
     n = int(os.environ.get("OPB_CFG4_ROWS", "2000000"))
     ndup = int(os.environ.get("OPB_CFG4_DUPS", "100000"))
-    base = gen(n - ndup, 768, 5, torch.float32)
-    g = torch.Generator(device=dev); g.manual_seed(6)
-    dup = torch.nn.functional.normalize(base[:ndup] + 0.2 * torch.nn.functional.normalize(torch.randn((ndup, 768), generator=g, device=dev), dim=1), dim=1)
-    x = torch.cat([base, dup]).to(torch.float16); del base, dup
-    pk = be.pack(x, _capi.PACK_F16)
-    t0 = time.perf_counter(); i, j, s = threshold_pairs(be, pk, 0.95); t = time.perf_counter() - t0
-    res["cfg4_rows"] = n; res["cfg4_threshold_join_s"] = t; res["cfg4_pairs"] = int(len(i)); res["cfg4_tflops_symmetric"] = n * n * 768 / t / 1e12
-    del x, pk
+    if n > 0:
+        base = gen(n - ndup, 768, 5, torch.float32)
+        g = torch.Generator(device=dev); g.manual_seed(6)
+        dup = torch.nn.functional.normalize(base[:ndup] + 0.2 * torch.nn.functional.normalize(torch.randn((ndup, 768), generator=g, device=dev), dim=1), dim=1)
+        x = torch.cat([base, dup]).to(torch.float16); del base, dup
+        pk = be.pack(x, _capi.PACK_F16)
+        t0 = time.perf_counter(); i, j, s = threshold_pairs(be, pk, 0.95); t = time.perf_counter() - t0
+        res["cfg4_rows"] = n; res["cfg4_threshold_join_s"] = t; res["cfg4_pairs"] = int(len(i)); res["cfg4_tflops_symmetric"] = n * n * 768 / t / 1e12
+        del x, pk
     # cfg5 (1 GPU): k-means 10M x 768 fp16, K=1024, 20 iters - faiss-parity mode (262 144-row subsample + final assign)
     n = 10_000_000
     x = gen(n, 768, 7)
     pk = be.pack(x, _capi.PACK_F16)
-    xh = np.empty((n, 768), np.float16)  # host copy only feeds the initial centroids
-    step = 1 << 20
-    for r0 in range(0, n, step): xh[r0:r0 + step] = x[r0:r0 + step].cpu().numpy()
-    del x
-    t0 = time.perf_counter(); r = kmeans(xh, 1024, niter=20, backend=be, packed=pk, pack_mode=_capi.PACK_F16); t = time.perf_counter() - t0
+    del x  # the device image is all k-means needs: centroids are unpacked from it, nothing goes through the host
+    stats = {}
+    t0 = time.perf_counter(); r = kmeans(None, 1024, niter=20, backend=be, packed=pk); t = time.perf_counter() - t0
     res["cfg5_parity_mode_s"] = t; res["cfg5_obj_first_last"] = [float(r.obj[0]), float(r.obj[-1])]
-    t0 = time.perf_counter(); r = kmeans(xh, 1024, niter=20, backend=be, packed=pk, pack_mode=_capi.PACK_F16, centroid_precision="fp16"); t = time.perf_counter() - t0
+    t0 = time.perf_counter(); r = kmeans(None, 1024, niter=20, backend=be, packed=pk, centroid_precision="fp16"); t = time.perf_counter() - t0
     res["cfg5_parity_mode_fp16_centroids_s"] = t
-    kw = dict(backend=be, packed=pk, pack_mode=_capi.PACK_F16, max_points_per_centroid=None, final_assign=False)
+    kw = dict(backend=be, packed=pk, max_points_per_centroid=None, final_assign=False)
     ts = {}
     for niter in (1, 5, 1, 5):  # per-iteration cost = slope (the 10M-entry init permutation is set-up, not iteration)
-        be.synchronize(); t0 = time.perf_counter(); kmeans(xh, 1024, niter=niter, **kw); be.synchronize(); ts[niter] = time.perf_counter() - t0
+        be.synchronize(); t0 = time.perf_counter(); kmeans(None, 1024, niter=niter, **kw); be.synchronize(); ts[niter] = time.perf_counter() - t0
     res["cfg5_full_data_per_iter_s"] = (ts[5] - ts[1]) / 4
     res["cfg5_full_data_setup_plus_first_iter_s"] = ts[1]
+    res["cfg5_full_data_algorithmic_tflops"] = 2.0 * n * 1024 * 768 / res["cfg5_full_data_per_iter_s"] / 1e12
+    # how often the one-pass certificate fails on this data (those points take the exact 2-pass search)
+    cent = be.pack(be.unpack(pk, be.to_device(np.arange(1024, dtype=np.int64))), _capi.PACK_SPLIT)
+    be.nearest(cent, pk, _capi.METRIC_L2, stats=stats)
+    res["cfg5_uncertified_fraction"] = stats["uncertified"] / max(1, stats["queries"])
 print(json.dumps(res, indent=1))
