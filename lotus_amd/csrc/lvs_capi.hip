@@ -953,7 +953,9 @@ extern "C" int32_t lvs_flat_search_keys(const void* xb, int32_t xb_pack, int64_t
             // threshold of the main pass: a workgroup then only inserts rows that beat it (~k * nb / sample per query
             // in total instead of per workgroup).  Exact: a threshold taken from real rows never excludes a top-k row.
             const int64_t sample = lvs_round_up(nb / 64 > 8192 ? nb / 64 : 8192, 32);
-            if (nq >= 8 && nb >= 8 * sample && lvs_tune("LVS_STREAM_SEED", 1) != 0) {
+            // Measured (1 M rows, profiles/r02_tuning.md): pays from the second query block on (-4 % at 64 queries); with
+            // up to 32 queries the extra launches cost more than the cold starts they remove (+5 .. 11 %).
+            if (nq > 32 && nb >= 8 * sample && lvs_tune("LVS_STREAM_SEED", 1) != 0) {
                 LvsStreamArgs ss = sa;
                 ss.nb = sample;
                 ss.max_wgs = 32;

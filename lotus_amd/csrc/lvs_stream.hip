@@ -1,4 +1,4 @@
-// Small-batch search kernel: up to 96 queries against the whole corpus shard - the HBM-bound regime of the path
+// Small-batch search kernel: up to 64 queries (LVS_STREAM_MAXQ) against the whole corpus shard - the HBM-bound regime of the path
 // (the literal `sem_search` operator issues ONE query per call: lotus/sem_ops/sem_search.py:121-122 -> faiss_vs.py:75;
 // small sim-joins and batched searches send a few dozen).
 //

@@ -70,8 +70,10 @@ struct LvsTileArgs {
 int lvs_tile_grid_blocks(int nqt, int nslab, int gq, int lead_slabs);
 hipError_t lvs_tile_launch(int mode, const LvsTileArgs& a, hipStream_t stream);
 
-// ---- small-batch streaming kernel (lvs_stream.hip): nq <= 96 (1..3 blocks of 32 queries per corpus pass), k <= LVS_KPASS ----
-#define LVS_STREAM_MAXQ 96
+// ---- small-batch streaming kernel (lvs_stream.hip): nq <= 64 (1..2 blocks of 32 queries per corpus pass), k <= LVS_KPASS.
+// The kernel itself takes three blocks, but measured at 1 M rows x 768 (profiles/r02_tuning.md) 96 queries cost 0.71 ms there
+// against 0.67 ms on the 128-query tile kernel: every workgroup pays its own list cold start per query. ----
+#define LVS_STREAM_MAXQ 64
 #define LVS_STREAM_MAXWG 768   // most workgroups (= partial candidate lists) a launch may use
 struct LvsStreamArgs {
     const void* xb;
