@@ -34,7 +34,12 @@ def segments(rows, name_key, order_key):
     return segs
 
 
-out = {"tag": tag, "csrc_sha": csrc_hash(), "peaks": {"hbm_GBs": PEAK_HBM_GBS, "fp16_mfma_TFLOPs": PEAK_FP16_MFMA_TFLOPS},
+sha = csrc_hash()
+try:  # the hash of the build that ran (written by tools/kernel_workload.py next to the manifest)
+    sha = open(os.path.join(src, "csrc_sha.txt")).read().strip() or sha
+except Exception:
+    pass
+out = {"tag": tag, "csrc_sha": sha, "peaks": {"hbm_GBs": PEAK_HBM_GBS, "fp16_mfma_TFLOPs": PEAK_FP16_MFMA_TFLOPS},
        "scenarios": {}}
 trace = glob.glob(os.path.join(src, "trace", "*kernel_trace.csv"))
 if trace:

@@ -111,4 +111,6 @@ scenario("gather_1M_rows", "gather_rows_kernel", lambda: be.gather(p4m, ids1m), 
 be.keys_to_result(dummy, IP)
 be.synchronize()
 json.dump(manifest, open(os.path.join(out_dir, "manifest.json"), "w"), indent=1)
+from bench import csrc_hash  # noqa: E402
+open(os.path.join(out_dir, "csrc_sha.txt"), "w").write(csrc_hash())
 print("scenarios:", [m["name"] for m in manifest])

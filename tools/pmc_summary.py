@@ -60,7 +60,14 @@ if "SQ_WAVE_CYCLES" in avg:
         if c in avg:
             summary[c.lower() + "_frac"] = avg[c] / avg["SQ_WAVE_CYCLES"]
 summary["tag"] = tag
-summary["csrc_sha"] = csrc_hash()  # bench.py reports `traffic` only while the kernel sources still hash to this
+# bench.py reports `traffic` only while the kernel sources still hash to the value of the build the counters were
+# collected on: that is the hash the un-profiled bench run of the same call printed (gpurun_out/<tag>/bench.json)
+sha = csrc_hash()
+try:
+    sha = json.load(open(os.path.join(src, "bench.json")))["roofline"]["csrc_sha"]
+except Exception:
+    pass
+summary["csrc_sha"] = sha
 json.dump(summary, open(os.path.join(out_dir, f"{tag}_pmc.json"), "w"), indent=1)
 if "traffic_bytes_per_launch" in summary:
     json.dump(summary, open(os.path.join(out_dir, "latest_pmc.json"), "w"), indent=1)
