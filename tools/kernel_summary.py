@@ -48,7 +48,10 @@ if trace:
     for m, seg in zip(manifest, segs):
         mine = [r for r in seg if m["kernel"] in r["Kernel_Name"]]
         lpc = m["launches_per_call"]
-        assert len(mine) >= (m["warm"] + m["reps"]) * lpc, (m["name"], len(mine))
+        if len(mine) < (m["warm"] + m["reps"]) * lpc:  # the call was routed to another kernel than the manifest expected
+            out["scenarios"][m["name"]] = {"kernel": m["kernel"], "skipped": f"only {len(mine)} matching dispatches",
+                                           "kernels_seen": sorted({r["Kernel_Name"][:60] for r in seg})[:6]}
+            continue
         timed = mine[m["warm"] * lpc:(m["warm"] + m["reps"]) * lpc]
         per_call_us = sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in timed) / 1e3 / m["reps"]
         e = {"kernel": m["kernel"], "reps": m["reps"], "launches_per_call": lpc, "kernel_us_per_call": per_call_us,
@@ -63,7 +66,7 @@ if trace:
             e["frac"] = e["achieved_TFLOPs"] / PEAK_FP16_MFMA_TFLOPS
         out["scenarios"][m["name"]] = e
 
-for p in glob.glob(os.path.join(src, "pmc_*", "*counter_collection.csv")):
+for p in glob.glob(os.path.join(src, "pmc_*", "k_counter_collection.csv"))  # the workload passes (-o k):
     rows = list(csv.DictReader(open(p)))
     segs = segments(rows, "Kernel_Name", "Dispatch_Id")
     if len(segs) != len(manifest):
@@ -76,12 +79,16 @@ for p in glob.glob(os.path.join(src, "pmc_*", "*counter_collection.csv")):
             if m["kernel"] in r["Kernel_Name"]:
                 by_counter[r["Counter_Name"]].append(float(r["Counter_Value"]))
         e = out["scenarios"].setdefault(m["name"], {})
+        if "skipped" in e:
+            continue
         c = e.setdefault("counters_per_call", {})
         for name, vals in by_counter.items():
             vals = vals[m["warm"] * lpc:(m["warm"] + m["reps"]) * lpc]
             if vals:
                 c[name] = sum(vals) / m["reps"]
 for e in out["scenarios"].values():
+    if "skipped" in e:
+        continue
     c = e.get("counters_per_call", {})
     if "FETCH_SIZE" in c:
         e["hbm_read_bytes_per_call"] = 2.0 * c["FETCH_SIZE"] * 1024

@@ -63,20 +63,20 @@ scenario("stream_1q_x_1M_d768", "lvs_stream_kernel", lambda: be.search_keys(p1m,
          bytes_per_call=1_000_000 * ld(p1m) * 2)
 scenario("stream_64q_x_1M_d768", "lvs_stream_kernel", lambda: be.search_keys(p1m, be.slice_rows(q100k, 0, 64), 10, IP), 10,
          bytes_per_call=1_000_000 * ld(p1m) * 2, launches_per_call=2, note="two 32-query blocks per corpus pass; sample + seeded main pass")
-scenario("stream_96q_x_1M_d768", "lvs_stream_kernel", lambda: be.search_keys(p1m, be.slice_rows(q100k, 0, 96), 10, IP), 10,
-         bytes_per_call=1_000_000 * ld(p1m) * 2, launches_per_call=2, note="three 32-query blocks per corpus pass; sample + seeded main pass")
+scenario("tile_96q_x_1M_d768", "lvs_tile_kernel<0, 2>", lambda: be.search_keys(p1m, be.slice_rows(q100k, 0, 96), 10, IP), 10,
+         bound="mfma", flops_per_call=2.0 * 96 * 1_000_000 * D, note="past LVS_STREAM_MAXQ = 64: 128-query tile geometry")
 scenario("stream_32q_x_1M_d768", "lvs_stream_kernel", lambda: be.search_keys(p1m, be.slice_rows(q100k, 0, 32), 10, IP), 10,
-         bytes_per_call=1_000_000 * ld(p1m) * 2, launches_per_call=2, note="sample pass + seeded main pass (both launches counted)")
+         bytes_per_call=1_000_000 * ld(p1m) * 2)
 scenario("tile_128q_x_1M_d768", "lvs_tile_kernel<0, 2>", lambda: be.search_keys(p1m, be.slice_rows(q100k, 0, 128), 10, IP), 10,
          bound="mfma", flops_per_call=2.0 * 128 * 1_000_000 * D, note="just past the streaming kernel: 128-query tile geometry")
 scenario("stream_1q_x_4M_d768", "lvs_stream_kernel", lambda: be.search_keys(p4m, be.slice_rows(q100k, 0, 1), 10, IP), 10,
          bytes_per_call=N4 * ld(p4m) * 2)
 scenario("stream_32q_x_4M_d768", "lvs_stream_kernel", lambda: be.search_keys(p4m, be.slice_rows(q100k, 0, 32), 10, IP), 10,
-         bytes_per_call=N4 * ld(p4m) * 2, launches_per_call=2)
+         bytes_per_call=N4 * ld(p4m) * 2)
 scenario("stream_1q_x_2M_d384", "lvs_stream_kernel", lambda: be.search_keys(p384, be.slice_rows(q384, 0, 1), 10, IP), 10,
          bytes_per_call=2_000_000 * ld(p384) * 2, note="d = 384 = BASELINE configs[0]'s dimension")
 scenario("stream_32q_x_2M_d384", "lvs_stream_kernel", lambda: be.search_keys(p384, q384, 10, IP), 10,
-         bytes_per_call=2_000_000 * ld(p384) * 2, launches_per_call=2)
+         bytes_per_call=2_000_000 * ld(p384) * 2)
 # ---- MFMA-bound: the tile kernel in its modes ----
 shard = be.slice_rows(p4m, 0, 125_000)
 scenario("topk_100k_x_125k_shard", "lvs_tile_kernel<0, 4>", lambda: be.search_keys(shard, q100k, 10, IP), 5, bound="mfma",
