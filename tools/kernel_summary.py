@@ -66,7 +66,7 @@ if trace:
             e["frac"] = e["achieved_TFLOPs"] / PEAK_FP16_MFMA_TFLOPS
         out["scenarios"][m["name"]] = e
 
-for p in glob.glob(os.path.join(src, "pmc_*", "k_counter_collection.csv"))  # the workload passes (-o k):
+for p in glob.glob(os.path.join(src, "pmc_*", "k_counter_collection.csv")):
     rows = list(csv.DictReader(open(p)))
     segs = segments(rows, "Kernel_Name", "Dispatch_Id")
     if len(segs) != len(manifest):

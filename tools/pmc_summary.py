@@ -34,7 +34,7 @@ if stats:
             summary["rocprof_kernel_calls"] = int(r["Calls"])
 
 counters = collections.defaultdict(list)
-for p in glob.glob(os.path.join(src, "pmc_*", "b_counter_collection.csv"))  # the bench passes (tools/profile_bench.sh: -o b):
+for p in glob.glob(os.path.join(src, "pmc_*", "b_counter_collection.csv")):
     for r in csv.DictReader(open(p)):
         if KERNEL in r["Kernel_Name"]:
             counters[r["Counter_Name"]].append(float(r["Counter_Value"]))
