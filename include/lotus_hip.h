@@ -100,6 +100,22 @@ int32_t lvs_flat_search_keys(const void* xb, int32_t xb_pack, int64_t nb, const 
                              int32_t d, int32_t metric, int32_t k, const float* xb_norms_sq, const float* xq_norms_sq,
                              int64_t id_offset, const uint32_t* row_ids, uint64_t* out_keys, void* workspace,
                              int64_t workspace_bytes, void* stream);
+/* The same search over the fp16 "hi" parts of both operands only: ONE MFMA pass whatever the pack modes (hi|lo rows are
+ * read at their own leading dimension).  Scores inside the keys are approximations: |s_hi - s| <= |q| |lo_row| + |lo_q| |row|
+ * <= 2^-10 |q| |row|.  Used with k1 > k list slots + lvs_rescore_keys + lvs_sort_keys_desc + lvs_certify_topk this gives the
+ * exact top k of fp32-accurate operands at the cost of fp16 ones (same workspace size as lvs_flat_search_keys). */
+int32_t lvs_flat_search_keys_hi(const void* xb, int32_t xb_pack, int64_t nb, const void* xq, int32_t xq_pack, int64_t nq,
+                                int32_t d, int32_t metric, int32_t k, const float* xb_norms_sq, const float* xq_norms_sq,
+                                int64_t id_offset, const uint32_t* row_ids, uint64_t* out_keys, void* workspace,
+                                int64_t workspace_bytes, void* stream);
+/* keys [nq][k] sorted best-first in place (k <= 64). */
+int32_t lvs_sort_keys_desc(uint64_t* keys, int64_t nq, int32_t k, void* stream);
+/* approx_keys [nq][k1] from lvs_flat_search_keys_hi (best first), exact_keys [nq][k1] the same candidates after
+ * lvs_rescore_keys + lvs_sort_keys_desc.  A query is certified when its k-th exact score is strictly above
+ * (last one-pass score of its list) + scale * sqrt(q_norms_sq) + slack: then no row outside the list can reach the top k.
+ * Uncertified queries are appended to out_idx (order unspecified), *out_count (device uint64, zeroed by the caller) += n. */
+int32_t lvs_certify_topk(const uint64_t* approx_keys, const uint64_t* exact_keys, const float* q_norms_sq, int64_t nq,
+                         int32_t k1, int32_t k, float scale, float slack, int64_t* out_idx, uint64_t* out_count, void* stream);
 /* Merge `nparts` candidate lists (e.g. the all-gathered per-shard lists): parts [nparts][nq][k] -> out [nq][k].
  * Any nparts >= 1 and k <= LVS_MAX_K (long lists are folded in rounds of at most 4096 keys per query). */
 int32_t lvs_merge_keys(const uint64_t* parts, int32_t nparts, int64_t nq, int32_t k, uint64_t* out_keys,
@@ -146,11 +162,11 @@ int64_t lvs_nearest_hi_workspace_bytes(int64_t nq, int64_t nb, int32_t d);
 int32_t lvs_nearest_hi(const void* xb, int32_t xb_pack, int64_t nb, const void* xq, int32_t xq_pack, int64_t nq, int32_t d,
                        int32_t metric, const float* xb_norms_sq, const float* xq_norms_sq, int64_t id_offset,
                        uint64_t* out_keys, float* out_second, void* workspace, int64_t workspace_bytes, void* stream);
-/* keys [nq] in/out: the score inside every key is replaced by the exact fp32 score (hi + lo parts of both operands) of
- * the pair (query q, the row the key names) - what the k-means objective sums (faiss Clustering: obj = sum of the
- * assignment distances). */
+/* keys [nq][k] in/out: the score inside every key is replaced by the exact fp32 score (hi + lo parts of both operands) of
+ * the pair (query q, the row the key names; row = id - id_offset); empty slots (key 0) stay empty; the order inside a
+ * query's list is NOT restored (lvs_sort_keys_desc). */
 int32_t lvs_rescore_keys(const void* xb, int32_t xb_pack, const void* xq, int32_t xq_pack, int64_t nq, int32_t d,
-                         int32_t metric, const float* xb_norms_sq, const float* xq_norms_sq, int64_t id_offset,
+                         int32_t metric, const float* xb_norms_sq, const float* xq_norms_sq, int64_t id_offset, int32_t k,
                          uint64_t* keys, void* stream);
 /* out_idx [<= nq] (order unspecified) = queries with score(key) - second <= scale * sqrt(q_norms_sq) + slack;
  * *out_count (device uint64, zeroed by the caller) += their number.  q_norms_sq NULL means |q| = 1. */

@@ -46,7 +46,11 @@ SIGNATURES = {
                               _i32, _i64, _vp, _vp, _vp, _vp, _vp]),
     "lvs_nearest_hi_workspace_bytes": (_i64, [_i64, _i64, _i32]),
     "lvs_nearest_hi": (_i32, [_vp, _i32, _i64, _vp, _i32, _i64, _i32, _i32, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp]),
-    "lvs_rescore_keys": (_i32, [_vp, _i32, _vp, _i32, _i64, _i32, _i32, _vp, _vp, _i64, _vp, _vp]),
+    "lvs_rescore_keys": (_i32, [_vp, _i32, _vp, _i32, _i64, _i32, _i32, _vp, _vp, _i64, _i32, _vp, _vp]),
+    "lvs_flat_search_keys_hi": (_i32, [_vp, _i32, _i64, _vp, _i32, _i64, _i32, _i32, _i32, _vp, _vp, _i64, _vp, _vp,
+                                       _vp, _i64, _vp]),
+    "lvs_sort_keys_desc": (_i32, [_vp, _i64, _i32, _vp]),
+    "lvs_certify_topk": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, ctypes.c_float, ctypes.c_float, _vp, _vp, _vp]),
     "lvs_margin_select": (_i32, [_vp, _vp, _vp, _i64, ctypes.c_float, ctypes.c_float, _vp, _vp, _vp]),
     "lvs_kmeans_accumulate_workspace_bytes": (_i64, [_i64, _i32]),
     "lvs_kmeans_accumulate": (_i32, [_vp, _i64, _i32, _i32, _vp, _i32, _vp, _vp, _vp, _i64, _vp]),

@@ -121,12 +121,26 @@ class HipBackend:
         return PackedRows(rows=src.rows[r0:r1], norms=src.norms[r0:r1], n=r1 - r0, d=src.d, mode=src.mode)
 
     # ---- search ----
+    CERT_MIN_PAIRS = 1 << 26  # below this many (query, row) pairs the extra launches cost more than the two passes saved
+    CERT_MAX_K = 48
+
     def search_keys(self, corpus: PackedRows, queries: PackedRows, k: int, metric: int, id_offset: int = 0,
-                    row_ids=None):
-        """-> int64 tensor [nq, k] holding the uint64 result keys (bit pattern)."""
+                    row_ids=None, one_pass: bool | None = None, stats: dict | None = None):
+        """-> int64 tensor [nq, k] holding the uint64 result keys (bit pattern).
+
+        fp32-accurate operands (fp16 hi|lo rows) need 2-3 MFMA passes in the plain search.  For large calls with
+        k <= 48 the same exact result comes from ONE pass (``one_pass``: None = decide by size, False = never):
+        ``lvs_flat_search_keys_hi`` with a few spare list slots, exact rescoring of the candidates, a per-query
+        certificate (``lvs_certify_topk``) and the plain search for the few uncertified queries only."""
         torch = self.torch
         if corpus.d != queries.d:
             raise ValueError("corpus / query dimension mismatch")
+        split = corpus.mode == _capi.PACK_SPLIT or queries.mode == _capi.PACK_SPLIT
+        if one_pass is None:
+            one_pass = queries.n * corpus.n >= self.CERT_MIN_PAIRS
+        if (one_pass and split and row_ids is None and 1 <= k <= self.CERT_MAX_K and corpus.n >= 4 * (k + 8)
+                and queries.n > 0):
+            return self._search_keys_certified(corpus, queries, k, metric, id_offset, stats)
         keys = torch.empty((queries.n, k), dtype=torch.int64, device=self.device)
         need = int(self.lib.lvs_flat_search_workspace_bytes(queries.n, corpus.n, corpus.d, k, corpus.mode, queries.mode))
         if need < 0:
@@ -135,6 +149,54 @@ class HipBackend:
         self._c("lvs_flat_search_keys", _ptr(corpus.rows), corpus.mode, corpus.n, _ptr(queries.rows), queries.mode,
                 queries.n, corpus.d, metric, k, _ptr(corpus.norms), _ptr(queries.norms), int(id_offset), _ptr(row_ids),
                 _ptr(keys), _ptr(ws), int(ws.numel()), self._stream())
+        return keys
+
+    def _search_call(self, name: str, corpus, queries, k, metric, id_offset):
+        torch = self.torch
+        keys = torch.empty((queries.n, k), dtype=torch.int64, device=self.device)
+        need = int(self.lib.lvs_flat_search_workspace_bytes(queries.n, corpus.n, corpus.d, k, corpus.mode, queries.mode))
+        if need < 0:
+            raise LotusHipError("lvs_flat_search_workspace_bytes rejected the shape")
+        ws = self._workspace(need)
+        self._c(name, _ptr(corpus.rows), corpus.mode, corpus.n, _ptr(queries.rows), queries.mode, queries.n, corpus.d, metric,
+                k, _ptr(corpus.norms), _ptr(queries.norms), int(id_offset), None, _ptr(keys), _ptr(ws), int(ws.numel()),
+                self._stream())
+        return keys
+
+    def _search_keys_certified(self, corpus, queries, k, metric, id_offset, stats):
+        """Exact top-k of fp32-accurate operands from one MFMA pass (see ``search_keys``).
+
+        The one-pass score of a pair differs from the exact one by at most ``|q| |lo_row| + |lo_q| |row| <= 2^-11 |q| R``
+        per split operand (``R`` = largest row norm; every component is rounded to 11 significant bits).  With k1 > k
+        list slots, a row that is NOT among a query's k1 candidates has a one-pass score <= the list's last one, so its
+        exact score is at most that + the bound; if the k-th EXACT score of the candidates is strictly higher, their
+        exact top k is the exact top k."""
+        torch = self.torch
+        nq = queries.n
+        k1 = 15 if k <= 10 else min(56, k + 8)
+        k1 = min(k1, corpus.n)
+        approx = self._search_call("lvs_flat_search_keys_hi", corpus, queries, k1, metric, id_offset)
+        exact = approx.clone()
+        self._c("lvs_rescore_keys", _ptr(corpus.rows), corpus.mode, _ptr(queries.rows), queries.mode, nq, corpus.d, metric,
+                _ptr(corpus.norms), _ptr(queries.norms), int(id_offset), k1, _ptr(exact), self._stream())
+        self._c("lvs_sort_keys_desc", _ptr(exact), nq, k1, self._stream())
+        R = float(corpus.norms.max().sqrt().item())
+        nsplit = int(corpus.mode == _capi.PACK_SPLIT) + int(queries.mode == _capi.PACK_SPLIT)
+        per_q = (2.0 ** -11) * R * nsplit + 8e-6 * R  # + fp32 accumulation noise, relative to |q| |row|
+        scale = per_q * (1.0 if metric == _capi.METRIC_IP else 2.0)
+        slack = 1e-6 * (1.0 + R * R)
+        idx = torch.empty((nq,), dtype=torch.int64, device=self.device)
+        cnt = torch.zeros((1,), dtype=torch.int64, device=self.device)
+        self._c("lvs_certify_topk", _ptr(approx), _ptr(exact), _ptr(queries.norms), nq, k1, k, float(scale), float(slack),
+                _ptr(idx), _ptr(cnt), self._stream())
+        keys = exact[:, :k].contiguous()
+        n_open = int(cnt.item())
+        if n_open:
+            sel = idx[:n_open]
+            keys[sel] = self.search_keys(corpus, self.gather(queries, sel), k, metric, id_offset=id_offset, one_pass=False)
+        if stats is not None:
+            stats["uncertified"] = stats.get("uncertified", 0) + n_open
+            stats["queries"] = stats.get("queries", 0) + nq
         return keys
 
     def nearest(self, corpus: PackedRows, queries: PackedRows, metric: int, id_offset: int = 0, stats: dict | None = None,
@@ -151,12 +213,13 @@ class HipBackend:
         torch = self.torch
         if corpus.mode == _capi.PACK_F16 and queries.mode == _capi.PACK_F16:
             return self.search_keys(corpus, queries, 1, metric, id_offset=id_offset)  # nothing to certify: already exact
+        plain = dict(id_offset=id_offset, one_pass=False)
         if corpus.d != queries.d:
             raise ValueError("corpus / query dimension mismatch")
         nq = queries.n
         keys = torch.empty((nq, 1), dtype=torch.int64, device=self.device)
         if nq == 0 or corpus.n == 0:
-            return self.search_keys(corpus, queries, 1, metric, id_offset=id_offset)
+            return self.search_keys(corpus, queries, 1, metric, **plain)
         # error bound per unit of |q|: largest lo-part norm and largest norm over the corpus rows (a small matrix in the
         # k-means use: the centroids)
         dpad = int(corpus.rows.shape[1]) // (2 if corpus.mode == _capi.PACK_SPLIT else 1)
@@ -183,10 +246,10 @@ class HipBackend:
         # (one HBM-bound pass over the queries; the k-means objective sums them)
         if exact_scores:
             self._c("lvs_rescore_keys", _ptr(corpus.rows), corpus.mode, _ptr(queries.rows), queries.mode, nq, corpus.d,
-                    metric, _ptr(corpus.norms), _ptr(queries.norms), int(id_offset), _ptr(keys), self._stream())
+                    metric, _ptr(corpus.norms), _ptr(queries.norms), int(id_offset), 1, _ptr(keys), self._stream())
         if n_open:
             sel = idx[:n_open]
-            keys[sel] = self.search_keys(corpus, self.gather(queries, sel), 1, metric, id_offset=id_offset)
+            keys[sel] = self.search_keys(corpus, self.gather(queries, sel), 1, metric, **plain)
         if stats is not None:
             stats["uncertified"] = stats.get("uncertified", 0) + n_open
             stats["queries"] = stats.get("queries", 0) + nq

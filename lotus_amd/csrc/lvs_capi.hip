@@ -355,11 +355,12 @@ __global__ __launch_bounds__(256) void rescore_keys_kernel(const _Float16* __res
                                                            const _Float16* __restrict__ xq, long long ldq, int dpad,
                                                            int metric, const float* __restrict__ bn,
                                                            const float* __restrict__ qn, long long id_offset, long long nq,
-                                                           u64* __restrict__ keys) {
+                                                           int k, u64* __restrict__ keys) {
     const int lane = threadIdx.x & 63;
-    const long long q = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (q >= nq) return;
-    const u64 key = keys[q];
+    const long long slot = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);  // one wave per (query, rank)
+    if (slot >= nq * k) return;
+    const long long q = slot / k;
+    const u64 key = keys[slot];
     if (key == 0) return;
     const uint32_t id = 0xFFFFFFFFu - (uint32_t)(key & 0xFFFFFFFFull);
     const long long row = (long long)id - id_offset;
@@ -382,8 +383,48 @@ __global__ __launch_bounds__(256) void rescore_keys_kernel(const _Float16* __res
     if (lane == 0) {
         float better = acc;
         if (metric == LVS_METRIC_L2) better = -fmaxf((qn[q] + bn[row]) - 2.0f * acc, 0.f);
-        keys[q] = lvs_pack_key(better, id);
+        keys[slot] = lvs_pack_key(better, id);
     }
+}
+
+// one wave per query: keys[q][0..k) sorted descending in place (k <= 64)
+__global__ __launch_bounds__(256) void sort_keys_kernel(u64* __restrict__ keys, long long nq, int k) {
+    const int lane = threadIdx.x & 63;
+    const long long q = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (q >= nq) return;
+    u64 v = lane < k ? keys[q * k + lane] : 0ull;
+    v = lvs_wave_sort_desc(v, lane);
+    if (lane < k) keys[q * k + lane] = v;
+}
+
+// Certificate of a one-pass ("hi" parts only) top-k search with k1 > k list slots:
+//   approx [nq][k1]: the one-pass keys, best first;  exact [nq][k1]: the same candidates rescored exactly and re-sorted.
+// A row outside the candidate list has a one-pass score <= the list's last one-pass score s_min, hence an exact score
+// <= s_min + bound(q); if the k-th exact score of the candidates is STRICTLY above that, the candidates' exact top k is the
+// exact top k.  Queries that fail the test are appended to out_idx.  An unfilled list (fewer than k1 rows) holds every row.
+__global__ __launch_bounds__(256) void certify_topk_kernel(const u64* __restrict__ approx, const u64* __restrict__ exact,
+                                                           const float* __restrict__ qn, long long nq, int k1, int k,
+                                                           float scale, float slack, long long* __restrict__ out_idx,
+                                                           unsigned long long* __restrict__ out_count) {
+    const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    bool open = false;
+    if (q < nq) {
+        const u64 last = approx[q * k1 + k1 - 1];
+        const u64 kth = exact[q * k1 + k - 1];
+        if (last != 0 && kth != 0) {
+            const float s_min = lvs_unord32((uint32_t)(last >> 32));
+            const float s_k = lvs_unord32((uint32_t)(kth >> 32));
+            const float bound = scale * sqrtf(qn ? qn[q] : 1.0f) + slack;
+            open = !(s_k > s_min + bound);
+        }
+    }
+    const unsigned long long m = __ballot(open);
+    if (m == 0) return;
+    const int lane = threadIdx.x & 63;
+    unsigned long long base = 0;
+    if (lane == 0) base = atomicAdd(out_count, (unsigned long long)__popcll(m));
+    base = lvs_shfl_u64(base, 0);
+    if (open) out_idx[base + __popcll(m & ((1ull << lane) - 1ull))] = q;
 }
 
 // queries whose winner is NOT certified by its margin: (best score - runner-up score) <= scale * |q| + slack.
@@ -478,6 +519,13 @@ extern "C" int32_t lvs_gather_f32(const float* src, const int64_t* ids, int64_t 
 // search
 // ---------------------------------------------------------------------------------------------------------------
 namespace {
+// lvs_flat_search_keys_hi: the same search planned over the fp16 "hi" parts only (one K segment whatever the pack modes)
+thread_local bool g_hi_only = false;
+struct HiOnlyScope {
+    HiOnlyScope() { g_hi_only = true; }
+    ~HiOnlyScope() { g_hi_only = false; }
+};
+
 struct Plan {
     int dpad, nkd, nk, ldb, ldq, nseg;
     int seg_q[3], seg_c[3];
@@ -506,8 +554,8 @@ int make_plan(int64_t nq, int64_t nb, int32_t d, int32_t xb_pack, int32_t xq_pac
     };
     p.seg_q[0] = p.seg_q[1] = p.seg_q[2] = p.seg_c[0] = p.seg_c[1] = p.seg_c[2] = 0;
     seg(0, 0);
-    if (xb_pack == LVS_PACK_SPLIT) seg(0, p.dpad);
-    if (xq_pack == LVS_PACK_SPLIT) seg(p.dpad, 0);
+    if (xb_pack == LVS_PACK_SPLIT && !g_hi_only) seg(0, p.dpad);
+    if (xq_pack == LVS_PACK_SPLIT && !g_hi_only) seg(p.dpad, 0);
     p.nk = p.nseg * p.nkd;
     p.ntiles = (int)lvs_ceil_div(nb > 0 ? nb : 1, LVS_BC);
     // geometry: 256 queries per tile with 15 list slots (k <= 15 and every non-top-k mode), else 128 queries / 56 slots
@@ -912,7 +960,7 @@ extern "C" int32_t lvs_flat_search_keys(const void* xb, int32_t xb_pack, int64_t
 
     // HBM-bound regime (the literal sem_search: one query per call): stream the corpus once, queries resident in LDS
     {
-        const int nqseg = xq_pack == LVS_PACK_SPLIT ? 2 : 1;
+        const int nqseg = (xq_pack == LVS_PACK_SPLIT && !g_hi_only) ? 2 : 1;
         const int jper = p.dpad / 16;
         int kcap = 0;
         const bool fits = lvs_stream_plan(nq, k, nqseg * jper, &kcap) > 0;
@@ -1116,8 +1164,9 @@ extern "C" int32_t lvs_nearest_hi(const void* xb, int32_t xb_pack, int64_t nb, c
 
 extern "C" int32_t lvs_rescore_keys(const void* xb, int32_t xb_pack, const void* xq, int32_t xq_pack, int64_t nq, int32_t d,
                                     int32_t metric, const float* xb_norms_sq, const float* xq_norms_sq, int64_t id_offset,
-                                    uint64_t* keys, void* stream) {
-    LVS_REQUIRE(nq >= 0 && d > 0, "bad shape");
+                                    int32_t k, uint64_t* keys, void* stream) {
+    LVS_REQUIRE(nq >= 0 && d > 0 && k >= 0, "bad shape");
+    if (k == 0) return LVS_OK;
     LVS_REQUIRE(metric == LVS_METRIC_IP || metric == LVS_METRIC_L2, "bad metric %d", metric);
     LVS_REQUIRE((xb_pack == LVS_PACK_F16 || xb_pack == LVS_PACK_SPLIT) && (xq_pack == LVS_PACK_F16 || xq_pack == LVS_PACK_SPLIT),
                 "bad pack mode %d/%d", xb_pack, xq_pack);
@@ -1127,16 +1176,50 @@ extern "C" int32_t lvs_rescore_keys(const void* xb, int32_t xb_pack, const void*
     LVS_DEVICE_GUARD(stream);
     const int dpad = (int)lvs_round_up(d, LVS_BK);
     const long long ldb = xb_pack == LVS_PACK_SPLIT ? 2 * dpad : dpad, ldq = xq_pack == LVS_PACK_SPLIT ? 2 * dpad : dpad;
-    const dim3 grid((unsigned)lvs_ceil_div(nq, 4)), block(256);
+    const dim3 grid((unsigned)lvs_ceil_div(nq * k, 4)), block(256);
     hipStream_t st = (hipStream_t)stream;
 #define LVS_RESCORE(QS, BS)                                                                                              \
     hipLaunchKernelGGL((rescore_keys_kernel<QS, BS>), grid, block, 0, st, (const _Float16*)xb, ldb, (const _Float16*)xq, ldq, \
-                       dpad, metric, xb_norms_sq, xq_norms_sq, (long long)id_offset, (long long)nq, (u64*)keys)
+                       dpad, metric, xb_norms_sq, xq_norms_sq, (long long)id_offset, (long long)nq, (int)k, (u64*)keys)
     if (xq_pack == LVS_PACK_SPLIT && xb_pack == LVS_PACK_SPLIT) LVS_RESCORE(1, 1);
     else if (xq_pack == LVS_PACK_SPLIT) LVS_RESCORE(1, 0);
     else if (xb_pack == LVS_PACK_SPLIT) LVS_RESCORE(0, 1);
     else LVS_RESCORE(0, 0);
 #undef LVS_RESCORE
+    LVS_HIP_CHECK(hipGetLastError());
+    return LVS_OK;
+}
+
+extern "C" int32_t lvs_flat_search_keys_hi(const void* xb, int32_t xb_pack, int64_t nb, const void* xq, int32_t xq_pack,
+                                           int64_t nq, int32_t d, int32_t metric, int32_t k, const float* xb_norms_sq,
+                                           const float* xq_norms_sq, int64_t id_offset, const uint32_t* row_ids,
+                                           uint64_t* out_keys, void* workspace, int64_t workspace_bytes, void* stream) {
+    HiOnlyScope hi;
+    return lvs_flat_search_keys(xb, xb_pack, nb, xq, xq_pack, nq, d, metric, k, xb_norms_sq, xq_norms_sq, id_offset, row_ids,
+                                out_keys, workspace, workspace_bytes, stream);
+}
+
+extern "C" int32_t lvs_sort_keys_desc(uint64_t* keys, int64_t nq, int32_t k, void* stream) {
+    LVS_REQUIRE(nq >= 0 && k >= 0 && k <= 64, "lvs_sort_keys_desc: k must be at most 64 (got %d)", k);
+    if (nq == 0 || k <= 1) return LVS_OK;
+    LVS_REQUIRE(keys, "NULL buffer");
+    LVS_DEVICE_GUARD(stream);
+    hipLaunchKernelGGL(sort_keys_kernel, dim3((unsigned)lvs_ceil_div(nq, 4)), dim3(256), 0, (hipStream_t)stream, (u64*)keys,
+                       (long long)nq, (int)k);
+    LVS_HIP_CHECK(hipGetLastError());
+    return LVS_OK;
+}
+
+extern "C" int32_t lvs_certify_topk(const uint64_t* approx_keys, const uint64_t* exact_keys, const float* q_norms_sq,
+                                    int64_t nq, int32_t k1, int32_t k, float scale, float slack, int64_t* out_idx,
+                                    uint64_t* out_count, void* stream) {
+    LVS_REQUIRE(nq >= 0 && k >= 1 && k1 >= k && scale >= 0.f && slack >= 0.f, "bad arguments");
+    if (nq == 0) return LVS_OK;
+    LVS_REQUIRE(approx_keys && exact_keys && out_idx && out_count, "NULL buffer");
+    LVS_DEVICE_GUARD(stream);
+    hipLaunchKernelGGL(certify_topk_kernel, dim3((unsigned)lvs_ceil_div(nq, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const u64*)approx_keys, (const u64*)exact_keys, q_norms_sq, (long long)nq, (int)k1, (int)k, scale, slack,
+                       (long long*)out_idx, (unsigned long long*)out_count);
     LVS_HIP_CHECK(hipGetLastError());
     return LVS_OK;
 }

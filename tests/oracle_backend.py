@@ -52,7 +52,7 @@ class OracleBackend:
         self.calls.append(("gather", len(idx)))
         return PackedRows(rows=src.rows[idx], norms=src.norms[idx], n=len(idx), d=src.d, mode=src.mode)
 
-    def search_keys(self, corpus, queries, k, metric, id_offset=0, row_ids=None):
+    def search_keys(self, corpus, queries, k, metric, id_offset=0, row_ids=None, one_pass=None, stats=None):
         self.calls.append(("search", queries.n, corpus.n, k, metric))
         xb, xq = corpus.rows.numpy(), queries.rows.numpy()
         if corpus.n == 0:

@@ -436,3 +436,54 @@ def test_seeded_streaming_search_with_duplicates_across_the_sample_boundary(hip_
         Dr, Ir = oracle.flat_search(_stored(xb, F16), _stored(xq, F16), k, IP)
         assert np.array_equal(I, Ir)
         assert np.abs(D - Dr).max() <= 1e-5
+
+
+@pytest.mark.parametrize("cmode,qmode,metric,nq,nb,d,k", [
+    (SPLIT, SPLIT, IP, 3000, 60_000, 384, 10),   # LOTUS's default: fp32 embeddings on both sides (3 passes -> 1)
+    (SPLIT, F16, L2, 2000, 50_000, 200, 5),
+    (F16, SPLIT, IP, 1000, 40_000, 768, 20),     # k1 = 28: the 128-query geometry
+    (SPLIT, SPLIT, L2, 300, 30_000, 128, 48),    # largest certified k (56 list slots)
+    (SPLIT, SPLIT, IP, 20, 100_000, 256, 10),    # few queries: the one-pass search is the streaming kernel
+    (SPLIT, SPLIT, IP, 500, 9, 64, 10),          # fewer rows than list slots: plain path
+])
+def test_one_pass_certified_search_equals_the_plain_search(hip_backend, cmode, qmode, metric, nq, nb, d, k):
+    """fp32-accurate operands: one MFMA pass over the hi parts + exact rescoring of k1 > k candidates + certificate
+    + plain search of the uncertified queries == the plain 2-3 pass search (same ids; scores to fp32 rounding)."""
+    be = hip_backend
+    xb = synth.corpus(nb, d, seed=nb % 91) * (1.3 if metric == L2 else 1.0)
+    xq, _ = synth.queries(xb, nq, seed=6)
+    cb = be.pack(xb.astype(np.float16) if cmode == F16 else xb, cmode)
+    cq = be.pack(xq.astype(np.float16) if qmode == F16 else xq, qmode)
+    stats = {}
+    Dg, Ig = (t.cpu().numpy() for t in be.keys_to_result(be.search_keys(cb, cq, k, metric, id_offset=11, one_pass=True, stats=stats), metric))
+    Dw, Iw = (t.cpu().numpy() for t in be.keys_to_result(be.search_keys(cb, cq, k, metric, id_offset=11, one_pass=False), metric))
+    err, hard, recall = synth.compare_topk(Dw, Iw, Dg, Ig, atol=4e-6 * max(1.0, np.abs(Dw[Iw >= 0]).max()), tie_gap=4e-6)
+    assert hard == 0 and recall == 1.0 and err <= 4e-6 * max(1.0, np.abs(Dw[Iw >= 0]).max())
+    if nb > 4 * (k + 8):
+        assert stats["queries"] == nq and stats["uncertified"] <= 0.25 * nq
+    # and against the oracle on the stored values
+    Dr, Ir = oracle.flat_search(_stored(xb, cmode), _stored(xq, qmode), k, metric)
+    atol = 1e-5 if metric == IP else 4e-5
+    err, hard, recall = synth.compare_topk(Dr, Ir + 11 * (Ir >= 0), Dg, Ig, atol=atol)
+    assert err <= atol and hard == 0 and recall >= 0.9999
+
+
+def test_one_pass_certificate_refuses_rows_that_differ_below_fp16_resolution(hip_backend):
+    """Twins with identical hi parts and different lo parts around rank k: the one-pass scores cannot order them, the
+    certificate must send those queries to the plain search - results stay exact."""
+    be = hip_backend
+    d, nb = 96, 20_000
+    h16 = (synth.corpus(nb, d, seed=5) * 1.1).astype(np.float16)
+    xb = h16.astype(np.float32)
+    xq = xb[:64].copy()
+    # every query gets 30 near-copies of its own row: same hi part, lo part growing with the copy number
+    for qi in range(64):
+        rows = 1000 + qi * 30 + np.arange(30)
+        xb[rows] = xb[qi]
+        xb[rows, :8] += (np.arange(30)[:, None] / 100.0) * np.spacing(np.abs(h16[qi, :8])).astype(np.float32)
+    cb, cq = be.pack(xb, SPLIT), be.pack(xq, SPLIT)
+    stats = {}
+    Dg, Ig = (t.cpu().numpy() for t in be.keys_to_result(be.search_keys(cb, cq, 10, IP, one_pass=True, stats=stats), IP))
+    Dw, Iw = (t.cpu().numpy() for t in be.keys_to_result(be.search_keys(cb, cq, 10, IP, one_pass=False), IP))
+    assert stats["uncertified"] >= 60
+    assert np.array_equal(Ig, Iw) and np.abs(Dg - Dw).max() <= 1e-6
