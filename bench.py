@@ -305,6 +305,29 @@ def secondary_legs(np, torch, be, _capi, xb, xq, corpus, queries, k):
                                  "achieved_tflops": fl / (kms * 1e-3) / 1e12,
                                  "frac": fl / (kms * 1e-3) / 1e12 / PEAK_FP16_MFMA_TFLOPS,
                                  "node_queries_per_s_if_8_gpus": queries.n / (kms * 1e-3)}
+    # LOTUS's default storage: fp32 embeddings (fp16 hi|lo pairs on the device).  10k queries x the same 1M rows, plain
+    # search (three K segments) vs the certified one-pass search (same exact result)
+    xb32 = torch.nn.functional.normalize(xb.float() + 1e-4 * torch.randn_like(xb, dtype=torch.float32), dim=1)
+    c32 = be.pack(xb32, _capi.PACK_SPLIT)
+    del xb32
+    q32 = be.pack(torch.nn.functional.normalize(xq[:10_000].float() + 1e-4 * torch.randn((10_000, d), device=xq.device), dim=1),
+                  _capi.PACK_SPLIT)
+    res32 = {}
+    for tag, one_pass in (("plain_3_segments", False), ("one_pass_certified", True)):
+        stats = {}
+        for _ in range(2):
+            be.search_keys(c32, q32, k, _capi.METRIC_IP, one_pass=one_pass)
+        be.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            be.search_keys(c32, q32, k, _capi.METRIC_IP, one_pass=one_pass, stats=stats)
+        be.synchronize()
+        ms = (time.perf_counter() - t0) / 3 * 1e3
+        res32[tag] = {"ms_per_call": ms, "algorithmic_tflops": 2.0 * q32.n * c32.n * d / (ms * 1e-3) / 1e12}
+        if one_pass:
+            res32[tag]["uncertified_fraction"] = stats["uncertified"] / max(1, stats["queries"])
+    legs["fp32_embeddings_10k_x_1M"] = res32
+    del c32, q32
     # T_call: VS.__call__(host ndarray) -> host (D, I), corpus resident; includes packing the queries,
     # the H2D copy of 154 MB and the D2H copy of the results
     from lotus_amd.vs import HipVS, _Resident
