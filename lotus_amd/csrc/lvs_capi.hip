@@ -614,6 +614,29 @@ int make_plan(int64_t nq, int64_t nb, int32_t d, int32_t xb_pack, int32_t xq_pac
         if (s > p.ntiles) s = p.ntiles;
     }
     if (max_slabs_cap > 0 && s > max_slabs_cap) s = max_slabs_cap;  // ... and at most this many
+    // Tail effect.  A launch is nqt * s (query tile, slab) items of equal length, one per CU at a time on 256 CUs: an item
+    // count just above a multiple of 256 leaves most of the chip idle for one whole item.  Measured with the slab count
+    // swept (profiles/r02_tuning.md): 100 k x 1 M at 21 slabs = 32.07 rounds 142.8-147.6 ms, 19 (29.02) 143.5-143.9,
+    // 17 (25.96) 140.5-142.4, 13 (19.86) 139.2-139.6; 100 k x 125 k at 11 slabs (16.80 rounds) 22.4 ms, 13 (19.86)
+    // 22.1.  So among the slab counts near the heuristic's choice (same group shape, slabs not shorter than
+    // the heuristic allows) take the one whose last round is fullest.
+    if (min_slabs == 0 && max_slabs_cap == 0 && (int64_t)p.nqt * s >= 4 * 256 && lvs_tune("LVS_TAIL", 1) != 0) {
+        const int64_t lead = p.lead_slabs;
+        const int64_t hi_lim = slabs_l2 > 0 ? lead + p.ntiles / lvs_tune("LVS_L2_MIN_TILES", 160) : max_slabs;
+        double best_cost = 1e30;
+        int64_t best = s;
+        for (int64_t c = lead + gs; c <= s + s / 4 && c <= hi_lim && c <= p.ntiles; c += gs) {
+            if (5 * c < 3 * s) continue;  // stay within [0.6 s, 1.25 s]
+            const double rounds = (double)p.nqt * (double)c / 256.0;
+            const double cost = (double)lvs_ceil_div((int64_t)p.nqt * c, 256) / rounds;
+            const int64_t dist = c > s ? c - s : s - c, bdist = best > s ? best - s : s - best;
+            if (cost < best_cost - 1e-9 || (cost < best_cost + 1e-9 && dist < bdist)) {
+                best_cost = cost;
+                best = c;
+            }
+        }
+        s = best;
+    }
     if (lvs_tune_set("LVS_NSLAB")) {  // -DLVS_TUNING builds only
         const int64_t v = lvs_tune("LVS_NSLAB", 0);
         if (v >= 1 && v <= p.ntiles) s = v;
