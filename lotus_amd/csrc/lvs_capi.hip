@@ -619,7 +619,7 @@ int make_plan(int64_t nq, int64_t nb, int32_t d, int32_t xb_pack, int32_t xq_pac
     // swept (profiles/r02_tuning.md): 100 k x 1 M at 21 slabs = 32.07 rounds 142.8-147.6 ms, 19 (29.02) 143.5-143.9,
     // 17 (25.96) 140.5-142.4, 13 (19.86) 139.2-139.6; 100 k x 125 k at 11 slabs (16.80 rounds) 22.4 ms, 13 (19.86)
     // 22.1.  So among the slab counts near the heuristic's choice (same group shape, slabs not shorter than
-    // the heuristic allows) take the one whose last round is fullest.
+    // the heuristic allows) take the one with the smallest estimated time = rounds x item length.
     if (min_slabs == 0 && max_slabs_cap == 0 && (int64_t)p.nqt * s >= 4 * 256 && lvs_tune("LVS_TAIL", 1) != 0) {
         const int64_t lead = p.lead_slabs;
         const int64_t hi_lim = slabs_l2 > 0 ? lead + p.ntiles / lvs_tune("LVS_L2_MIN_TILES", 160) : max_slabs;
@@ -627,8 +627,12 @@ int make_plan(int64_t nq, int64_t nb, int32_t d, int32_t xb_pack, int32_t xq_pac
         int64_t best = s;
         for (int64_t c = lead + gs; c <= s + s / 4 && c <= hi_lim && c <= p.ntiles; c += gs) {
             if (5 * c < 3 * s) continue;  // stay within [0.6 s, 1.25 s]
-            const double rounds = (double)p.nqt * (double)c / 256.0;
-            const double cost = (double)lvs_ceil_div((int64_t)p.nqt * c, 256) / rounds;
+            // estimated launch time in tiles: item length x rounds.  Two views of "rounds": 256 CUs taking one item each
+            // (ceil(items / 256)) and 8 XCDs taking one 32-slot group each (blocks are dealt to the XCDs group by group,
+            // item_of_block); the measurements lie between the two (13 < 9 < 17 < 21 slabs at 100 k x 1 M), so both count.
+            const int64_t groups = lvs_ceil_div(p.nqt, 32) * lead + lvs_ceil_div(p.nqt, p.gq) * lvs_ceil_div(c - lead, gs);
+            const double rounds = 0.5 * (double)(lvs_ceil_div((int64_t)p.nqt * c, 256) + lvs_ceil_div(groups, 8));
+            const double cost = rounds * (double)lvs_ceil_div(p.ntiles, c);
             const int64_t dist = c > s ? c - s : s - c, bdist = best > s ? best - s : s - best;
             if (cost < best_cost - 1e-9 || (cost < best_cost + 1e-9 && dist < bdist)) {
                 best_cost = cost;
