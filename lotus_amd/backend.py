@@ -140,6 +140,8 @@ class HipBackend:
             one_pass = queries.n * corpus.n >= self.CERT_MIN_PAIRS
         if (one_pass and split and row_ids is None and 1 <= k <= self.CERT_MAX_K and corpus.n >= 4 * (k + 8)
                 and queries.n > 0):
+            if k == 1:  # the winner + runner-up certificate is the cheaper one-pass form for a single neighbour
+                return self.nearest(corpus, queries, metric, id_offset=id_offset, stats=stats)
             return self._search_keys_certified(corpus, queries, k, metric, id_offset, stats)
         keys = torch.empty((queries.n, k), dtype=torch.int64, device=self.device)
         need = int(self.lib.lvs_flat_search_workspace_bytes(queries.n, corpus.n, corpus.d, k, corpus.mode, queries.mode))

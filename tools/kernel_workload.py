@@ -90,7 +90,7 @@ nchunks = -(-NR // be.RANGE_CHUNK_ROWS)
 scenario("range_selfjoin_1M", "lvs_tile_kernel<3, 4>", lambda: be.range_join(p1m, p1m, 0.95, IP, q_row0=0), 1, warm=1,
          bound="mfma", flops_per_call=1.0 * NR * NR * D, launches_per_call=nchunks,
          note="sem_dedup threshold self-join (cfg4 shape at 1 M rows); algorithmic flops = N^2 d (each unordered pair once)")
-scenario("top1_kmeans_2M_x_1024_hilo", "lvs_tile_kernel<2, 4>", lambda: be.search_keys(pc, pts, 1, L2), 3, warm=1,
+scenario("top1_kmeans_2M_x_1024_hilo", "lvs_tile_kernel<2, 4>", lambda: be.search_keys(pc, pts, 1, L2, one_pass=False), 3, warm=1,
          bound="mfma", flops_per_call=2.0 * 2_000_000 * 1024 * D,
          note="k-means assignment, fp16 points x fp32-accurate (hi|lo) centroids: 2 K segments = 2x the MFMA work")
 scenario("top1_kmeans_2M_x_1024_fp16c", "lvs_tile_kernel<2, 4>", lambda: be.search_keys(pc16, pts, 1, L2), 3, warm=1,
@@ -98,6 +98,17 @@ scenario("top1_kmeans_2M_x_1024_fp16c", "lvs_tile_kernel<2, 4>", lambda: be.sear
 scenario("nearest_hi_2M_x_1024", "lvs_tile_kernel<5, 4>", lambda: be.nearest(pc, pts, L2), 3, warm=1,
          bound="mfma", flops_per_call=2.0 * 2_000_000 * 1024 * D,
          note="certified k-means assignment: ONE pass over the hi parts + margin certificate (same winners as the hi|lo search)")
+x32m = x16[:1_000_000].float()
+x32m += 1e-4 * torch.randn(x32m.shape, generator=g, device=dev)
+c32 = be.pack(x32m, SPLIT)
+q32 = be.pack(xq[:10_000].float() + 1e-4 * torch.randn((10_000, D), generator=g, device=dev), SPLIT)
+del x32m
+scenario("fp32_topk_10k_x_1M_plain", "lvs_tile_kernel<0, 4>", lambda: be.search_keys(c32, q32, 10, IP, one_pass=False), 3, warm=1,
+         bound="mfma", flops_per_call=2.0 * 10_000 * 1_000_000 * D, note="fp32 embeddings (hi|lo rows), plain search: three K segments")
+scenario("fp32_topk_10k_x_1M_one_pass", "lvs_tile_kernel<0, 4>", lambda: be.search_keys(c32, q32, 10, IP, one_pass=True), 3, warm=1,
+         bound="mfma", flops_per_call=2.0 * 10_000 * 1_000_000 * D, launches_per_call=1,
+         note="same result from one pass over the hi parts with 15 list slots (+ rescoring, certificate, ~1 % of the queries searched again: those launches are not in this figure)")
+del c32, q32
 # ---- HBM-bound helpers ----
 scenario("km_reduce_4M_x_1024", "km_reduce_kernel", lambda: be.kmeans_accumulate(p4m, assign, 1024), 3, warm=1,
          bytes_per_call=N4 * ld(p4m) * 2)
