@@ -19,7 +19,8 @@ Extra objects:
                   against the CPU oracle (oracle/flat.py) on a query sample - at every N, rank 0;
   "legs"          (N=1) short secondary measurements in the same process: BASELINE configs[1] (10k x 1M), the literal
                   single-query sem_search (HBM-bound streaming kernel), the 8-GPU shard shape (100k x 125k) and T_call
-                  (`HipVS.__call__` host ndarray -> host (D, I), PCIe included) - each with kernel ms and roofline fraction.
+                  (`HipVS.__call__` host ndarray -> host (D, I), PCIe included), the per-GPU shape of the query split and the fp32-embeddings
+                  call (plain vs certified one-pass) - each with kernel ms and roofline fraction.
 """
 from __future__ import annotations
 
@@ -305,6 +306,15 @@ def secondary_legs(np, torch, be, _capi, xb, xq, corpus, queries, k):
                                  "achieved_tflops": fl / (kms * 1e-3) / 1e12,
                                  "frac": fl / (kms * 1e-3) / 1e12 / PEAK_FP16_MFMA_TFLOPS,
                                  "node_queries_per_s_if_8_gpus": queries.n / (kms * 1e-3)}
+    # ... and what each of 8 GPUs does under the QUERY split of the same join (HipVS(shard="queries"): corpus replicated,
+    # 12 500 queries per GPU against all 1 M rows, finished lists all-gathered, no merge)
+    q8 = be.slice_rows(queries, 0, min(queries.n, 12_500))
+    kms, wms = kernel_leg(corpus, q8, 5)
+    fl = 2.0 * q8.n * corpus.n * d
+    legs["query_split_12500_x_1M"] = {"kernel_ms": kms, "ms_per_call": wms, "bound": "mfma",
+                                      "achieved_tflops": fl / (kms * 1e-3) / 1e12,
+                                      "frac": fl / (kms * 1e-3) / 1e12 / PEAK_FP16_MFMA_TFLOPS,
+                                      "node_queries_per_s_if_8_gpus": 8 * q8.n / (kms * 1e-3)}
     # LOTUS's default storage: fp32 embeddings (fp16 hi|lo pairs on the device).  10k queries x the same 1M rows, plain
     # search (three K segments) vs the certified one-pass search (same exact result)
     xb32 = torch.nn.functional.normalize(xb.float() + 1e-4 * torch.randn_like(xb, dtype=torch.float32), dim=1)

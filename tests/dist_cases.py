@@ -82,6 +82,13 @@ def worker(rank, world, port, tmp, out_q, backend_kind):
                           ("k1000", vs(xq[:40], 1000)), ("rank_all", vs(xq[:5], 3000)),
                           ("k1500_sub", vs(xq[:4], 1500, ids=ids)), ("rank_sub", vs(xq[:4], 2600, ids=subset_big()))):
             res[name] = (np.asarray(out.distances), np.asarray(out.indices))
+        # the other split: corpus replicated, every rank searches its slice of the queries (299 = uneven slices)
+        vq = HipVS(backend=be, shard="queries")
+        vq.load_index(os.path.join(tmp, "idx"))
+        entq = vq._resident[vq.index_dir]
+        res["q_bounds"] = (entq.lo, entq.hi, entq.packed.n)
+        for name, out in (("q_full", vq(xq[:299], 7)), ("q_sub", vq(xq[:299], 7, ids=ids)), ("q_one", vq(xq[:1], 5))):
+            res[name] = (np.asarray(out.distances), np.asarray(out.indices))
         res["scores"] = vs.scores(xq[:6])
         res["scores_sub"] = vs.scores(xq[:6], ids=ids[:77])
         # k-means on the row-sharded index: all rows, then a subset of rows
@@ -163,6 +170,14 @@ def check(res, exact: bool):
         same_topk(r["rank_sub"], ref_rsub, 2600)  # ... and on a subset of the rows (ids remapped through the shards)
         assert r["scores"].shape == (6, NB) and np.abs(r["scores"] - S).max() <= 1e-5
         assert np.abs(r["scores_sub"] - S[:, ids[:77]]).max() <= 1e-5
+    ref_qf = oracle.flat_search(xb32, xq32[:299], 7)
+    ref_qs = oracle.flat_search(xb32, xq32[:299], 7, ids=ids)
+    ref_q1 = oracle.flat_search(xb32, xq32[:1], 5)
+    for r in res:
+        assert r["q_bounds"] == (0, NB, NB)  # query split: the whole corpus on every rank
+        same_topk(r["q_full"], ref_qf, 7)
+        same_topk(r["q_sub"], ref_qs, 7)
+        same_topk(r["q_one"], ref_q1, 5)    # fewer queries than ranks: one rank's slice is empty
     # every rank holds the same merged answers
     for key in ("full", "sub", "k1000", "rank_all"):
         assert np.array_equal(res[0][key][1], res[1][key][1]) and np.array_equal(res[0][key][0], res[1][key][0])
