@@ -578,12 +578,14 @@ int make_plan(int64_t nq, int64_t nb, int32_t d, int32_t xb_pack, int32_t xq_pac
     // enough (query tile, slab) items to load-balance 256 CUs, slabs kept >= 32 tiles, a multiple of gs slabs
     int64_t want = lvs_ceil_div(4096, p.nqt);
     // Long corpus streams: 8 query tiles x 4 slabs per XCD share BOTH operands through the 4 MB L2 (hit rate 37 % -> 70 %,
-    // half the fabric traffic, +3 % clock) and win 1-5 % once each of >= 20 slabs still has >= 160 tiles
-    // (profiles/r01_tuning.md); shorter slabs lose more to the extra cold starts than the locality returns.
+    // half the fabric traffic, +3 % clock).  Measured against the 32 x 1 groups (profiles/r02_tuning.md): 100 k x 1 M
+    // +9 % on the main loop, 100 k x 500 k 78.1 -> 72.6 ms, 100 k x 250 k 41.5 -> 38.5 ms, no difference at 100 k x 125 k
+    // (12 slabs of 40 tiles) - so it is used whenever >= 8 narrow slabs of >= 40 tiles exist.
     int64_t slabs_l2 = 0;
     if (p.v2 && p.gq > 8 && p.nqt >= 64 && min_slabs == 0) {
-        const int64_t n8 = lvs_round_up(want > 20 ? want : 20, 4);
-        const int64_t min_tiles = lvs_tune("LVS_L2_MIN_TILES", 160);
+        const int64_t l2_min_slabs = lvs_tune("LVS_L2_MIN_SLABS", 8);
+        const int64_t n8 = lvs_round_up(want > l2_min_slabs ? want : l2_min_slabs, 4);
+        const int64_t min_tiles = lvs_tune("LVS_L2_MIN_TILES", 40);
         if (p.ntiles / n8 >= min_tiles) {
             p.gq = 8;
             slabs_l2 = n8;
@@ -614,25 +616,23 @@ int make_plan(int64_t nq, int64_t nb, int32_t d, int32_t xb_pack, int32_t xq_pac
         if (s > p.ntiles) s = p.ntiles;
     }
     if (max_slabs_cap > 0 && s > max_slabs_cap) s = max_slabs_cap;  // ... and at most this many
-    // Tail effect.  A launch is nqt * s (query tile, slab) items of equal length, one per CU at a time on 256 CUs: an item
-    // count just above a multiple of 256 leaves most of the chip idle for one whole item.  Measured with the slab count
-    // swept (profiles/r02_tuning.md): 100 k x 1 M at 21 slabs = 32.07 rounds 142.8-147.6 ms, 19 (29.02) 143.5-143.9,
-    // 17 (25.96) 140.5-142.4, 13 (19.86) 139.2-139.6; 100 k x 125 k at 11 slabs (16.80 rounds) 22.4 ms, 13 (19.86)
-    // 22.1.  So among the slab counts near the heuristic's choice (same group shape, slabs not shorter than
-    // the heuristic allows) take the one with the smallest estimated time = rounds x item length.
+    // Tail effect.  A launch is nqt * s (query tile, slab) items of equal length; an XCD (32 CUs, one workgroup each) runs
+    // 32 of ITS items at a time, so the launch lasts max over the XCDs of ceil(items of that XCD / 32) item-times
+    // (lvs_tile_xcd_rounds follows item_of_block's deal exactly, incl. the last groups spread over all XCDs).  Measured
+    // with the slab count swept (profiles/r02_tuning.md): 100 k x 1 M at 21 slabs 142.8-147.6 ms, 17 140.5-142.4,
+    // 13 139.2-139.6.  So among the slab counts near the heuristic's choice (same group shape, slabs not shorter than the
+    // heuristic allows) take the one with the smallest estimated time = rounds x (item length + its fixed cost).
     if (min_slabs == 0 && max_slabs_cap == 0 && (int64_t)p.nqt * s >= 4 * 256 && lvs_tune("LVS_TAIL", 1) != 0) {
         const int64_t lead = p.lead_slabs;
-        const int64_t hi_lim = slabs_l2 > 0 ? lead + p.ntiles / lvs_tune("LVS_L2_MIN_TILES", 160) : max_slabs;
+        const int64_t hi_lim = slabs_l2 > 0 ? lead + p.ntiles / lvs_tune("LVS_L2_MIN_TILES", 40) : max_slabs;
         double best_cost = 1e30;
         int64_t best = s;
         for (int64_t c = lead + gs; c <= s + s / 4 && c <= hi_lim && c <= p.ntiles; c += gs) {
-            if (5 * c < 3 * s) continue;  // stay within [0.6 s, 1.25 s]
-            // estimated launch time in tiles: item length x rounds.  Two views of "rounds": 256 CUs taking one item each
-            // (ceil(items / 256)) and 8 XCDs taking one 32-slot group each (blocks are dealt to the XCDs group by group,
-            // item_of_block); the measurements lie between the two (13 < 9 < 17 < 21 slabs at 100 k x 1 M), so both count.
-            const int64_t groups = lvs_ceil_div(p.nqt, 32) * lead + lvs_ceil_div(p.nqt, p.gq) * lvs_ceil_div(c - lead, gs);
-            const double rounds = 0.5 * (double)(lvs_ceil_div((int64_t)p.nqt * c, 256) + lvs_ceil_div(groups, 8));
-            const double cost = rounds * (double)lvs_ceil_div(p.ntiles, c);
+            if (10 * c < 3 * s) continue;  // stay within [0.3 s, 1.25 s]
+            const int64_t tps = lvs_ceil_div(p.ntiles, c), ns = lvs_ceil_div(p.ntiles, tps);
+            const int rounds = lvs_tile_xcd_rounds(p.nqt, (int)ns, p.gq, (int)lead);
+            // an item also pays a list cold start and its candidate write-out: about two tiles' worth
+            const double cost = (double)rounds * (double)(tps + 2);
             const int64_t dist = c > s ? c - s : s - c, bdist = best > s ? best - s : s - best;
             if (cost < best_cost - 1e-9 || (cost < best_cost + 1e-9 && dist < bdist)) {
                 best_cost = cost;
@@ -647,6 +647,12 @@ int make_plan(int64_t nq, int64_t nb, int32_t d, int32_t xb_pack, int32_t xq_pac
     }
     p.tiles_per_slab = (int)lvs_ceil_div(p.ntiles, s);
     p.nslab = (int)lvs_ceil_div(p.ntiles, p.tiles_per_slab);
+#ifdef LVS_TUNING
+    if (lvs_tune("LVS_PLAN_PRINT", 0) != 0)
+        fprintf(stderr, "lvs plan: nq %lld nb %lld k %d -> nqt %d ntiles %d gq %d lead %d slabs %d x %d tiles, items %lld, xcd rounds %d\n",
+                (long long)nq, (long long)nb, (int)k, p.nqt, p.ntiles, p.gq, p.lead_slabs, p.nslab, p.tiles_per_slab,
+                (long long)p.nqt * p.nslab, lvs_tile_xcd_rounds(p.nqt, p.nslab, p.gq, p.lead_slabs));
+#endif
     p.kpass = k < LVS_KPASS ? (k > 0 ? k : 1) : LVS_KPASS;  // k <= 15 -> one pass on the 256-query geometry
     p.npass = k > 0 ? (int)lvs_ceil_div(k, p.kpass) : 0;
     int64_t off = 256;  // the first 256 bytes hold status words (the large-k overflow flag) in every layout

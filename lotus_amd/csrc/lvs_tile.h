@@ -67,7 +67,38 @@ struct LvsTileArgs {
     unsigned long long* dbg;  // tuning aid (build with -DLVS_COUNT_EVENTS, run with LVS_COUNT=1): [0] block visits, [1] insertions, [2] wave-tiles, [3..5] cycles in filter / visit loop / insertions
 };
 
+// ---- the (query tile, slab) items of a launch in XCD groups of 32 slots (see item_of_block in lvs_tile.hip) ----
+struct LvsTileGroups {
+    int nqg32, n0;   // 32-wide groups of the leading slab(s): nqg32 per slab, n0 in all
+    int nqg, nsg;    // narrow groups: nqg along the query tiles x nsg along the slabs
+    int total, full; // all groups; the largest multiple of 8 below (whole generations: one group per XCD)
+};
+__host__ __device__ inline LvsTileGroups lvs_tile_groups(int nqt, int nslab, int gq, int lead_slabs) {
+    LvsTileGroups g;
+    const int gs = 32 / gq;
+    g.nqg32 = (nqt + 31) / 32;
+    g.n0 = g.nqg32 * lead_slabs;
+    g.nqg = (nqt + gq - 1) / gq;
+    g.nsg = (nslab - lead_slabs + gs - 1) / gs;
+    g.total = g.n0 + g.nqg * g.nsg;
+    g.full = g.total & ~7;
+    return g;
+}
+// slot r (0..31) of group g -> (query tile, slab); false when the slot is empty
+__host__ __device__ inline bool lvs_tile_group_slot(int nqt, int nslab, int gq, int lead_slabs, const LvsTileGroups& gr,
+                                                    int g, int r, int& qt, int& slab) {
+    if (g < gr.n0) {
+        slab = g / gr.nqg32;
+        qt = (g % gr.nqg32) * 32 + r;
+    } else {
+        const int h = g - gr.n0;
+        qt = (h % gr.nqg) * gq + (r % gq);
+        slab = lead_slabs + (h / gr.nqg) * (32 / gq) + (r / gq);
+    }
+    return qt < nqt && slab < nslab;
+}
 int lvs_tile_grid_blocks(int nqt, int nslab, int gq, int lead_slabs);
+int lvs_tile_xcd_rounds(int nqt, int nslab, int gq, int lead_slabs);
 hipError_t lvs_tile_launch(int mode, const LvsTileArgs& a, hipStream_t stream);
 
 // ---- small-batch streaming kernel (lvs_stream.hip): nq <= 64 (1..2 blocks of 32 queries per corpus pass), k <= LVS_KPASS.

@@ -137,26 +137,22 @@ __device__ __forceinline__ void first_hit(const f32x16& v, float tf, bool qv, fl
 // start with the thresholds its earlier slabs published.  With a.lead_slabs = 1 the first slab of EVERY query tile is
 // done first in 32-wide groups (one slab at a time per query: a single cold start), and only the remaining slabs use
 // the narrow groups whose 32/gq slabs per query run concurrently.
+// The last G % 8 groups would occupy G % 8 XCDs for a whole item while the others idle: their slots are dealt across
+// all eight XCDs instead (slot r of such a group runs on XCD r % 8), so every XCD ends within one item of the others.
 __device__ inline bool item_of_block(const LvsTileArgs& a, int b, int& qt, int& slab) {
-    int x = b & 7, j = b >> 3;
-    int gseq = j >> 5, r = j & 31;
-    int g = gseq * 8 + x;
-    if (a.lead_slabs > 0) {
-        const int nqg32 = (a.nqt + 31) / 32;
-        const int n0 = nqg32 * a.lead_slabs;
-        if (g < n0) {
-            slab = g / nqg32;
-            qt = (g % nqg32) * 32 + r;
-            return qt < a.nqt && slab < a.nslab;
-        }
-        g -= n0;
+    const LvsTileGroups gr = lvs_tile_groups(a.nqt, a.nslab, a.gq, a.lead_slabs);
+    int g, r;
+    if (b < gr.full * 32) {
+        const int x = b & 7, j = b >> 3;
+        g = (j >> 5) * 8 + x;
+        r = j & 31;
+    } else {
+        const int f = b - gr.full * 32;
+        g = gr.full + (f >> 5);
+        r = f & 31;
+        if (g >= gr.total) return false;
     }
-    int gq = a.gq, gs = 32 / a.gq;
-    int nqg = (a.nqt + gq - 1) / gq;
-    int qgroup = g % nqg, sgroup = g / nqg;
-    qt = qgroup * gq + (r % gq);
-    slab = a.lead_slabs + sgroup * gs + (r / gq);
-    return qt < a.nqt && slab < a.nslab;
+    return lvs_tile_group_slot(a.nqt, a.nslab, a.gq, a.lead_slabs, gr, g, r, qt, slab);
 }
 
 }  // namespace
@@ -799,8 +795,36 @@ hipError_t lvs_tile_launch(int mode, const LvsTileArgs& a, hipStream_t stream) {
 }
 
 int lvs_tile_grid_blocks(int nqt, int nslab, int gq, int lead_slabs) {
-    int gs = 32 / gq;
-    long long nqg = (nqt + gq - 1) / gq, nsg = (nslab - lead_slabs + gs - 1) / gs;
-    long long groups = (long long)((nqt + 31) / 32) * lead_slabs + nqg * nsg;
-    return (int)(lvs_round_up(groups, 8) * 32);
+    return lvs_tile_groups(nqt, nslab, gq, lead_slabs).total * 32;
+}
+
+// Items (valid (query tile, slab) pairs) each XCD receives under item_of_block's deal, in units of rounds: an XCD runs 32
+// items at a time (one workgroup per CU), so it needs ceil(items / 32) item-times.  Returns the largest over the 8 XCDs.
+int lvs_tile_xcd_rounds(int nqt, int nslab, int gq, int lead_slabs) {
+    const LvsTileGroups gr = lvs_tile_groups(nqt, nslab, gq, lead_slabs);
+    long long items[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const int gs = 32 / gq;
+    for (int g = 0; g < gr.full; ++g) {
+        int vq, vs;
+        if (g < gr.n0) {
+            vq = nqt - (g % gr.nqg32) * 32;
+            vq = vq < 0 ? 0 : (vq > 32 ? 32 : vq);
+            vs = 1;
+        } else {
+            const int h = g - gr.n0;
+            vq = nqt - (h % gr.nqg) * gq;
+            vq = vq < 0 ? 0 : (vq > gq ? gq : vq);
+            vs = nslab - lead_slabs - (h / gr.nqg) * gs;
+            vs = vs < 0 ? 0 : (vs > gs ? gs : vs);
+        }
+        items[g & 7] += (long long)vq * vs;
+    }
+    for (int g = gr.full; g < gr.total; ++g)
+        for (int r = 0; r < 32; ++r) {
+            int qt, slab;
+            if (lvs_tile_group_slot(nqt, nslab, gq, lead_slabs, gr, g, r, qt, slab)) ++items[r & 7];
+        }
+    long long worst = 0;
+    for (int x = 0; x < 8; ++x) worst = items[x] > worst ? items[x] : worst;
+    return (int)((worst + 31) / 32);
 }

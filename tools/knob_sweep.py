@@ -1,5 +1,6 @@
-"""Sweep one LVS_* planner knob of the TUNING build at a given shape (development aid).
-usage: python tools/knob_sweep.py QxN KNOB v1 v2 ...   e.g.  100000x1000000 LVS_NSLAB 21 25 29 33"""
+"""Sweep LVS_* planner knobs of the TUNING build at a given shape (development aid).
+usage: python tools/knob_sweep.py QxN KNOB v1 v2 ...        e.g.  100000x1000000 LVS_NSLAB 21 25 29 33
+       python tools/knob_sweep.py QxN SET A=1,B=2 A=3 ...   (several knobs per setting)"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -33,11 +34,15 @@ def kernel_ms(reps=4):
     return min(ts), sorted(ts)[len(ts) // 2]
 
 fl = 2.0 * nq * nb * d
+touched = set()
 for rnd in range(2):  # two interleaved rounds: box drift shows up as a difference between them
     for v in ["default"] + vals:
-        if v == "default":
-            os.environ.pop(knob, None)
-        else:
-            os.environ[knob] = v
+        for name in touched:
+            os.environ.pop(name, None)
+        if v != "default":
+            for kv in (v.split(",") if knob == "SET" else [f"{knob}={v}"]):
+                name, val = kv.split("=")
+                os.environ[name] = val
+                touched.add(name)
         mn, med = kernel_ms()
-        print(f"{knob}={v:8s} min {mn:8.2f} ms  med {med:8.2f} ms  {fl / (mn * 1e-3) / 1e12:7.1f} TFLOP/s", flush=True)
+        print(f"{sys.argv[1]} {knob}={v:34s} min {mn:8.2f} ms  med {med:8.2f} ms  {fl / (mn * 1e-3) / 1e12:7.1f} TFLOP/s", flush=True)

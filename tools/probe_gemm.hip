@@ -672,6 +672,197 @@ void run_pp(const char* name, const _Float16* xb, const _Float16* xq, float* out
     fflush(stdout);
 }
 
+
+// ---- query operand straight from global memory: the B fragments (queries, shared by only WM = 2 waves) are loaded one
+// K-step ahead with global_load_dwordx4 into registers (the natural row-major layout already gives lane l the 16 bytes
+// row l % 32, k-chunk l / 32 of a 32x32x16 fragment), so only the corpus goes through LDS: 16 instead of 24 fragment
+// reads per wave and K-step, 32 KB instead of 64 KB staged per K-step, and room for a ring of STAGES 32 KB stages
+// (STAGES = 3: the top-of-step wait is vmcnt(4), the staging loads get more than a full K-step to land).
+// Register sets of the B fragments alternate between two K-steps (loop unrolled by two), 64 VGPRs in all.
+__device__ inline void gload16(half8& dst, const void* p) {
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(p) : "memory");
+}
+template <int N>
+__device__ inline void vm_wait8(half8 (&b)[4][2]) {
+    asm volatile("s_waitcnt vmcnt(%8)" : "+v"(b[0][0]), "+v"(b[0][1]), "+v"(b[1][0]), "+v"(b[1][1]), "+v"(b[2][0]), "+v"(b[2][1]),
+                 "+v"(b[3][0]), "+v"(b[3][1]) : "n"(N) : "memory");
+}
+template <int N>
+__device__ inline void lds_wait1(half8& a) {
+    asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(a) : "n"(N));
+}
+template <int DEPTH, int STAGES, int BFIRST, int STAMP, int SWZ = 0>
+__global__ __launch_bounds__(512, 2) void gemm_bdirect(const _Float16* __restrict__ xb, const _Float16* __restrict__ xq,
+                                                        float* __restrict__ out, int ntiles, int nk, long long ld,
+                                                        unsigned long long* __restrict__ stamps, int qmod) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int MI = 4, NI = 2, WN = 4, NW = 8, NF = 16;
+    constexpr int CSTAGE = BC * ROWB;                      // 32 KB: corpus rows only
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int xcd = blockIdx.x & 7, li = (blockIdx.x >> 3) & 31, gen = blockIdx.x >> 8;
+    const int gq = qmod;
+    const int qt = (gen * 8 + xcd) * gq + (li % gq);
+    const int slab = li / gq, nsl = 32 / gq;
+    const int tile0 = slab * (ntiles / nsl);
+    const long long q0 = (long long)qt * BQ;
+    unsigned loff[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int row = wave * 32 + i * 8 + (lane >> 3);
+        int col = ((lane & 7) ^ ((row >> 1) & 7)) * 8;
+        loff[i] = (unsigned)((row * ld + col) * 2);
+    }
+    int foff[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk)
+        foff[kk] = (lane & 31) * ROWB + ((((kk * 2) + (lane >> 5)) ^ (((lane & 31) >> 1) & 7)) << 4);
+    const int a_base = wm * MI * 32 * ROWB;
+    const char* bq[2];
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+        bq[ni] = SWZ ? (const char*)xq + (((long long)qt * 4 + wn) * nk * 8 + ni) * 1024 + lane * 16   // [64-query block][ks][kk][ni][lane]
+                     : (const char*)(xq + (q0 + wn * 64 + ni * 32 + (lane & 31)) * ld + (lane >> 5) * 8);
+    f32x16 acc[MI][NI];
+    float best[NI];
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) best[ni] = -1e30f;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+    const int T = ntiles * nk;
+    auto stage = [&](int t, int i) {                       // one staging load (8 corpus rows of this wave) of K-step t
+        int tc = t < T ? t : T - 1;
+        int ti = tc / nk, ks = tc - ti * nk; ti = (ti + tile0) % ntiles;
+        glds16((const char*)xb + (long long)ti * BC * ld * 2 + loff[i] + ks * BK * 2,
+               smem + (t % STAGES) * CSTAGE + (wave * 32 + i * 8) * ROWB);
+    };
+    auto bload = [&](int t, int j, half8 (&B)[4][2]) {    // fragment j = kk * 2 + ni of K-step t
+        int tc = t < T ? t : T - 1;
+        int ks = tc % nk;
+        if (SWZ) gload16(B[j >> 1][j & 1], bq[j & 1] + ks * 8192 + (j >> 1) * 2048);
+        else gload16(B[j >> 1][j & 1], bq[j & 1] + ks * BK * 2 + (j >> 1) * 32);
+    };
+    half8 B0[4][2], B1[4][2];
+    // prologue: stages 0 .. STAGES-2 and the fragments of K-step 0; the LAST group issued is the one the steady-state
+    // wait may leave outstanding (4 staging loads if the B loads come first in a K-step, else the 8 B loads)
+    if (BFIRST) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) bload(0, j, B0);
+        for (int s = 0; s + 1 < STAGES; ++s)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) stage(s, i);
+    } else {
+        for (int s = 0; s + 1 < STAGES; ++s)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) stage(s, i);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) bload(0, j, B0);
+    }
+    int ksin = 0;
+    auto kstep = [&](int t, half8 (&Bc)[4][2], half8 (&Bn)[4][2]) {
+        unsigned long long ta = 0, tb = 0;
+        const bool st = STAMP && stamps && t >= 200 && t < 264 && (blockIdx.x == 0 || blockIdx.x == 1001);
+        if (st) ta = __builtin_amdgcn_s_memtime();
+        // stage t and Bc complete: with B loads first only the youngest staging group (stage t + STAGES - 2) may be in flight
+        if (BFIRST && STAGES > 2) vm_wait8<4>(Bc); else vm_wait8<0>(Bc);
+        __builtin_amdgcn_s_barrier();                      // raw: __syncthreads() would add its own vmcnt(0)
+        if (st) tb = __builtin_amdgcn_s_memtime();
+        const unsigned sbu = (unsigned)(unsigned long long)(smem + (t % STAGES) * CSTAGE);
+        half8 Af[DEPTH + 1];
+        if (wave >= NW / 2) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int f = 0; f < DEPTH; ++f) lds_read16(Af[f], sbu + a_base + (f % MI) * 32 * ROWB + foff[f / MI]);
+        static_for<NF>([&](auto fc) {
+            constexpr int f = decltype(fc)::value;
+            constexpr int kk = f / MI, mi = f % MI;
+            if constexpr (f + DEPTH < NF) {
+                constexpr int f2 = f + DEPTH;
+                lds_read16(Af[f2 % (DEPTH + 1)], sbu + a_base + (f2 % MI) * 32 * ROWB + foff[f2 / MI]);
+            }
+            if constexpr (BFIRST) {
+                if constexpr (f < 8) bload(t + 1, f, Bn);
+                else if constexpr (f < 12) stage(t + STAGES - 1, f - 8);
+            } else {
+                if constexpr (f < 4) stage(t + STAGES - 1, f);
+                else if constexpr (f < 12) bload(t + 1, f - 4, Bn);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            constexpr int last = f + DEPTH < NF ? f + DEPTH : NF - 1;   // youngest A read issued so far
+            lds_wait1<last - f>(Af[f % (DEPTH + 1)]);
+            acc[mi][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Af[f % (DEPTH + 1)], Bc[kk][0], acc[mi][0], 0, 0, 0);
+            acc[mi][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Af[f % (DEPTH + 1)], Bc[kk][1], acc[mi][1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        if (st) {
+            unsigned long long tc = __builtin_amdgcn_s_memtime();
+            if (lane == 0) {
+                unsigned long long* o = stamps + (((blockIdx.x ? 1 : 0) * NW + wave) * 64 + (t - 200)) * 3;
+                o[0] = ta; o[1] = tb; o[2] = tc;
+            }
+        }
+        if (++ksin < nk) return;
+        ksin = 0;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) best[ni] = fmaxf(best[ni], acc[mi][ni][r]);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+            }
+    };
+    for (int t = 0; t < T; t += 2) {                       // T = ntiles * nk is even
+        kstep(t, B0, B1);
+        kstep(t + 1, B1, B0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) out[((long long)blockIdx.x * NW + wave) * 64 * NI + ni * 64 + lane] = best[ni];
+}
+
+template <int DEPTH, int STAGES, int BFIRST, int SWZ = 0>
+void run_bdirect(const char* name, const _Float16* xb, const _Float16* xq, float* out, int nqt, int ntiles, int nk, long long ld,
+                 const float* ref_out, unsigned long long* stamps) {
+    auto k = gemm_bdirect<DEPTH, STAGES, BFIRST, 1, SWZ>;
+    CHECK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, STAGES * BC * ROWB));
+    const size_t nst = 2 * 8 * 64 * 3;
+    CHECK(hipMemset(stamps, 0, nst * 8));
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0));
+    CHECK(hipEventCreate(&e1));
+    float best = 1e30f;
+    for (int it = 0; it < 4; ++it) {
+        CHECK(hipEventRecord(e0));
+        hipLaunchKernelGGL(k, dim3(nqt), dim3(512), STAGES * BC * ROWB, 0, xb, xq, out, ntiles, nk, ld, stamps, 32);
+        CHECK(hipEventRecord(e1));
+        CHECK(hipEventSynchronize(e1));
+        float ms;
+        CHECK(hipEventElapsedTime(&ms, e0, e1));
+        if (it > 0 && ms < best) best = ms;
+    }
+    double fl = 2.0 * nqt * 256.0 * ntiles * 256.0 * nk * 64.0;
+    size_t n = (size_t)nqt * 8 * 128, bad = 0;
+    std::vector<float> a(n), b(n);
+    CHECK(hipMemcpy(a.data(), out, n * 4, hipMemcpyDeviceToHost));
+    CHECK(hipMemcpy(b.data(), ref_out, n * 4, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < n; ++i) bad += a[i] != b[i];
+    std::vector<unsigned long long> hs(nst);
+    CHECK(hipMemcpy(hs.data(), stamps, nst * 8, hipMemcpyDeviceToHost));
+    double per = (double)(hs[63 * 3] - hs[0]) / 63.0;
+    double wt = 0, mf = 0;
+    for (int i = 0; i < 64; ++i) { wt += (double)(hs[i * 3 + 1] - hs[i * 3]); mf += (double)(hs[i * 3 + 2] - hs[i * 3 + 1]); }
+    double us_per_kstep = best * 1e3 / ((double)ntiles * nk * (nqt / 256.0));
+    printf("%-44s %8.2f ms  %7.1f TFLOP/s   cyc/K-step %.0f (wait %.0f, mfma %.0f)  clock %.2f GHz   mismatches: %zu\n", name, best,
+           fl / (best * 1e-3) / 1e12, per, wt / 64, mf / 64, per / us_per_kstep / 1e3, bad);
+    fflush(stdout);
+}
+
 template <int WM, int WN, int MI, int NI, int WPE, int DEPTH, int BPOS, int PRIO, int SPREAD, int ABL = 0>
 void run(const char* name, const _Float16* xb, const _Float16* xq, float* out, int nqt, int ntiles, int nk, long long ld, unsigned long long* stamps = nullptr, int qmod = 32) {
     auto k = gemm_probe<WM, WN, MI, NI, WPE, DEPTH, BPOS, PRIO, SPREAD, 0, ABL>;
@@ -743,19 +934,47 @@ int main(int argc, char** argv) {
     CHECK(hipMalloc(&ref, (size_t)nqt * 16 * 64 * 4 * 4));
     CHECK(hipMalloc(&ids, 1024));
     CHECK(hipMemcpy(xb, h.data(), nb * d * 2, hipMemcpyHostToDevice));
+    CHECK(hipMemset(xq, 0, nq * d * 2));
     CHECK(hipMemcpy(xq, h.data() + 12345 * d, nq * d * 2 - 12345 * d * 2, hipMemcpyHostToDevice));
     unsigned long long* stamps;
     CHECK(hipMalloc(&stamps, 2 * 8 * 64 * 3 * 8));
+    // fragment-major copy of the queries: [64-query block][K-step][kk][ni][lane] x 8 halfs = what lane `lane` feeds the MFMA
+    _Float16* xqs;
+    CHECK(hipMalloc(&xqs, nq * d * 2));
+    {
+        const _Float16* hq = h.data() + (size_t)12345 * d;
+        std::vector<_Float16> sw((size_t)nq * d);
+        const size_t nrows_ok = (h.size() / d) - 12345;     // rows of hq that exist on the host (the rest was never copied)
+        for (long long blk = 0; blk < nq / 64; ++blk)
+            for (int ks = 0; ks < nk; ++ks)
+                for (int kk = 0; kk < 4; ++kk)
+                    for (int ni = 0; ni < 2; ++ni)
+                        for (int l = 0; l < 64; ++l) {
+                            size_t row = (size_t)blk * 64 + ni * 32 + (l & 31);
+                            _Float16* dst = &sw[((((size_t)blk * nk + ks) * 4 + kk) * 2 + ni) * 512 + (size_t)l * 8];
+                            for (int e = 0; e < 8; ++e)
+                                dst[e] = row < nrows_ok ? hq[row * d + ks * 64 + kk * 16 + (l >> 5) * 8 + e] : (_Float16)0;
+                        }
+        CHECK(hipMemcpy(xqs, sw.data(), (size_t)nq * d * 2, hipMemcpyHostToDevice));
+    }
     for (int rep = 0; rep < 2; ++rep) {
         if (rep == 1) {  // the same binaries on zero-filled operands: no data-dependent switching power
             CHECK(hipMemset(xb, 0, nb * d * 2));
             CHECK(hipMemset(xq, 0, nq * d * 2));
+            CHECK(hipMemset(xqs, 0, nq * d * 2));
             printf("---- zero-filled operands ----\n");
         }
         clock_of<3, 0>("product loop (stamped)", xb, xq, ref, nqt, ntiles, nk, d, stamps);
         run<2, 4, 4, 2, 2, 2, 2, 1, 3>("8 waves 128x64, asm waits (product loop)", xb, xq, ref, nqt, ntiles, nk, d);
-        run_agpr("4 waves 128x128, accumulators in AGPRs (asm)", xb, xq, out, nqt, ntiles, nk, d, ref, ids);
-        run_pp<8>("ping-pong, staging inside MFMA 0/1", xb, xq, out, nqt, ntiles, nk, d, ref, ids);
+        if (argc > 1) {   // the earlier probes (tuning log): AGPR accumulators, ping-pong
+            run_agpr("4 waves 128x128, accumulators in AGPRs (asm)", xb, xq, out, nqt, ntiles, nk, d, ref, ids);
+            run_pp<8>("ping-pong, staging inside MFMA 0/1", xb, xq, out, nqt, ntiles, nk, d, ref, ids);
+        }
+        run_bdirect<2, 3, 1>("queries from global (row-major), 3 stages", xb, xq, out, nqt, ntiles, nk, d, ref, stamps);
+        run_bdirect<2, 2, 0, 1>("queries fragment-major from global, 2 stages", xb, xqs, out, nqt, ntiles, nk, d, ref, stamps);
+        run_bdirect<2, 3, 1, 1>("same, 3 stages, vmcnt(4)", xb, xqs, out, nqt, ntiles, nk, d, ref, stamps);
+        run_bdirect<2, 4, 1, 1>("same, 4 stages, vmcnt(4)", xb, xqs, out, nqt, ntiles, nk, d, ref, stamps);
+        run_bdirect<3, 3, 1, 1>("same, 3 stages, A depth 3", xb, xqs, out, nqt, ntiles, nk, d, ref, stamps);
 
     }
     unsigned hid[8];
