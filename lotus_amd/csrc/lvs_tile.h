@@ -97,8 +97,54 @@ __host__ __device__ inline bool lvs_tile_group_slot(int nqt, int nslab, int gq, 
     }
     return qt < nqt && slab < nslab;
 }
-int lvs_tile_grid_blocks(int nqt, int nslab, int gq, int lead_slabs);
-int lvs_tile_xcd_rounds(int nqt, int nslab, int gq, int lead_slabs);
+// block b of the launch -> (group, slot).  Whole generations: XCD b % 8 runs slot (b / 8) % 32 of group (b / 256) * 8 + b % 8;
+// the last total % 8 groups are dealt slot by slot across all XCDs (slot r on XCD r % 8).  false: b is past the last group.
+__host__ __device__ inline bool lvs_tile_block_slot(const LvsTileGroups& gr, int b, int& g, int& r) {
+    if (b < gr.full * 32) {
+        const int x = b & 7, j = b >> 3;
+        g = (j >> 5) * 8 + x;
+        r = j & 31;
+        return true;
+    }
+    const int f = b - gr.full * 32;
+    g = gr.full + (f >> 5);
+    r = f & 31;
+    return g < gr.total;
+}
+inline int lvs_tile_grid_blocks(int nqt, int nslab, int gq, int lead_slabs) {
+    return lvs_tile_groups(nqt, nslab, gq, lead_slabs).total * 32;
+}
+
+// Items (valid (query tile, slab) pairs) each XCD receives under item_of_block's deal, in units of rounds: an XCD runs 32
+// items at a time (one workgroup per CU), so it needs ceil(items / 32) item-times.  Returns the largest over the 8 XCDs.
+inline int lvs_tile_xcd_rounds(int nqt, int nslab, int gq, int lead_slabs) {
+    const LvsTileGroups gr = lvs_tile_groups(nqt, nslab, gq, lead_slabs);
+    long long items[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const int gs = 32 / gq;
+    for (int g = 0; g < gr.full; ++g) {
+        int vq, vs;
+        if (g < gr.n0) {
+            vq = nqt - (g % gr.nqg32) * 32;
+            vq = vq < 0 ? 0 : (vq > 32 ? 32 : vq);
+            vs = 1;
+        } else {
+            const int h = g - gr.n0;
+            vq = nqt - (h % gr.nqg) * gq;
+            vq = vq < 0 ? 0 : (vq > gq ? gq : vq);
+            vs = nslab - lead_slabs - (h / gr.nqg) * gs;
+            vs = vs < 0 ? 0 : (vs > gs ? gs : vs);
+        }
+        items[g & 7] += (long long)vq * vs;
+    }
+    for (int g = gr.full; g < gr.total; ++g)
+        for (int r = 0; r < 32; ++r) {
+            int qt, slab;
+            if (lvs_tile_group_slot(nqt, nslab, gq, lead_slabs, gr, g, r, qt, slab)) ++items[r & 7];
+        }
+    long long worst = 0;
+    for (int x = 0; x < 8; ++x) worst = items[x] > worst ? items[x] : worst;
+    return (int)((worst + 31) / 32);
+}
 hipError_t lvs_tile_launch(int mode, const LvsTileArgs& a, hipStream_t stream);
 
 // ---- small-batch streaming kernel (lvs_stream.hip): nq <= 64 (1..2 blocks of 32 queries per corpus pass), k <= LVS_KPASS.

@@ -142,16 +142,7 @@ __device__ __forceinline__ void first_hit(const f32x16& v, float tf, bool qv, fl
 __device__ inline bool item_of_block(const LvsTileArgs& a, int b, int& qt, int& slab) {
     const LvsTileGroups gr = lvs_tile_groups(a.nqt, a.nslab, a.gq, a.lead_slabs);
     int g, r;
-    if (b < gr.full * 32) {
-        const int x = b & 7, j = b >> 3;
-        g = (j >> 5) * 8 + x;
-        r = j & 31;
-    } else {
-        const int f = b - gr.full * 32;
-        g = gr.full + (f >> 5);
-        r = f & 31;
-        if (g >= gr.total) return false;
-    }
+    if (!lvs_tile_block_slot(gr, b, g, r)) return false;
     return lvs_tile_group_slot(a.nqt, a.nslab, a.gq, a.lead_slabs, gr, g, r, qt, slab);
 }
 
@@ -792,39 +783,4 @@ hipError_t lvs_tile_launch(int mode, const LvsTileArgs& a, hipStream_t stream) {
     if (mode == LVS_MODE_SCORES) return launch_one<LVS_MODE_SCORES, 4>(a, stream);
     if (mode == LVS_MODE_COLLECT) return launch_one<LVS_MODE_COLLECT, 4>(a, stream);
     return launch_one<LVS_MODE_TOPK, 4>(a, stream);
-}
-
-int lvs_tile_grid_blocks(int nqt, int nslab, int gq, int lead_slabs) {
-    return lvs_tile_groups(nqt, nslab, gq, lead_slabs).total * 32;
-}
-
-// Items (valid (query tile, slab) pairs) each XCD receives under item_of_block's deal, in units of rounds: an XCD runs 32
-// items at a time (one workgroup per CU), so it needs ceil(items / 32) item-times.  Returns the largest over the 8 XCDs.
-int lvs_tile_xcd_rounds(int nqt, int nslab, int gq, int lead_slabs) {
-    const LvsTileGroups gr = lvs_tile_groups(nqt, nslab, gq, lead_slabs);
-    long long items[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    const int gs = 32 / gq;
-    for (int g = 0; g < gr.full; ++g) {
-        int vq, vs;
-        if (g < gr.n0) {
-            vq = nqt - (g % gr.nqg32) * 32;
-            vq = vq < 0 ? 0 : (vq > 32 ? 32 : vq);
-            vs = 1;
-        } else {
-            const int h = g - gr.n0;
-            vq = nqt - (h % gr.nqg) * gq;
-            vq = vq < 0 ? 0 : (vq > gq ? gq : vq);
-            vs = nslab - lead_slabs - (h / gr.nqg) * gs;
-            vs = vs < 0 ? 0 : (vs > gs ? gs : vs);
-        }
-        items[g & 7] += (long long)vq * vs;
-    }
-    for (int g = gr.full; g < gr.total; ++g)
-        for (int r = 0; r < 32; ++r) {
-            int qt, slab;
-            if (lvs_tile_group_slot(nqt, nslab, gq, lead_slabs, gr, g, r, qt, slab)) ++items[r & 7];
-        }
-    long long worst = 0;
-    for (int x = 0; x < 8; ++x) worst = items[x] > worst ? items[x] : worst;
-    return (int)((worst + 31) / 32);
 }

@@ -130,3 +130,15 @@ def test_merge_keys_accepts_long_lists_from_many_parts():
     lib = _capi.load()
     assert lib.lvs_merge_keys(None, 8, 0, 1000, None, None) == 0          # nq == 0: nothing to do, accepted
     assert lib.lvs_merge_keys(None, 8, 5, 4000, None, None) == _capi.EINVAL  # NULL buffers / k beyond LVS_MAX_K
+
+
+def test_block_to_item_deal_covers_every_item_once(tmp_path):
+    """The tile kernel's blockIdx -> (query tile, slab) deal (lvs_tile.h): every item exactly once for 1 716 combinations of
+    query tiles x slabs x XCD group shape, and the planner's per-XCD round count equals a direct count (host code only)."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = tmp_path / "mapping_check"
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    subprocess.run([hipcc, "-O1", "-std=c++17", "--offload-arch=gfx950", "-w",
+                    os.path.join(root, "tests", "native", "mapping_check.cpp"), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout
+    assert out.startswith("ok "), out
