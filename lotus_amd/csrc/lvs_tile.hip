@@ -253,7 +253,7 @@ __global__ __launch_bounds__(512, 2) void lvs_tile_kernel(const LvsTileArgs a) {
         ubk[ni] = ~0ull;
         qnv[ni] = 0.f;
         if (qvalid[ni]) {
-            if (a.ub) ubk[ni] = a.ub[(q0 + qloc[ni]) * a.ub_stride];
+            if (MI != 4 && a.ub) ubk[ni] = a.ub[(q0 + qloc[ni]) * a.ub_stride];  // multi-pass (k > 56) runs on the 128-query geometry only
             if (a.metric == LVS_METRIC_L2) qnv[ni] = a.qn[q0 + qloc[ni]];
             if (MODE == LVS_MODE_COLLECT) {  // ubk = LOWER bound key here, tauf = its score
                 ubk[ni] = a.thr_key[q0 + qloc[ni]];
@@ -305,6 +305,7 @@ __global__ __launch_bounds__(512, 2) void lvs_tile_kernel(const LvsTileArgs a) {
     // static priority raise evens it out (+2 % on the bare loop, tools/probe_gemm.hip)
     if (wave >= 4) __builtin_amdgcn_s_setprio(1);
     uint32_t gpre[2] = {0u, 0u};  // cross-workgroup thresholds, prefetched one K-step before the tile epilogue
+    uint32_t lpre[2] = {0u, 0u};  // own lists' thresholds, read in the same K-step (nobody inserts between epilogues)
 #ifdef LVS_COUNT_EVENTS
     unsigned n_visit = 0, n_ins = 0, n_wt = 0;  // tuning aid, see a.dbg
     unsigned long long c_filter = 0, c_visit = 0, c_ins = 0;  // cycles (s_memtime) in the filter / visit loop / insertions
@@ -320,10 +321,13 @@ __global__ __launch_bounds__(512, 2) void lvs_tile_kernel(const LvsTileArgs a) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
         }
-        if (MODE == LVS_MODE_TOPK && ks_in_tile == nk - 1 && !a.no_share) {
+        if (MODE == LVS_MODE_TOPK && ks_in_tile == nk - 1) {
 #pragma unroll
-            for (int ni = 0; ni < 2; ++ni)
-                if (qvalid[ni]) gpre[ni] = a.gtau[q0 + qloc[ni]];
+            for (int ni = 0; ni < 2; ++ni) {
+                if (qvalid[ni] && !a.no_share) gpre[ni] = a.gtau[q0 + qloc[ni]];
+                // every wave passed this K-step's barrier, so every insertion of the previous epilogue is in the list
+                lpre[ni] = ((const uint32_t*)(lists + qloc[ni] * KCAP + k - 1))[1];  // score half of the k-th key
+            }
         }
         // ---- one K-step, software-pipelined by hand: 4*MI steps f = kk*MI + mi of {A-fragment read two steps ahead,
         // one staging load of the NEXT K-step (first 4 + QG steps), 2 MFMAs}; B fragments double-buffered per kk ----
@@ -523,12 +527,9 @@ __global__ __launch_bounds__(512, 2) void lvs_tile_kernel(const LvsTileArgs a) {
                 gord[ni] = g > gord[ni] ? g : gord[ni];
                 tauf[ni] = fmaxf(tauf[ni], tau_float(gord[ni]));
             }
-        // own lists' current thresholds (they may have risen since this lane last looked)
+        // own lists' thresholds (they may have risen since this lane last looked: the wave sharing these queries inserts too)
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni) {
-            uint32_t lo = (uint32_t)(lists[qloc[ni] * KCAP + k - 1] >> 32);
-            tauf[ni] = fmaxf(tauf[ni], tau_float(lo));
-        }
+        for (int ni = 0; ni < 2; ++ni) tauf[ni] = fmaxf(tauf[ni], tau_float(lpre[ni]));
         // fast filter: which of the wave's 2*MI 32x32 blocks hold a score that may enter some query's list?
         uint32_t hitmask = 0;  // wave-uniform, bit tsel = mi * 2 + ni
 #ifdef LVS_COUNT_EVENTS
@@ -572,7 +573,7 @@ __global__ __launch_bounds__(512, 2) void lvs_tile_kernel(const LvsTileArgs a) {
                     // slot reads right behind it.  LDS executes a wave's DS instructions in order, so when the
                     // swap succeeded the reads saw the list under the lock; otherwise everything is retried.
                     u64* UL = lists + uq * KCAP;
-                    u64 mine = 0, prev = ~0ull;
+                    u64 mine = 0;
                     for (;;) {
                         uint32_t seen = 0;
                         if (lane == 0) {
@@ -580,12 +581,14 @@ __global__ __launch_bounds__(512, 2) void lvs_tile_kernel(const LvsTileArgs a) {
                                                                  __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                         }
                         asm volatile("" ::: "memory");  // keep the reads behind the swap in program order
-                        if (lane < k) {
-                            mine = UL[lane];
-                            if (lane > 0) prev = UL[lane - 1];
-                        }
+                        if (lane < k) mine = UL[lane];
                         if (__builtin_amdgcn_readfirstlane(seen) == 0) break;  // lock word was 0: we own it
                     }
+                    // slot j - 1 is the neighbouring lane's `mine` (DPP wave_shr:1; lane 0 keeps the "old" operand = all
+                    // ones: nothing is above slot 0) - one LDS read per insertion less
+                    const uint32_t plo = __builtin_amdgcn_update_dpp(0xFFFFFFFFu, (uint32_t)mine, 0x138, 0xF, 0xF, false);
+                    const uint32_t phi = __builtin_amdgcn_update_dpp(0xFFFFFFFFu, (uint32_t)(mine >> 32), 0x138, 0xF, 0xF, false);
+                    const u64 prev = ((u64)phi << 32) | plo;
                     u64 newv = 0;
                     if (lane < k) newv = mine > ukey ? mine : (prev > ukey ? ukey : prev);
                     __builtin_amdgcn_wave_barrier();
@@ -638,7 +641,7 @@ __global__ __launch_bounds__(512, 2) void lvs_tile_kernel(const LvsTileArgs a) {
                 ++n_visit;
 #endif
                 const int q = ni ? qloc[1] : qloc[0];
-                const u64 ubq = ni ? ubk[1] : ubk[0];
+                const u64 ubq = MI == 4 ? ~0ull : (ni ? ubk[1] : ubk[0]);  // no upper bound on the 256-query geometry (one pass)
                 const uint32_t go = ni ? gord[1] : gord[0];
                 const long long rbase = trow0 + lrow_base + mi * 32;
                 // the visiting wave is on the workgroup's critical path (the next barrier waits for it): let its
@@ -776,7 +779,7 @@ hipError_t lvs_tile_launch(int mode, const LvsTileArgs& a, hipStream_t stream) {
         if (mode != LVS_MODE_TOPK || a.k > LVS3_KCAP) return hipErrorInvalidValue;
         return launch_one<LVS_MODE_TOPK, 2>(a, stream);
     }
-    if (a.bq != LVS2_BQ || a.k > LVS2_KCAP) return hipErrorInvalidValue;
+    if (a.bq != LVS2_BQ || a.k > LVS2_KCAP || a.ub) return hipErrorInvalidValue;
     if (mode == LVS_MODE_TOP1) return launch_one<LVS_MODE_TOP1, 4>(a, stream);
     if (mode == LVS_MODE_TOP2) return a.out_second ? launch_one<LVS_MODE_TOP2, 4>(a, stream) : hipErrorInvalidValue;
     if (mode == LVS_MODE_RANGE) return launch_one<LVS_MODE_RANGE, 4>(a, stream);
