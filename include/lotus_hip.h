@@ -186,6 +186,8 @@ int32_t lvs_kmeans_update_centroids(const float* sums, const float* counts, int3
 /* HOST helpers (plain host pointers), bit-exact with faiss: rand_perm(n, seed) = Fisher-Yates on std::mt19937
  * (training subsample and initial centroids), and split_clusters (empty-cluster re-seeding, RNG seed 1234). */
 int32_t lvs_rand_perm_host(int64_t n, int64_t seed, int64_t* out_perm);
+/* out_prefix[0..m) = the first m entries of lvs_rand_perm_host(n, seed) in O(m) time and memory (m <= n). */
+int32_t lvs_rand_perm_prefix_host(int64_t n, int64_t seed, int64_t m, int64_t* out_prefix);
 int32_t lvs_kmeans_split_clusters_host(int32_t d, int32_t k, int64_t n, float* hassign, float* centroids,
                                        int32_t* out_nsplit);
 

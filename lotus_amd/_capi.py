@@ -56,6 +56,7 @@ SIGNATURES = {
     "lvs_kmeans_accumulate": (_i32, [_vp, _i64, _i32, _i32, _vp, _i32, _vp, _vp, _vp, _i64, _vp]),
     "lvs_kmeans_update_centroids": (_i32, [_vp, _vp, _i32, _i32, _vp, _vp]),
     "lvs_rand_perm_host": (_i32, [_i64, _i64, _vp]),
+    "lvs_rand_perm_prefix_host": (_i32, [_i64, _i64, _i64, _vp]),
     "lvs_kmeans_split_clusters_host": (_i32, [_i32, _i32, _i64, _vp, _vp, ctypes.POINTER(_i32)]),
     "lvs_timing_enable": (_i32, [_i32]),
     "lvs_timing_read": (_i32, [ctypes.POINTER(_dbl), ctypes.POINTER(_i64)]),

@@ -365,7 +365,12 @@ class HipBackend:
         k, d = int(centroids.shape[0]), int(centroids.shape[1])
         self._c("lvs_kmeans_update_centroids", _ptr(sums), _ptr(counts), k, d, _ptr(centroids), self._stream())
 
-    def rand_perm(self, n: int, seed: int) -> np.ndarray:
+    def rand_perm(self, n: int, seed: int, m: int | None = None) -> np.ndarray:
+        """faiss ``rand_perm(n, seed)``; with ``m`` only its first ``m`` entries (O(m) host time instead of O(n))."""
+        if m is not None and m < n:
+            out = np.empty(m, np.int64)
+            _capi.check(self.lib.lvs_rand_perm_prefix_host(n, seed, m, out.ctypes.data), "lvs_rand_perm_prefix_host")
+            return out
         out = np.empty(n, np.int64)
         _capi.check(self.lib.lvs_rand_perm_host(n, seed, out.ctypes.data), "lvs_rand_perm_host")
         return out

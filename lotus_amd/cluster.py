@@ -96,7 +96,7 @@ def kmeans(x, k: int, niter: int = 20, seed: int = 1234, max_points_per_centroid
 
     train_ids = np.arange(n, dtype=np.int64)
     if max_points_per_centroid is not None and n > k * max_points_per_centroid:
-        train_ids = be.rand_perm(n, seed)[: k * max_points_per_centroid]
+        train_ids = be.rand_perm(n, seed, k * max_points_per_centroid)  # only the prefix is used: O(k * 256) host work
     nt = len(train_ids)
     obj = np.zeros(niter, np.float32)
     nsplit = np.zeros(niter, np.int64)
@@ -117,7 +117,7 @@ def kmeans(x, k: int, niter: int = 20, seed: int = 1234, max_points_per_centroid
     if nt == k:
         centroids = centroid_rows(train_ids)  # faiss: "n == k: copy points as centroids and stop"
     else:
-        perm = be.rand_perm(nt, seed + 1)
+        perm = be.rand_perm(nt, seed + 1, k)
         centroids = centroid_rows(train_ids[perm[:k]])
         # the training rows this rank works on
         if sharded_rows:

@@ -9,6 +9,7 @@
 //     empty-cluster re-seeding exactly as faiss.
 #include <cstring>
 #include <random>
+#include <vector>
 
 #include <rocprim/rocprim.hpp>
 
@@ -216,6 +217,35 @@ extern "C" int32_t lvs_rand_perm_host(int64_t n, int64_t seed, int64_t* out_perm
         int64_t t = out_perm[i];
         out_perm[i] = out_perm[i2];
         out_perm[i2] = t;
+    }
+    return LVS_OK;
+}
+
+// The first m entries of the same permutation in O(m): step i of the forward Fisher-Yates fixes perm[i] and touches only
+// perm[i] and perm[i2 >= i], and both callers (training subsample, initial centroids) read a prefix - of 10 M entries at
+// configs[4]'s size, where the full permutation costs 0.17 s of host time per call.  Positions >= m live in a hash map.
+extern "C" int32_t lvs_rand_perm_prefix_host(int64_t n, int64_t seed, int64_t m, int64_t* out_prefix) {
+    LVS_REQUIRE(n >= 0 && m >= 0 && m <= n && (m == 0 || out_prefix), "bad arguments");
+    std::mt19937 mt((unsigned)seed);
+    for (int64_t i = 0; i < m; ++i) out_prefix[i] = i;
+    // open-addressing table (linear probing), at most one new entry per step: <= 25 % full
+    size_t cap = 16;
+    while (cap < (size_t)m * 4) cap <<= 1;
+    std::vector<int64_t> keys(cap, -1), vals(cap);  // position >= m -> its current content (absent: the position itself)
+    for (int64_t i = 0; i < m && i + 1 < n; ++i) {
+        const int64_t i2 = i + (int64_t)(mt() % (uint32_t)(n - i));
+        if (i2 < m) {
+            const int64_t t = out_prefix[i];
+            out_prefix[i] = out_prefix[i2];
+            out_prefix[i2] = t;
+        } else {
+            size_t h = ((uint64_t)i2 * 0x9E3779B97F4A7C15ull) >> 20 & (cap - 1);
+            while (keys[h] != -1 && keys[h] != i2) h = (h + 1) & (cap - 1);
+            const int64_t v = keys[h] == i2 ? vals[h] : i2;
+            keys[h] = i2;
+            vals[h] = out_prefix[i];
+            out_prefix[i] = v;
+        }
     }
     return LVS_OK;
 }

@@ -143,8 +143,9 @@ class OracleBackend:
         counts = np.bincount(a[ok], minlength=k).astype(np.float32)
         return torch.from_numpy(sums), torch.from_numpy(counts)
 
-    def rand_perm(self, n, seed):
-        return oracle.rand_perm(n, seed)
+    def rand_perm(self, n, seed, m=None):
+        perm = oracle.rand_perm(n, seed)
+        return perm if m is None else perm[:m]
 
     def split_clusters(self, n, hassign, centroids):
         from oracle.kmeans import _split_clusters

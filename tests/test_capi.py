@@ -142,3 +142,22 @@ def test_block_to_item_deal_covers_every_item_once(tmp_path):
                     os.path.join(root, "tests", "native", "mapping_check.cpp"), "-o", str(exe)], check=True)
     out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout
     assert out.startswith("ok "), out
+
+
+def test_permutation_prefix_equals_the_full_permutation():
+    """lvs_rand_perm_prefix_host (O(m)) against lvs_rand_perm_host and the oracle's restatement of faiss rand_perm."""
+    import numpy as np
+
+    import oracle
+
+    lib = _capi.load()
+    for n, m, seed in [(1, 1, 3), (2, 1, 0), (10, 10, 1234), (1000, 7, 1), (1000, 999, 2), (100003, 256, 1234),
+                       (100003, 4096, 1235), (300000, 262144, 99), (5, 0, 1)]:
+        full = np.empty(n, np.int64)
+        assert lib.lvs_rand_perm_host(n, seed, full.ctypes.data) == 0
+        pre = np.full(max(m, 1), -1, np.int64)
+        assert lib.lvs_rand_perm_prefix_host(n, seed, m, pre.ctypes.data) == 0
+        assert np.array_equal(pre[:m], full[:m]), (n, m, seed)
+        if n <= 100003:
+            assert np.array_equal(full, oracle.rand_perm(n, seed))
+    assert lib.lvs_rand_perm_prefix_host(10, 1, 11, None) == _capi.EINVAL
