@@ -13,7 +13,9 @@ fixture for this path (every test in ``.github/tests/rm_tests.py`` needs a
 downloaded embedding model and asserts matched strings only), and faiss itself
 cannot be run here.  The oracle is therefore pinned only by (i) hand-checkable
 cases, (ii) agreement between its two independent implementations (numpy/BLAS
-and plain C) and (iii) an exact float64 brute-force cross-check.
+and plain C), (iii) an exact float64 brute-force cross-check and (iv) agreement
+with scikit-learn's brute-force neighbours / Lloyd k-means (an independent
+library, not the reference's dependency; tests/test_oracle.py).
 
 Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline``
 leg may import this package; nothing under ``lotus_amd/`` does.

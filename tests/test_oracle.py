@@ -187,3 +187,48 @@ def test_cpu_timing_comparators_agree_with_the_oracle(which):
     D, I, _ = fn(xb[:5], xq[:3], 8)
     assert (I[:, 5:] == -1).all() and (np.sort(I[:, :5], axis=1) == np.arange(5)).all()
     assert np.all(D[:, 5:] == -np.float32(3.4028234663852886e38))
+
+
+def test_search_agrees_with_an_independent_brute_force_library():
+    """faiss is not installable here, so the oracle cannot be run against it ("parity unpinned").  As an
+    independent third-party check, scikit-learn's brute-force NearestNeighbors (its own pairwise-distance code) must
+    return the same neighbours wherever adjacent distances are not within rounding of each other, for L2 and for
+    inner product on unit vectors (cosine distance = 1 - ip)."""
+    from sklearn.neighbors import NearestNeighbors
+
+    for seed, (n, d, nq, k) in enumerate([(2000, 48, 64, 10), (5000, 96, 40, 5), (1500, 384, 32, 7)]):
+        xb = synth.corpus(n, d, seed=seed + 10)
+        xq, _ = synth.queries(xb, nq, seed=seed + 20)
+        for metric, sk_metric in ((oracle.METRIC_L2, "euclidean"), (oracle.METRIC_INNER_PRODUCT, "cosine")):
+            D, I = oracle.flat_search(xb, xq, k, metric)
+            nn = NearestNeighbors(n_neighbors=k, algorithm="brute", metric=sk_metric).fit(xb.astype(np.float64))
+            sd, si = nn.kneighbors(xq.astype(np.float64))
+            ref = sd ** 2 if metric == oracle.METRIC_L2 else 1.0 - sd
+            assert np.allclose(D, ref, atol=2e-5), (metric, np.abs(D - ref).max())
+            # ids may only differ inside groups of near-equal scores
+            for q in range(nq):
+                if np.array_equal(I[q], si[q]):
+                    continue
+                bad = I[q] != si[q]
+                gaps = np.abs(ref[q][bad][:, None] - ref[q][None, :])
+                assert (np.sort(gaps, axis=1)[:, 1] < 4e-5).all(), (metric, q, I[q], si[q])
+
+
+def test_lloyd_iterations_agree_with_an_independent_kmeans():
+    """Same initial centroids (x[rand_perm(n, seed + 1)[:k]]), same number of Lloyd iterations, no subsampling and no empty
+    cluster: scikit-learn's KMeans (its own E/M steps) must end at the oracle's centroids and assignment."""
+    from sklearn.cluster import KMeans
+
+    rng = np.random.default_rng(5)
+    k, d, n, niter = 8, 16, 1600, 12
+    centers = rng.standard_normal((k, d)).astype(np.float32) * 3
+    x = (centers[rng.integers(0, k, n)] + rng.standard_normal((n, d)).astype(np.float32)).astype(np.float32)
+    res = oracle.kmeans_faiss(x, k, niter=niter, seed=1234)
+    assert res.nsplit.sum() == 0
+    init = x[oracle.rand_perm(n, 1235)[:k]]
+    sk = KMeans(n_clusters=k, init=init.astype(np.float64), n_init=1, max_iter=niter, tol=0.0, algorithm="lloyd")
+    sk.fit(x.astype(np.float64))
+    assert np.allclose(res.centroids, sk.cluster_centers_, atol=1e-4), np.abs(res.centroids - sk.cluster_centers_).max()
+    assert (res.assign == sk.labels_).mean() > 0.999  # points within rounding of a cell border may differ
+    # faiss's objective of the LAST iteration is measured against the centroids BEFORE that iteration's update
+    assert res.obj[-1] >= sk.inertia_ * (1 - 1e-5)
