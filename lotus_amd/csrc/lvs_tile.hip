@@ -495,7 +495,8 @@ __global__ __launch_bounds__(512, 2) void lvs_tile_kernel(const LvsTileArgs a) {
                                 s = -fmaxf((qnv[ni] + bn4[e]) - 2.0f * s, 0.f);
                             else
                                 s = row < a.nb ? s : -INFINITY;
-                            if constexpr (MODE == LVS_MODE_TOP2) secv[ni] = fmaxf(secv[ni], fminf(s, bestv[ni]));
+                            // runner-up = median of (s, best, runner-up) while runner-up <= best holds: one v_med3_f32
+                            if constexpr (MODE == LVS_MODE_TOP2) secv[ni] = __builtin_amdgcn_fmed3f(s, bestv[ni], secv[ni]);
                             if (s > bestv[ni]) {
                                 bestv[ni] = s;
                                 besti[ni] = (uint32_t)row;

@@ -10,7 +10,7 @@ _capi.load(os.path.abspath(sys.argv[1]))
 from lotus_amd.backend import HipBackend
 
 be = HipBackend("cuda:0")
-d, k = 768, 10
+d, k = 768, int(os.environ.get("AB_K", "10"))
 for shape in sys.argv[2:]:
     nq, nb = (int(v) for v in shape.split("x"))
     g = torch.Generator(device=be.device); g.manual_seed(1)
