@@ -537,11 +537,13 @@ __global__ __launch_bounds__(512, 2) void lvs_tile_kernel(const LvsTileArgs a) {
         ++n_wt;
         const unsigned long long tm0 = __builtin_amdgcn_s_memtime();
 #endif
+        // lanes without a query compare against +inf: no exec-masked branch around each block's max16
+        const float tfe[2] = {qvalid[0] ? tauf[0] : INFINITY, qvalid[1] ? tauf[1] : INFINITY};
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
             for (int ni = 0; ni < 2; ++ni)
-                if (wave_any(qvalid[ni] && (max16(acc[mi][ni]) >= tauf[ni]))) hitmask |= 1u << (mi * 2 + ni);
+                if (wave_any(max16(acc[mi][ni]) >= tfe[ni])) hitmask |= 1u << (mi * 2 + ni);
 #ifdef LVS_TUNING
         if (a.debug_hot == 2) hitmask = 0;  // tuning aid: skip the slow path (results are wrong, timing only)
 #endif
