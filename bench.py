@@ -18,7 +18,7 @@ Extra objects:
   "recall_at_k" / "id_mismatches_outside_near_ties" / "max_abs_score_err": the GPU result of the LAST timed step checked
                   against the CPU oracle (oracle/flat.py) on a query sample - at every N, rank 0;
   "legs"          (N=1) short secondary measurements in the same process: BASELINE configs[1] (10k x 1M), the literal
-                  single-query sem_search (HBM-bound streaming kernel), the 8-GPU shard shape (100k x 125k) and T_call
+                  single-query sem_search (HBM-bound streaming kernel), the per-GPU shard shapes at N = 8 / 4 / 2 (100k x 125k / 250k / 500k) and T_call
                   (`HipVS.__call__` host ndarray -> host (D, I), PCIe included), the per-GPU shape of the query split and the fp32-embeddings
                   call (plain vs certified one-pass) - each with kernel ms and roofline fraction.
 """
@@ -306,6 +306,15 @@ def secondary_legs(np, torch, be, _capi, xb, xq, corpus, queries, k):
                                  "achieved_tflops": fl / (kms * 1e-3) / 1e12,
                                  "frac": fl / (kms * 1e-3) / 1e12 / PEAK_FP16_MFMA_TFLOPS,
                                  "node_queries_per_s_if_8_gpus": queries.n / (kms * 1e-3)}
+    # the per-GPU shapes of the same join at N = 2 and N = 4 (500 k / 250 k rows of the corpus per GPU)
+    for rows, ng in ((500_000, 2), (250_000, 4)):
+        sh = be.slice_rows(corpus, 0, min(corpus.n, rows))
+        kms, wms = kernel_leg(sh, queries, 3)
+        fl = 2.0 * queries.n * sh.n * d
+        legs[f"shard_100k_x_{rows // 1000}k"] = {"kernel_ms": kms, "ms_per_call": wms, "bound": "mfma",
+                                                  "achieved_tflops": fl / (kms * 1e-3) / 1e12,
+                                                  "frac": fl / (kms * 1e-3) / 1e12 / PEAK_FP16_MFMA_TFLOPS,
+                                                  f"node_queries_per_s_if_{ng}_gpus": queries.n / (kms * 1e-3)}
     # ... and what each of 8 GPUs does under the QUERY split of the same join (HipVS(shard="queries"): corpus replicated,
     # 12 500 queries per GPU against all 1 M rows, finished lists all-gathered, no merge)
     q8 = be.slice_rows(queries, 0, min(queries.n, 12_500))

@@ -228,10 +228,12 @@ extern "C" int32_t lvs_rand_perm_prefix_host(int64_t n, int64_t seed, int64_t m,
     LVS_REQUIRE(n >= 0 && m >= 0 && m <= n && (m == 0 || out_prefix), "bad arguments");
     std::mt19937 mt((unsigned)seed);
     for (int64_t i = 0; i < m; ++i) out_prefix[i] = i;
-    // open-addressing table (linear probing), at most one new entry per step: <= 25 % full
+    // open-addressing table (linear probing), key and value side by side (one cache line per probe), at most one new
+    // entry per step: <= 50 % full.  position >= m -> its current content (absent: the position itself)
+    struct Slot { int64_t key, val; };
     size_t cap = 16;
-    while (cap < (size_t)m * 4) cap <<= 1;
-    std::vector<int64_t> keys(cap, -1), vals(cap);  // position >= m -> its current content (absent: the position itself)
+    while (cap < (size_t)m * 2) cap <<= 1;
+    std::vector<Slot> tab(cap, Slot{-1, 0});
     for (int64_t i = 0; i < m && i + 1 < n; ++i) {
         const int64_t i2 = i + (int64_t)(mt() % (uint32_t)(n - i));
         if (i2 < m) {
@@ -239,11 +241,11 @@ extern "C" int32_t lvs_rand_perm_prefix_host(int64_t n, int64_t seed, int64_t m,
             out_prefix[i] = out_prefix[i2];
             out_prefix[i2] = t;
         } else {
-            size_t h = ((uint64_t)i2 * 0x9E3779B97F4A7C15ull) >> 20 & (cap - 1);
-            while (keys[h] != -1 && keys[h] != i2) h = (h + 1) & (cap - 1);
-            const int64_t v = keys[h] == i2 ? vals[h] : i2;
-            keys[h] = i2;
-            vals[h] = out_prefix[i];
+            size_t h = (size_t)(((uint64_t)i2 * 0x9E3779B97F4A7C15ull) >> 20) & (cap - 1);
+            while (tab[h].key != -1 && tab[h].key != i2) h = (h + 1) & (cap - 1);
+            const int64_t v = tab[h].key == i2 ? tab[h].val : i2;
+            tab[h].key = i2;
+            tab[h].val = out_prefix[i];
             out_prefix[i] = v;
         }
     }
