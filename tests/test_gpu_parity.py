@@ -487,3 +487,23 @@ def test_one_pass_certificate_refuses_rows_that_differ_below_fp16_resolution(hip
     Dw, Iw = (t.cpu().numpy() for t in be.keys_to_result(be.search_keys(cb, cq, 10, IP, one_pass=False), IP))
     assert stats["uncertified"] >= 60
     assert np.array_equal(Ig, Iw) and np.abs(Dg - Dw).max() <= 1e-6
+
+
+@pytest.mark.parametrize("nq,nb,d", [(100_000, 125_000, 32), (50_000, 250_000, 64), (16_384, 700_000, 32)])
+def test_planner_shapes_sampled_parity(hip_backend, nq, nb, d):
+    """Launch shapes that take the planner's 8 x 4 L2 groups with a leading slab and a remainder of groups dealt across
+    all XCDs (lvs_tile.h): the whole launch runs on the GPU, five queries of EVERY 256-query tile are checked against
+    the oracle (a query's list depends on every (tile, slab) item of its tile)."""
+    k = 10
+    xb = synth.corpus(nb, d, seed=11)
+    xq, _ = synth.queries(xb, nq, seed=12)
+    D, I, _ = _run(hip_backend, xb, xq, k, F16, IP)
+    rng = np.random.default_rng(nq)
+    tiles = np.arange(0, nq, 256)
+    pick = np.unique(np.minimum(tiles[:, None] + rng.integers(0, 256, (len(tiles), 5)), nq - 1).reshape(-1))
+    pick = np.union1d(pick, [0, nq - 1])
+    Dr, Ir = oracle.flat_search(_stored(xb, F16), _stored(xq[pick], F16), k, IP)
+    err, hard, recall = synth.compare_topk(Dr, Ir, D[pick], I[pick], atol=1e-5)
+    assert err <= 1e-5 and hard == 0 and recall >= 0.9999, (err, hard, recall)
+    assert (I[pick] == Ir).mean() > 0.999
+    assert (I >= 0).all() and (np.diff(D, axis=1) <= 0).all()  # every list full and best-first
