@@ -157,7 +157,9 @@ int32_t lvs_range_join(const void* xb, int32_t xb_pack, int64_t nb, const void* 
  * out_second [nq] = runner-up score in the "larger = better" domain (-inf when there is none).  The true score of a
  * (query, row) pair differs from this one by at most 2 |q| |lo_row| + 2 |lo_q| |row| (Cauchy-Schwarz), so a winner whose
  * margin exceeds twice that bound is the exact winner; lvs_margin_select lists the queries that are NOT certified so
- * that only those go through the exact (2-3 pass) search again. */
+ * that only those go through the exact (2-3 pass) search again.  The kernel carries a score's position in the low six
+ * mantissa bits of u = q.y (inner product) or u = 2 q.y - |y|^2 (L2) while it runs, so the reported winner and runner-up
+ * scores are each perturbed by less than 2^-17 |u|: add 2^-16 max|u| to the margin bound. */
 int64_t lvs_nearest_hi_workspace_bytes(int64_t nq, int64_t nb, int32_t d);
 int32_t lvs_nearest_hi(const void* xb, int32_t xb_pack, int64_t nb, const void* xq, int32_t xq_pack, int64_t nq, int32_t d,
                        int32_t metric, const float* xb_norms_sq, const float* xq_norms_sq, int64_t id_offset,

@@ -233,6 +233,10 @@ class HipBackend:
         c = 2.0 if metric == _capi.METRIC_IP else 4.0
         scale = c * (per_q + 8e-6 * R)          # + fp32 accumulation noise of both searches, relative to |q| |row|
         slack = 1e-6 * (1.0 + R * R)
+        # lvs_nearest_hi tags every running score in its low six mantissa bits (relative perturbation < 2^-17 of
+        # u = q.y or 2 q.y - |y|^2, for the winner and for the runner-up)
+        scale += 2.0 ** -16 * (1.0 if metric == _capi.METRIC_IP else 2.0) * R
+        slack += 0.0 if metric == _capi.METRIC_IP else 2.0 ** -16 * R * R
         sec = torch.empty((nq,), dtype=torch.float32, device=self.device)
         need = int(self.lib.lvs_nearest_hi_workspace_bytes(nq, corpus.n, corpus.d))
         ws = self._workspace(need)

@@ -269,6 +269,10 @@ __global__ __launch_bounds__(512, 2) void lvs_tile_kernel(const LvsTileArgs a) {
     float bestv[2] = {-INFINITY, -INFINITY};
     float secv[2] = {-INFINITY, -INFINITY};  // TOP2: second-best score seen by this lane
     uint32_t besti[2] = {0xFFFFFFFFu, 0xFFFFFFFFu};
+    // TOP2 under L2: running best / runner-up of u = 2 q.y - |y|^2 (the query norm and the clamp are applied once, at the
+    // end), the position of a score inside the tile (6 bits) carried in the low mantissa bits; first row of the winner's tile
+    float bestu[2] = {-INFINITY, -INFINITY}, secu[2] = {-INFINITY, -INFINITY};
+    uint32_t bestrow0[2] = {0u, 0u};
 
     f32x16 acc[MI][2];
 #pragma unroll
@@ -463,14 +467,46 @@ __global__ __launch_bounds__(512, 2) void lvs_tile_kernel(const LvsTileArgs a) {
             // ---- k == 1: per-lane running best, no lists.  Rows are visited in increasing order, so a strict
             // "greater" keeps the lowest row among equal scores (the oracle's tie rule).  TOP2 also keeps the
             // second-best SCORE (an equal score counts: margin 0), from which the caller certifies the winner. ----
-            if (a.metric == LVS_METRIC_L2) {
+            if (MODE == LVS_MODE_TOP2 || a.metric == LVS_METRIC_L2) {
                 __syncthreads();
                 if (tid < BC) {
                     const long long row = trow0 + tid;
-                    bnl[tid] = row < a.nb ? a.bn[row] : INFINITY;  // rows past the end never win
+                    // |y|^2 (0 under inner product); rows past the end never win (TOP2 tags scores in their mantissa: a
+                    // finite sentinel, not inf)
+                    const float nv = a.metric == LVS_METRIC_L2 ? a.bn[row < a.nb ? row : a.nb - 1] : 0.f;
+                    bnl[tid] = row < a.nb ? nv : (MODE == LVS_MODE_TOP2 ? 3.0e38f : INFINITY);
                 }
                 __syncthreads();
             }
+            if constexpr (MODE == LVS_MODE_TOP2) {
+                // Certified nearest row (lvs_nearest_hi): the caller only needs a winner, its margin over the runner-up
+                // and an approximate score, so each score costs four VALU operations instead of eight: u = c s - |y|^2
+                // (one fma; c = 2 under L2, where |q|^2 and the clamp at 0 do not change the order and are applied at the
+                // end; c = 1 and |y|^2 := 0 under inner product), the score's position in the tile (mi * 16 + r, an inline
+                // constant) replaces its low six mantissa bits (a relative perturbation < 2^-17 that the caller's margin
+                // bound includes), best = max, runner-up = med3.
+                const float before0 = bestu[0], before1 = bestu[1];
+                const float cs = a.metric == LVS_METRIC_L2 ? 2.0f : 1.0f;
+                static_for<MI>([&](auto mic) {
+                    constexpr int mi = decltype(mic)::value;
+#pragma unroll
+                    for (int r4 = 0; r4 < 4; ++r4) {
+                        const f32x4 bn4 = *(const f32x4*)(bnl + lrow_base + mi * 32 + 8 * r4);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+#pragma unroll
+                            for (int ni = 0; ni < 2; ++ni) {
+                                const float u = __builtin_fmaf(cs, acc[mi][ni][r4 * 4 + e], -bn4[e]);
+                                const float up = __uint_as_float((__float_as_uint(u) & 0xFFFFFFC0u) | (uint32_t)(mi * 16 + r4 * 4 + e));
+                                secu[ni] = __builtin_amdgcn_fmed3f(up, bestu[ni], secu[ni]);
+                                bestu[ni] = fmaxf(bestu[ni], up);
+                            }
+                        __builtin_amdgcn_sched_barrier(0);  // keep the norm reads next to their uses (register footprint)
+                    }
+                });
+                if (bestu[0] != before0) bestrow0[0] = (uint32_t)trow0;
+                if (bestu[1] != before1) bestrow0[1] = (uint32_t)trow0;
+            } else
 #pragma unroll 1
             for (int mi = 0; mi < MI; ++mi) {  // rolled: keeps the epilogue's register footprint small
                 f32x16 t0, t1;
@@ -495,8 +531,6 @@ __global__ __launch_bounds__(512, 2) void lvs_tile_kernel(const LvsTileArgs a) {
                                 s = -fmaxf((qnv[ni] + bn4[e]) - 2.0f * s, 0.f);
                             else
                                 s = row < a.nb ? s : -INFINITY;
-                            // runner-up = median of (s, best, runner-up) while runner-up <= best holds: one v_med3_f32
-                            if constexpr (MODE == LVS_MODE_TOP2) secv[ni] = __builtin_amdgcn_fmed3f(s, bestv[ni], secv[ni]);
                             if (s > bestv[ni]) {
                                 bestv[ni] = s;
                                 besti[ni] = (uint32_t)row;
@@ -721,6 +755,20 @@ __global__ __launch_bounds__(512, 2) void lvs_tile_kernel(const LvsTileArgs a) {
 #endif
     if constexpr (MODE == LVS_MODE_RANGE || MODE == LVS_MODE_SCORES || MODE == LVS_MODE_COLLECT) return;
     if constexpr (MODE == LVS_MODE_TOP1 || MODE == LVS_MODE_TOP2) {
+        if constexpr (MODE == LVS_MODE_TOP2) {
+            // unpack the tagged running values: row from (tile, tag); score = -max(|q|^2 - u, 0) under L2 ("better" domain)
+            const bool l2 = a.metric == LVS_METRIC_L2;
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) {
+                if (bestu[ni] > -1.0e38f) {
+                    const uint32_t tag = __float_as_uint(bestu[ni]) & 63u;
+                    const uint32_t r = tag & 15u;
+                    besti[ni] = bestrow0[ni] + (uint32_t)(wm * (MI * 32) + 4 * (lane >> 5)) + (tag >> 4) * 32u + (r & 3u) + 8u * (r >> 2);
+                    bestv[ni] = l2 ? -fmaxf(qnv[ni] - bestu[ni], 0.f) : bestu[ni];
+                    secv[ni] = secu[ni] > -1.0e38f ? (l2 ? -fmaxf(qnv[ni] - secu[ni], 0.f) : secu[ni]) : -INFINITY;
+                }
+            }
+        }
         // four lanes (l, l+32 of waves wm = 0, 1) hold partial winners of each query: combine by key
         __syncthreads();
 #pragma unroll

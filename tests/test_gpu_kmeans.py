@@ -192,3 +192,35 @@ def test_kmeans_uses_the_certified_assignment(hip_backend):
     ref = oracle.kmeans_faiss(_stored(x, SPLIT), 24, niter=6)
     assert (r.assign == ref.assign).mean() >= 1 - 1e-4
     assert np.allclose(r.obj, ref.obj, rtol=1e-5)
+
+
+def test_certified_nearest_zero_scores_ragged_rows_and_every_tile_position(hip_backend):
+    """The one-pass kernel tags a score's position (tile row) in its low mantissa bits: a unique winner whose score is
+    exactly 0 (the tag then lives in a denormal), corpus sizes that leave the last tile ragged, and winners planted at
+    every position of a 256-row tile must all decode to the right row."""
+    be = hip_backend
+    d = 64
+    # (1) inner product: one-hot rows; query orthogonal to row 5 (score exactly 0), negative against every other row
+    nb = 300
+    xb = -np.eye(nb, d, dtype=np.float32) - 0.5          # every row strongly negative against an all-ones query ...
+    xb[5] = 0.0
+    xb[5, 0], xb[5, 1] = 1.0, -1.0                        # ... except row 5: 1 - 1 = 0 exactly
+    xq = np.ones((3, d), np.float32)
+    cb, cq = be.pack(xb, SPLIT), be.pack(xq, SPLIT)
+    _, Ig = be.keys_to_result(be.nearest(cb, cq, IP), IP)
+    _, Iw = be.keys_to_result(be.search_keys(cb, cq, 1, IP), IP)
+    assert np.array_equal(Ig.cpu().numpy(), Iw.cpu().numpy()) and (Ig.cpu().numpy() == 5).all()
+    # (2) L2: the query IS a corpus row (distance 0 -> u = |y|^2 exactly), ragged sizes, winners at every tile position
+    for nb in (1, 255, 257, 1000, 1283):
+        rng = np.random.default_rng(nb)
+        xb = (synth.corpus(nb, d, seed=nb) * 1.7).astype(np.float16).astype(np.float32)
+        pick = np.arange(nb) if nb <= 300 else np.concatenate([np.arange(256), np.arange(nb - 300, nb)])
+        xq = xb[pick].copy()
+        cb, cq = be.pack(xb, SPLIT), be.pack(xq, SPLIT)
+        for metric in (L2, IP) if nb > 1 else (L2,):
+            stats = {}
+            Dg, Ig = (t.cpu().numpy() for t in be.keys_to_result(be.nearest(cb, cq, metric, stats=stats), metric))
+            Dw, Iw = (t.cpu().numpy() for t in be.keys_to_result(be.search_keys(cb, cq, 1, metric), metric))
+            assert np.array_equal(Ig, Iw), (nb, metric)
+            if metric == L2:
+                assert np.array_equal(Ig[:, 0], pick) and np.abs(Dg).max() <= 1e-5
