@@ -467,7 +467,7 @@ __global__ __launch_bounds__(512, 2) void lvs_tile_kernel(const LvsTileArgs a) {
             // ---- k == 1: per-lane running best, no lists.  Rows are visited in increasing order, so a strict
             // "greater" keeps the lowest row among equal scores (the oracle's tie rule).  TOP2 also keeps the
             // second-best SCORE (an equal score counts: margin 0), from which the caller certifies the winner. ----
-            if (MODE == LVS_MODE_TOP2 || a.metric == LVS_METRIC_L2) {
+            {
                 __syncthreads();
                 if (tid < BC) {
                     const long long row = trow0 + tid;
@@ -506,38 +506,30 @@ __global__ __launch_bounds__(512, 2) void lvs_tile_kernel(const LvsTileArgs a) {
                 });
                 if (bestu[0] != before0) bestrow0[0] = (uint32_t)trow0;
                 if (bestu[1] != before1) bestrow0[1] = (uint32_t)trow0;
-            } else
-#pragma unroll 1
-            for (int mi = 0; mi < MI; ++mi) {  // rolled: keeps the epilogue's register footprint small
-                f32x16 t0, t1;
-                switch (mi) {
-                    case 0: t0 = acc[0][0]; t1 = acc[0][1]; break;
-                    case 1: t0 = acc[1][0]; t1 = acc[1][1]; break;
-                    case 2: t0 = acc[2][0]; t1 = acc[2][1]; break;
-                    default: t0 = acc[3][0]; t1 = acc[3][1]; break;
-                }
+            } else {
+                // TOP1 (exact): the same one-fma order value u = c s - |y|^2; a strict "greater" keeps the lowest row among
+                // equal values, the position inside the tile is selected as an inline constant, the winner's tile is
+                // noted once per tile - four VALU operations per score instead of eight.
+                const float before0 = bestu[0], before1 = bestu[1];
+                const float cs = a.metric == LVS_METRIC_L2 ? 2.0f : 1.0f;
+                static_for<MI>([&](auto mic) {
+                    constexpr int mi = decltype(mic)::value;
 #pragma unroll
-                for (int r4 = 0; r4 < 4; ++r4) {
-                    const int lrow = lrow_base + mi * 32 + 8 * r4;
-                    f32x4 bn4 = {0.f, 0.f, 0.f, 0.f};
-                    if (a.metric == LVS_METRIC_L2) bn4 = *(const f32x4*)(bnl + lrow);
+                    for (int r4 = 0; r4 < 4; ++r4) {
+                        const f32x4 bn4 = *(const f32x4*)(bnl + lrow_base + mi * 32 + 8 * r4);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const long long row = trow0 + lrow + e;
+                        for (int e = 0; e < 4; ++e)
 #pragma unroll
-                        for (int ni = 0; ni < 2; ++ni) {
-                            float s = ni ? t1[r4 * 4 + e] : t0[r4 * 4 + e];
-                            if (a.metric == LVS_METRIC_L2)
-                                s = -fmaxf((qnv[ni] + bn4[e]) - 2.0f * s, 0.f);
-                            else
-                                s = row < a.nb ? s : -INFINITY;
-                            if (s > bestv[ni]) {
-                                bestv[ni] = s;
-                                besti[ni] = (uint32_t)row;
+                            for (int ni = 0; ni < 2; ++ni) {
+                                const float u = __builtin_fmaf(cs, acc[mi][ni][r4 * 4 + e], -bn4[e]);
+                                besti[ni] = u > bestu[ni] ? (uint32_t)(mi * 16 + r4 * 4 + e) : besti[ni];
+                                bestu[ni] = fmaxf(bestu[ni], u);
                             }
-                        }
+                        __builtin_amdgcn_sched_barrier(0);  // keep the norm reads next to their uses (register footprint)
                     }
-                }
+                });
+                if (bestu[0] != before0) bestrow0[0] = (uint32_t)trow0;
+                if (bestu[1] != before1) bestrow0[1] = (uint32_t)trow0;
             }
         } else {
         if (a.metric == LVS_METRIC_L2) {
@@ -755,13 +747,14 @@ __global__ __launch_bounds__(512, 2) void lvs_tile_kernel(const LvsTileArgs a) {
 #endif
     if constexpr (MODE == LVS_MODE_RANGE || MODE == LVS_MODE_SCORES || MODE == LVS_MODE_COLLECT) return;
     if constexpr (MODE == LVS_MODE_TOP1 || MODE == LVS_MODE_TOP2) {
-        if constexpr (MODE == LVS_MODE_TOP2) {
-            // unpack the tagged running values: row from (tile, tag); score = -max(|q|^2 - u, 0) under L2 ("better" domain)
+        {
+            // row from (tile, position: TOP2 carries it in the value's low mantissa bits, TOP1 beside it); score =
+            // -max(|q|^2 - u, 0) under L2 ("better" domain)
             const bool l2 = a.metric == LVS_METRIC_L2;
 #pragma unroll
             for (int ni = 0; ni < 2; ++ni) {
                 if (bestu[ni] > -1.0e38f) {
-                    const uint32_t tag = __float_as_uint(bestu[ni]) & 63u;
+                    const uint32_t tag = MODE == LVS_MODE_TOP2 ? (__float_as_uint(bestu[ni]) & 63u) : besti[ni];
                     const uint32_t r = tag & 15u;
                     besti[ni] = bestrow0[ni] + (uint32_t)(wm * (MI * 32) + 4 * (lane >> 5)) + (tag >> 4) * 32u + (r & 3u) + 8u * (r >> 2);
                     bestv[ni] = l2 ? -fmaxf(qnv[ni] - bestu[ni], 0.f) : bestu[ni];
