@@ -11,6 +11,7 @@ from lotus_amd.backend import HipBackend
 
 be = HipBackend("cuda:0")
 d, k = 768, int(os.environ.get("AB_K", "10"))
+METRIC = int(os.environ.get("AB_METRIC", "0"))  # 0 inner product, 1 L2
 for shape in sys.argv[2:]:
     nq, nb = (int(v) for v in shape.split("x"))
     g = torch.Generator(device=be.device); g.manual_seed(1)
@@ -21,12 +22,12 @@ for shape in sys.argv[2:]:
     cb, cq = be.pack(xb, _capi.PACK_F16), be.pack(xq, _capi.PACK_F16)
     del xb, xq, u
     for _ in range(2):
-        be.search_keys(cb, cq, k, 0)
+        be.search_keys(cb, cq, k, METRIC)
     be.synchronize()
     ts = []
     for _ in range(5):
         be.timing_enable(True)
-        be.search_keys(cb, cq, k, 0)
+        be.search_keys(cb, cq, k, METRIC)
         be.synchronize()
         tot, cnt = be.timing_read()
         ts.append(tot / max(cnt, 1))
