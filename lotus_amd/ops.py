@@ -100,13 +100,19 @@ def sem_sim_join(df1: pd.DataFrame, df2: pd.DataFrame, left_on: str, right_on: s
         vs.load_index(col_index_dir)
     qv = queries if _is_vectors(queries) else rm.convert_query_to_query_vector(queries)
     right_index = np.asarray(df2.index)
-    out = vs(qv, K, ids=right_index.tolist())
+    # the reference hands a Python list over (sem_sim_join.py:132-134); HipVS takes the array as it is (a million-entry
+    # list costs ~50 ms to build and as much to turn back into an array)
+    native = hasattr(vs, "packed_rows") and right_index.dtype.kind in "iu"
+    out = vs(qv, K, ids=right_index if native else right_index.tolist())
     I = np.asarray(out.indices)
     D = np.asarray(out.distances)
     ok = I >= 0  # ids come from df2.index, so every non-padded hit is a right row
     qpos = np.broadcast_to(np.arange(I.shape[0])[:, None], I.shape)[ok]
     right_ids = I[ok]
     left_ids = np.asarray(df1.index)[qpos]
+    fast = _joined_frame(df1, df2, qpos, left_ids, right_ids, D[ok], lsuffix, rsuffix, score_suffix, keep_index)
+    if fast is not None:
+        return fast
     d1 = df1.copy()
     d2 = df2.copy()
     d1["_left_id"] = d1.index
@@ -117,6 +123,47 @@ def sem_sim_join(df1: pd.DataFrame, df2: pd.DataFrame, left_on: str, right_on: s
     if not keep_index:
         joined.drop(columns=["_left_id", "_right_id"], inplace=True)
     return joined
+
+
+def _joined_frame(df1, df2, qpos, left_ids, right_ids, scores, lsuffix, rsuffix, score_suffix, keep_index):
+    """The frame the reference's two joins (``sem_sim_join.py:152-162``) produce, built from positional takes: rows =
+    one per (left row, match) in the order given, index = the left row's label, columns = df1's, ``_left_id``,
+    ``_right_id``, ``_scores``, df2's (overlapping names suffixed as ``DataFrame.join`` does).  Returns ``None`` when
+    the shortcut does not apply (duplicate labels, non-default column index) - the caller then runs the joins."""
+    if not (df1.index.is_unique and df2.index.is_unique and df1.columns.is_unique and df2.columns.is_unique):
+        return None
+    if df1.columns.nlevels != 1 or df2.columns.nlevels != 1 or df1.index.nlevels != 1 or df2.index.nlevels != 1:
+        return None
+    mid = ["_left_id", "_right_id", "_scores" + score_suffix]
+    lcols = list(df1.columns) + mid
+    rcols = list(df2.columns)
+    if any(c in df1.columns for c in mid) or "_right_id" in df2.columns:
+        return None  # the joins give these their own (version-dependent) treatment
+    overlap = set(lcols) & set(rcols)
+    if overlap and not lsuffix and not rsuffix:
+        return None  # DataFrame.join raises here; let it
+    rpos = df2.index.get_indexer(right_ids)
+    if (rpos < 0).any():
+        return None
+    index = df1.index.take(qpos)
+    left = df1.take(qpos)
+    right = df2.take(rpos)
+    left.index = index
+    right.index = index
+    ren_l = {c: f"{c}{lsuffix}" for c in overlap if c in df1.columns}
+    ren_r = {c: f"{c}{rsuffix}" for c in overlap}
+    if ren_l:
+        left = left.rename(columns=ren_l)
+    if ren_r:
+        right = right.rename(columns=ren_r)
+    mid_names = [f"{c}{lsuffix}" if c in overlap else c for c in mid]
+    middle = pd.DataFrame({mid_names[0]: np.asarray(left_ids), mid_names[1]: np.asarray(right_ids),
+                           mid_names[2]: scores}, index=index)
+    if len(set(left.columns) | set(middle.columns) | set(right.columns)) != left.shape[1] + 3 + right.shape[1]:
+        return None  # suffixed names collide with existing ones: leave it to pandas
+    if not keep_index:
+        middle = middle[[mid_names[2]]]
+    return pd.concat([left, middle, right], axis=1, copy=False)
 
 
 def sem_dedup(df: pd.DataFrame, col_name: str, threshold: float, rm=None, vs=None, shard: bool = False) -> pd.DataFrame:

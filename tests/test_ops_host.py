@@ -178,3 +178,58 @@ def test_ops_sem_cluster_by_standalone(tmp_path):
         assert len(set(out["cluster_id"][lab == b])) == 1  # every true blob maps to one cluster
     with pytest.raises(ValueError):
         ops.sem_cluster_by(df, "t", 500, vs=vs)
+
+
+def test_joined_frame_shortcut_equals_the_reference_joins():
+    """`ops._joined_frame` (positional takes) against the two `DataFrame.join`s of `sem_sim_join.py:152-162` on random
+    frames: label indexes, overlapping column names with every suffix combination, keep_index, empty results; where
+    pandas raises (overlap without suffix) the shortcut must step aside."""
+    import pandas as pd
+
+    from lotus_amd import ops
+
+    def ref(df1, df2, left_ids, right_ids, sc, lsuffix, rsuffix, score_suffix, keep_index):
+        d1, d2 = df1.copy(), df2.copy()
+        d1["_left_id"] = d1.index
+        d2["_right_id"] = d2.index
+        temp = pd.DataFrame({"_left_id": left_ids, "_right_id": right_ids, "_scores" + score_suffix: sc})
+        j = d1.join(temp.set_index("_left_id"), how="right", on="_left_id").join(
+            d2.set_index("_right_id"), how="left", on="_right_id", lsuffix=lsuffix, rsuffix=rsuffix)
+        if not keep_index:
+            j.drop(columns=["_left_id", "_right_id"], inplace=True)
+        return j
+
+    rng = np.random.default_rng(0)
+    n_equal = n_deferred = 0
+    for trial in range(120):
+        nl, nr = int(rng.integers(1, 8)), int(rng.integers(1, 9))
+        li = rng.permutation(50)[:nl] if trial % 2 else np.arange(nl)
+        ri = rng.permutation(60)[:nr] + 100 if trial % 3 else np.arange(nr)
+        if trial % 7 == 0:
+            li = np.array([f"L{i}" for i in li], dtype=object)
+        df1 = pd.DataFrame({"q": [f"l{i}" for i in range(nl)], "x": rng.random(nl), "n": rng.integers(0, 9, nl)}, index=li)
+        df2 = pd.DataFrame({"text": [f"r{i}" for i in range(nr)], "x": rng.integers(0, 9, nr).astype(np.int32)}, index=ri)
+        if trial % 5 == 0:
+            df2 = df2.drop(columns=["x"])
+        K = int(rng.integers(1, 4))
+        keep = rng.random(nl * K) > (1.0 if trial % 11 == 0 else 0.2)  # every 11th trial: an empty result
+        qpos = np.repeat(np.arange(nl), K)[keep]
+        left_ids = np.asarray(df1.index)[qpos]
+        right_ids = np.asarray(df2.index)[rng.integers(0, nr, len(qpos))]
+        sc = rng.random(len(qpos)).astype(np.float32)
+        for lsuf, rsuf, ssuf, keep_index in [("", "", "", False), ("_l", "_r", "", True), ("", "_r", "_s", False), ("_l", "", "", True)]:
+            got = ops._joined_frame(df1, df2, qpos, left_ids, right_ids, sc, lsuf, rsuf, ssuf, keep_index)
+            try:
+                want = ref(df1, df2, left_ids, right_ids, sc, lsuf, rsuf, ssuf, keep_index)
+            except ValueError:
+                assert got is None
+                n_deferred += 1
+                continue
+            if got is not None:
+                pd.testing.assert_frame_equal(got, want)
+                n_equal += 1
+    assert n_equal > 300 and n_deferred > 10
+    # duplicate labels: not the shortcut's business
+    dup = pd.DataFrame({"q": ["a", "b"]}, index=[1, 1])
+    assert ops._joined_frame(dup, pd.DataFrame({"t": ["x"]}), np.array([0]), np.array([1]), np.array([0]),
+                             np.array([0.5], np.float32), "", "", "", False) is None
