@@ -159,7 +159,7 @@ def kmeans(x, k: int, niter: int = 20, seed: int = 1234, max_points_per_centroid
     if final_assign:
         cpk = be.pack(centroids, cmode)
         if dist is None:
-            keys = be.nearest(cpk, packed, _capi.METRIC_L2)
+            keys = be.nearest(cpk, packed, _capi.METRIC_L2, exact_scores=False)  # ids only: no rescoring pass
             _, I = be.keys_to_result(keys, _capi.METRIC_L2)
             assign = I.reshape(-1).cpu().numpy().astype(np.int64)
         else:
@@ -171,7 +171,7 @@ def kmeans(x, k: int, niter: int = 20, seed: int = 1234, max_points_per_centroid
                 per = -(-n // world)
                 lo, hi = min(n, rank * per), min(n, (rank + 1) * per)
                 mine, pos = be.slice_rows(packed, lo, hi), np.arange(lo, hi, dtype=np.int64)
-            keys = be.nearest(cpk, mine, _capi.METRIC_L2)
+            keys = be.nearest(cpk, mine, _capi.METRIC_L2, exact_scores=False)
             _, I = be.keys_to_result(keys, _capi.METRIC_L2)
             # ranks may hold different numbers of rows: exchange (position, cluster id) pairs padded to the largest share
             cnt = torch.tensor([mine.n], dtype=torch.int64, device=I.device)
