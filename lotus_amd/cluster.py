@@ -161,7 +161,7 @@ def kmeans(x, k: int, niter: int = 20, seed: int = 1234, max_points_per_centroid
         if dist is None:
             keys = be.nearest(cpk, packed, _capi.METRIC_L2, exact_scores=False)  # ids only: no rescoring pass
             _, I = be.keys_to_result(keys, _capi.METRIC_L2)
-            assign = I.reshape(-1).cpu().numpy().astype(np.int64)
+            assign = np.asarray(I.reshape(-1).cpu().numpy(), dtype=np.int64)  # already int64: no copy
         else:
             import torch
 
