@@ -185,8 +185,14 @@ class HipBackend:
         R = float(corpus.norms.max().sqrt().item())
         nsplit = int(corpus.mode == _capi.PACK_SPLIT) + int(queries.mode == _capi.PACK_SPLIT)
         per_q = (2.0 ** -11) * R * nsplit + 8e-6 * R  # + fp32 accumulation noise, relative to |q| |row|
-        scale = per_q * (1.0 if metric == _capi.METRIC_IP else 2.0)
-        slack = 1e-6 * (1.0 + R * R)
+        # 2^-11 |x| bounds a component's lo part only in fp16's NORMAL range; below 6.1e-5 the rounding error of the hi
+        # half is absolute (<= 2^-25 per component), i.e. |lo_row| <= 2^-11 |row| + sqrt(d) 2^-25 - it matters for
+        # unnormalised embeddings of tiny magnitude
+        sub = (corpus.rows.shape[1] // (2 if corpus.mode == _capi.PACK_SPLIT else 1)) ** 0.5 * 2.0 ** -25
+        per_q += sub * int(corpus.mode == _capi.PACK_SPLIT)
+        c = 1.0 if metric == _capi.METRIC_IP else 2.0
+        scale = per_q * c
+        slack = 1e-6 * (1.0 + R * R) + c * sub * R * int(queries.mode == _capi.PACK_SPLIT)
         idx = torch.empty((nq,), dtype=torch.int64, device=self.device)
         cnt = torch.zeros((1,), dtype=torch.int64, device=self.device)
         self._c("lvs_certify_topk", _ptr(approx), _ptr(exact), _ptr(queries.norms), nq, k1, k, float(scale), float(slack),
@@ -233,6 +239,8 @@ class HipBackend:
         c = 2.0 if metric == _capi.METRIC_IP else 4.0
         scale = c * (per_q + 8e-6 * R)          # + fp32 accumulation noise of both searches, relative to |q| |row|
         slack = 1e-6 * (1.0 + R * R)
+        if queries.mode == _capi.PACK_SPLIT:    # |lo_q| <= 2^-11 |q| + sqrt(d) 2^-25 (fp16 subnormal range)
+            slack += c * (dpad ** 0.5) * 2.0 ** -25 * R
         # lvs_nearest_hi tags every running score in its low six mantissa bits (relative perturbation < 2^-17 of
         # u = q.y or 2 q.y - |y|^2, for the winner and for the runner-up)
         scale += 2.0 ** -16 * (1.0 if metric == _capi.METRIC_IP else 2.0) * R

@@ -16,6 +16,7 @@ from __future__ import annotations
 import json
 import os
 import pickle
+import struct
 
 import numpy as np
 
@@ -46,7 +47,10 @@ def write_dir(index_dir: str, embeddings, host: np.ndarray, metric: int, raw: bo
     if not raw:
         return
     tag = _dtype_tag(host.dtype)
-    meta = {"version": RAW_VERSION, "n": int(host.shape[0]), "d": int(host.shape[1]), "dtype": tag, "metric": int(metric)}
+    meta = {"version": RAW_VERSION, "n": int(host.shape[0]), "d": int(host.shape[1]), "dtype": tag, "metric": int(metric),
+            # the reference's two files as they are NOW: a writer that does not know about rows.json (stock LOTUS re-running
+            # sem_index into this directory) changes them, and the description below is then void (_described_rows)
+            "written_with": _file_stamps(index_dir)}
     if tag == "f32":
         meta["file"] = "index"  # mapped in place: the faiss file's code section is the float32 matrix
     else:
@@ -56,6 +60,27 @@ def write_dir(index_dir: str, embeddings, host: np.ndarray, metric: int, raw: bo
     with open(tmp, "w") as fp:
         json.dump(meta, fp)
     os.replace(tmp, meta_path)  # the description appears only once the rows are complete
+
+
+def _file_stamps(index_dir: str) -> dict:
+    out = {}
+    for name in ("index", "vecs"):
+        try:
+            st = os.stat(os.path.join(index_dir, name))
+            out[name] = [int(st.st_size), int(st.st_mtime_ns)]
+        except FileNotFoundError:
+            out[name] = [-1, -1]
+    return out
+
+
+def _mmap_flat_or_none(path: str):
+    """The code section of a faiss ``IndexFlat`` file as a memmap, or None when the file is something else -
+    ``FaissVS(factory_string="IVF.." / "HNSW..")`` (``faiss_vs.py:14,23,30``) writes a non-flat index, whose rows can only
+    come from the ``vecs`` pickle."""
+    try:
+        return faiss_io.mmap_index_flat(path)[0]
+    except (ValueError, struct.error, OSError):
+        return None
 
 
 def signature(index_dir: str):
@@ -74,14 +99,20 @@ def _described_rows(index_dir: str):
     meta_path = os.path.join(index_dir, "rows.json")
     if not os.path.exists(meta_path):
         return None
-    with open(meta_path) as fp:
-        meta = json.load(fp)
-    n, d, tag = int(meta["n"]), int(meta["d"]), meta["dtype"]
+    try:
+        with open(meta_path) as fp:
+            meta = json.load(fp)
+        n, d, tag = int(meta["n"]), int(meta["d"]), meta["dtype"]
+    except (OSError, ValueError, KeyError, TypeError):
+        return None
     if meta.get("version") != RAW_VERSION or tag not in _DTYPES:
         return None
+    stamps = meta.get("written_with")
+    if stamps is not None and stamps != _file_stamps(index_dir):
+        return None  # `index` / `vecs` were rewritten by a writer that left this description (and rows.f16|f64) behind
     if meta["file"] == "index":
-        rows, _ = faiss_io.mmap_index_flat(os.path.join(index_dir, "index"))
-        return rows if rows.shape == (n, d) else None
+        rows = _mmap_flat_or_none(os.path.join(index_dir, "index"))
+        return rows if (rows is not None and rows.shape == (n, d)) else None
     path = os.path.join(index_dir, meta["file"])
     if not os.path.exists(path) or os.path.getsize(path) != n * d * np.dtype(_DTYPES[tag]).itemsize:
         return None
@@ -110,6 +141,8 @@ def open_device_rows(index_dir: str):
         return rows, "mmap"
     idx = os.path.join(index_dir, "index")
     if os.path.exists(idx):
-        return faiss_io.mmap_index_flat(idx)[0], "index-mmap"
-    with open(os.path.join(index_dir, "vecs"), "rb") as fp:  # neither: only the pickle exists
+        rows = _mmap_flat_or_none(idx)
+        if rows is not None:
+            return rows, "index-mmap"
+    with open(os.path.join(index_dir, "vecs"), "rb") as fp:  # no mappable file: only the pickle has the rows
         return np.asarray(pickle.load(fp)), "pickle"

@@ -106,6 +106,16 @@ class HipVS(VS):
             return 0, 1
         return dist.get_rank(self._pg), dist.get_world_size(self._pg)
 
+    def _group(self):
+        """(rank, world) of the process group this store works in under EITHER split (rows or queries) - what decides who
+        writes an index directory and which collectives every rank must enter; (0, 1) when not distributed."""
+        if not (self._shard or self._shard_queries):
+            return 0, 1
+        from . import _dist
+
+        _, rank, world = _dist.context(True, self._pg)
+        return rank, world
+
     def _pack_mode(self, dtype) -> int:
         if self.storage == "fp16":
             return _capi.PACK_F16
@@ -163,7 +173,7 @@ class HipVS(VS):
         device image).  Rank 0 writes the reference's two files plus the mappable row store (``lotus_amd/store.py``);
         ``persist=False`` skips the disk entirely, ``raw=False`` writes the reference's files only."""
         emb = self._as_matrix(embeddings, "embeddings")
-        rank, world = self._dist()
+        rank, world = self._group()  # under the query split every rank holds the whole corpus, but only ONE may write it
         persist = bool(kwargs.get("persist", True))
         is_dev = self._is_device_tensor(emb)
         if persist:
@@ -174,6 +184,7 @@ class HipVS(VS):
                 from . import _dist
 
                 _dist.barrier(self._pg)
+        # the signature is taken after the barrier: every rank records the finished directory
         self._install(index_dir, emb, stored=None if is_dev else emb,
                       sig=store.signature(index_dir) if persist else None)
         self.index_dir = index_dir
@@ -207,11 +218,11 @@ class HipVS(VS):
                 sel = np.arange(ent.n, dtype=np.int64)[sel]
             out = be.unpack(ent.packed, be.to_device(sel)).cpu().numpy()
             return out.astype(np.float16) if ent.packed.mode == _capi.PACK_F16 else out
-        if ent is not None and ent.vecs is not None:
-            vecs = ent.vecs
+        if ent is not None and ent.vecs is not None and (ent.sig is None or ent.sig == store.signature(index_dir)):
+            vecs = ent.vecs  # the caller's array / an open map - unless the directory was rewritten since (load_index's rule)
         else:
             vecs, _ = store.open_stored_rows(index_dir)
-            if ent is not None:
+            if ent is not None and ent.sig == store.signature(index_dir):
                 ent.vecs = vecs
         return np.asarray(vecs[sel])
 
@@ -393,7 +404,9 @@ class HipVS(VS):
             if sub.size == ent.n and np.array_equal(sub, np.arange(ent.n)):
                 sub = None
         be = self.backend
-        if ent.lo == 0 and ent.hi == ent.n:  # the whole index lives on this rank
+        # the path is chosen from the group size - identical on every rank - never from this rank's share of the rows
+        # (with ceil(n / world) >= n rank 0 holds everything while the others still enter the collectives)
+        if self._dist()[1] == 1:  # the whole index lives on this rank
             packed = ent.packed if sub is None else be.gather(ent.packed, be.to_device(sub))
             res = _kmeans(None, ncentroids, niter=niter, backend=be, packed=packed, process_group=self._pg, **kw)
         else:

@@ -89,6 +89,15 @@ def worker(rank, world, port, tmp, out_q, backend_kind):
         res["q_bounds"] = (entq.lo, entq.hi, entq.packed.n)
         for name, out in (("q_full", vq(xq[:299], 7)), ("q_sub", vq(xq[:299], 7, ids=ids)), ("q_one", vq(xq[:1], 5))):
             res[name] = (np.asarray(out.distances), np.asarray(out.indices))
+        # index() under the query split: every rank holds the whole corpus, ONE rank writes the directory
+        import lotus_amd.store as store_mod
+
+        writes, orig_write = [], store_mod.write_dir
+        store_mod.write_dir = lambda *a, **k: (writes.append(a[0]), orig_write(*a, **k))[1]
+        vq2 = HipVS(backend=be, shard="queries")
+        vq2.index(None, xb[:500], os.path.join(tmp, "qidx"))
+        store_mod.write_dir = orig_write
+        res["q_index"] = (len(writes), vq2._resident[vq2.index_dir].sig, np.asarray(vq2(xq[:9], 3).indices))
         res["scores"] = vs.scores(xq[:6])
         res["scores_sub"] = vs.scores(xq[:6], ids=ids[:77])
         # k-means on the row-sharded index: all rows, then a subset of rows
@@ -178,6 +187,11 @@ def check(res, exact: bool):
         same_topk(r["q_full"], ref_qf, 7)
         same_topk(r["q_sub"], ref_qs, 7)
         same_topk(r["q_one"], ref_q1, 5)    # fewer queries than ranks: one rank's slice is empty
+    ref_qi = oracle.flat_search(xb32[:500], xq32[:9], 3)
+    assert [r["q_index"][0] for r in res] == [1, 0]           # only the group's rank 0 wrote the directory
+    assert res[0]["q_index"][1] == res[1]["q_index"][1]       # ... and both recorded the finished directory's signature
+    for r in res:
+        assert np.array_equal(r["q_index"][2], ref_qi[1])
     # every rank holds the same merged answers
     for key in ("full", "sub", "k1000", "rank_all"):
         assert np.array_equal(res[0][key][1], res[1][key][1]) and np.array_equal(res[0][key][0], res[1][key][0])

@@ -114,3 +114,63 @@ def test_never_persisted_index_serves_vectors_from_the_device_image(tmp_path):
     got = vs.get_vectors_from_index(d, [5, 2])
     assert got.dtype == np.float16 and np.array_equal(got, x[[5, 2]])
     assert vs(x[:3], 1).indices[:, 0].tolist() == [0, 1, 2]
+
+
+def test_non_flat_faiss_index_falls_back_to_the_pickle(tmp_path):
+    """FaissVS(factory_string="IVF.."/"HNSW..") (faiss_vs.py:14,23,30) writes a non-IxF* `index`; such a
+    directory must load from `vecs` instead of raising 'not a faiss IndexFlat file'."""
+    x = synth.corpus(120, 16, seed=7)
+    d = str(tmp_path / "ivf")
+    os.makedirs(d)
+    with open(os.path.join(d, "vecs"), "wb") as fp:
+        pickle.dump(x, fp)
+    with open(os.path.join(d, "index"), "wb") as fp:
+        fp.write(b"IwFl" + b"\x00" * 100)  # an IVF index: another fourcc, another layout
+    rows, how = store.open_device_rows(d)
+    assert how == "pickle" and np.array_equal(rows, x)
+    vs = HipVS(backend=OracleBackend())
+    vs.load_index(d)
+    assert vs(x[11:12], 1).indices[0, 0] == 11
+    assert np.array_equal(vs.get_vectors_from_index(d, [4, 2]), x[[4, 2]])
+    # ... also when a row-store description that points INTO the index file survived the overwrite
+    d2 = str(tmp_path / "was_flat")
+    HipVS(backend=OracleBackend()).index(None, x, d2)  # float32: rows.json says file == "index"
+    with open(os.path.join(d2, "index"), "wb") as fp:
+        fp.write(b"IwFl" + b"\x00" * 100)
+    rows, how = store.open_device_rows(d2)
+    assert how == "pickle" and np.array_equal(rows, x)
+    with open(os.path.join(d2, "index"), "wb") as fp:  # truncated header: struct.error territory
+        fp.write(b"IxFI\x01")
+    assert store.open_device_rows(d2)[1] == "pickle"
+
+
+def test_stale_raw_rows_are_not_served_after_a_foreign_rewrite(tmp_path):
+    """stock LOTUS re-running sem_index into a directory HipVS wrote with fp16 embeddings leaves rows.f16 and
+    rows.json behind; same n and d must not be enough to trust them."""
+    a = synth.corpus(80, 8, seed=8).astype(np.float16)
+    b = synth.corpus(80, 8, seed=9).astype(np.float32)  # same shape, other rows
+    d = str(tmp_path / "i")
+    vs = HipVS(backend=OracleBackend())
+    vs.index(None, a, d)
+    assert store.open_stored_rows(d)[1] == "mmap"
+    with open(os.path.join(d, "vecs"), "wb") as fp:  # what FaissVS.index does (faiss_vs.py:27-30): only its two files
+        pickle.dump(b, fp)
+    faiss_io.write_index_flat(os.path.join(d, "index"), b, 0)
+    rows, how = store.open_stored_rows(d)
+    assert how == "pickle" and np.array_equal(rows, b)
+    rows, how = store.open_device_rows(d)
+    assert how == "index-mmap" and np.array_equal(np.asarray(rows), b)
+    vs.load_index(d)  # the resident entry is stale too (signature)
+    assert vs(b[33:34], 1).indices[0, 0] == 33
+    assert np.array_equal(vs.get_vectors_from_index(d, [5]), b[[5]])
+
+
+def test_get_vectors_notices_a_rewritten_directory_without_load_index(tmp_path):
+    a, b = synth.corpus(30, 8, seed=10), synth.corpus(30, 8, seed=11)
+    d = str(tmp_path / "i")
+    vs = HipVS(backend=OracleBackend())
+    vs.index(None, a, d)
+    assert np.array_equal(vs.get_vectors_from_index(d, [3]), a[[3]])
+    HipVS(backend=OracleBackend()).index(None, b, d)
+    os.utime(os.path.join(d, "vecs"), ns=(5, 5))
+    assert np.array_equal(vs.get_vectors_from_index(d, [3]), b[[3]])
