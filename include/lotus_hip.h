@@ -29,7 +29,9 @@
 extern "C" {
 #endif
 
-#define LVS_ABI_VERSION 2 /* 2: pack modes in lvs_flat_search_workspace_bytes, lvs_build_flags, k-means device update */
+#define LVS_ABI_VERSION 3 /* 2: pack modes in lvs_flat_search_workspace_bytes, lvs_build_flags, k-means device update;
+                             3: k-means iteration entirely on the device (objective, split, repack, accumulate from keys),
+                                lvs_pack_rows_checked, lvs_margin_select_stats */
 
 #define LVS_OK 0
 #define LVS_EINVAL (-1)   /* bad argument */
@@ -73,6 +75,13 @@ int32_t lvs_packed_ld(int32_t d, int32_t pack_mode);        /* leading dimension
  * out_norms_sq (nullable): [n] float32 |x_i|^2 of the stored (rounded) values, used by the L2 metric. */
 int32_t lvs_pack_rows(const void* src, int32_t src_dtype, int64_t n, int32_t d, int32_t pack_mode,
                       int32_t normalize, void* dst, float* out_norms_sq, void* stream);
+/* The same with input validation (faiss takes any float32, faiss_vs.py:24; fp16-based rows do not): *out_flags (device word,
+ * nullable, OR-ed into - zero it first) receives LVS_PACK_FLAG_NONFINITE when an input value is inf / NaN and
+ * LVS_PACK_FLAG_RANGE when a finite value lies outside fp16's range (|x| > 65504 after the optional normalisation). */
+#define LVS_PACK_FLAG_NONFINITE 1
+#define LVS_PACK_FLAG_RANGE 2
+int32_t lvs_pack_rows_checked(const void* src, int32_t src_dtype, int64_t n, int32_t d, int32_t pack_mode, int32_t normalize,
+                              void* dst, float* out_norms_sq, uint32_t* out_flags, void* stream);
 /* dst[i] = src[ids[i]] for packed rows (the `ids` branch gather, faiss_vs.py:59-64). */
 int32_t lvs_gather_rows(const void* src, int32_t ld, const int64_t* ids, int64_t n_ids, void* dst, void* stream);
 /* dst[i][0..d) = float32 value (hi + lo) of packed row ids[i] (row i when ids is NULL): the inverse of lvs_pack_rows
@@ -174,17 +183,46 @@ int32_t lvs_rescore_keys(const void* xb, int32_t xb_pack, const void* xq, int32_
  * *out_count (device uint64, zeroed by the caller) += their number.  q_norms_sq NULL means |q| = 1. */
 int32_t lvs_margin_select(const uint64_t* keys, const float* second, const float* q_norms_sq, int64_t nq, float scale,
                           float slack, int64_t* out_idx, uint64_t* out_count, void* stream);
+/* The same test with the corpus statistics read from the device: corpus_stats[0] = R^2 (largest squared row norm),
+ * corpus_stats[1] = E^2 (largest squared lo-part norm) as written by lvs_kmeans_pack_centroids / lvs_kmeans_update_centroids;
+ * bound = (coef5[0] E + coef5[1] R) sqrt(q_norms_sq) + coef5[2] + coef5[3] R + coef5[4] R^2.  Lets the k-means loop run
+ * without a host round trip per iteration. */
+int32_t lvs_margin_select_stats(const uint64_t* keys, const float* second, const float* q_norms_sq, int64_t nq,
+                                const float* corpus_stats, const float* coef5, int64_t* out_idx, uint64_t* out_count,
+                                void* stream);
 int64_t lvs_kmeans_accumulate_workspace_bytes(int64_t n, int32_t k);
 /* sums [k][d] float32 += packed rows of x grouped by assign[i] (int64, values outside [0,k) are skipped);
  * counts [k] float32 += group sizes.  Both must be initialised by the caller.  Rows of one centroid are added
- * in row order (faiss compute_centroids order), so the result is deterministic. */
+ * in row order (faiss compute_centroids order), so the result is deterministic.  (Rows are bucketed by a stable counting
+ * sort on the centroid ids: per-chunk histograms, a scan, an in-order scatter.) */
 int32_t lvs_kmeans_accumulate(const void* x, int64_t n, int32_t d, int32_t pack_mode, const int64_t* assign,
                               int32_t k, float* sums, float* counts, void* workspace, int64_t workspace_bytes,
                               void* stream);
-/* centroids [k][d] float32 (in/out): c = sums * (1 / count) where count > 0, unchanged where the cluster is empty
- * (faiss compute_centroids; empty clusters are then re-seeded by lvs_kmeans_split_clusters_host). */
-int32_t lvs_kmeans_update_centroids(const float* sums, const float* counts, int32_t k, int32_t d, float* centroids,
-                                    void* stream);
+/* The same straight from the assignment search's result keys [n] (row i is assigned to centroid id(keys[i]) - id_offset;
+ * empty keys are skipped): no decode pass in between. */
+int32_t lvs_kmeans_accumulate_keys(const void* x, int64_t n, int32_t d, int32_t pack_mode, const uint64_t* keys,
+                                   int64_t id_offset, int32_t k, float* sums, float* counts, void* workspace,
+                                   int64_t workspace_bytes, void* stream);
+/* faiss's objective of an iteration (sum of the squared assignment distances, Clustering.cpp) without a pass over the
+ * points, from what the update needs anyway: *out_obj (device float64) = *x_norms_sq_sum - 2 sum_j <c_j, S_j> + sum_j n_j |c_j|^2
+ * with the centroids BEFORE the update (float64 arithmetic, fixed summation order).  x_norms_sq_sum (device float64,
+ * nullable = 0): sum of |x_i|^2 over the assigned rows.  Linear in (sums, counts): ranks add their partial values. */
+int64_t lvs_kmeans_objective_workspace_bytes(int32_t k);
+int32_t lvs_kmeans_objective(const float* centroids, const float* sums, const float* counts, int32_t k, int32_t d,
+                             const double* x_norms_sq_sum, double* out_obj, void* workspace, int64_t workspace_bytes,
+                             void* stream);
+/* packed_out / norms_out = lvs_pack_rows(centroids) and stats_out (device float[2], nullable) = {largest |row|^2, largest
+ * |lo part of a row|^2} - the centroid-side terms of the one-pass assignment's certificate (lvs_margin_select_stats). */
+int32_t lvs_kmeans_pack_centroids(const float* centroids, int32_t k, int32_t d, int32_t pack_mode, void* packed_out,
+                                  float* norms_out, float* stats_out, void* stream);
+/* One call = the rest of a faiss Clustering iteration after the sums: centroids [k][d] float32 (in/out): c = sums * (1 / count)
+ * where count > 0, unchanged where the cluster is empty (compute_centroids); then, when n_train > 0, faiss's split_clusters
+ * on the device (std::mt19937(1234) replayed by one thread: same draws and decisions as lvs_kmeans_split_clusters_host;
+ * counts is modified as faiss modifies hassign; *out_nsplit (device int32, nullable) = clusters re-seeded); then, when
+ * packed_out is given, the updated centroids are repacked (lvs_kmeans_pack_centroids). */
+int32_t lvs_kmeans_update_centroids(const float* sums, float* counts, int32_t k, int32_t d, int64_t n_train, float* centroids,
+                                    int32_t* out_nsplit, int32_t pack_mode, void* packed_out, float* norms_out,
+                                    float* stats_out, void* stream);
 /* HOST helpers (plain host pointers), bit-exact with faiss: rand_perm(n, seed) = Fisher-Yates on std::mt19937
  * (training subsample and initial centroids), and split_clusters (empty-cluster re-seeding, RNG seed 1234). */
 int32_t lvs_rand_perm_host(int64_t n, int64_t seed, int64_t* out_perm);

@@ -17,8 +17,9 @@ DTYPE_F32, DTYPE_F16 = 0, 1
 METRIC_IP, METRIC_L2 = 0, 1
 PACK_F16, PACK_SPLIT = 0, 1
 MAX_K = 2048
-ABI_VERSION = 2
+ABI_VERSION = 3
 BUILD_TUNING, BUILD_COUNT_EVENTS = 1, 2
+PACK_FLAG_NONFINITE, PACK_FLAG_RANGE = 1, 2
 
 _i32, _i64, _vp, _dbl = ctypes.c_int32, ctypes.c_int64, ctypes.c_void_p, ctypes.c_double
 
@@ -31,6 +32,7 @@ SIGNATURES = {
     "lvs_device_info": (_i32, [_i32, ctypes.c_char_p, _i32, ctypes.POINTER(_i32), ctypes.POINTER(_i64)]),
     "lvs_packed_ld": (_i32, [_i32, _i32]),
     "lvs_pack_rows": (_i32, [_vp, _i32, _i64, _i32, _i32, _i32, _vp, _vp, _vp]),
+    "lvs_pack_rows_checked": (_i32, [_vp, _i32, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
     "lvs_gather_rows": (_i32, [_vp, _i32, _vp, _i64, _vp, _vp]),
     "lvs_gather_f32": (_i32, [_vp, _vp, _i64, _vp, _vp]),
     "lvs_unpack_rows": (_i32, [_vp, _i32, _i32, _vp, _i64, _vp, _vp]),
@@ -52,9 +54,14 @@ SIGNATURES = {
     "lvs_sort_keys_desc": (_i32, [_vp, _i64, _i32, _vp]),
     "lvs_certify_topk": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, ctypes.c_float, ctypes.c_float, _vp, _vp, _vp]),
     "lvs_margin_select": (_i32, [_vp, _vp, _vp, _i64, ctypes.c_float, ctypes.c_float, _vp, _vp, _vp]),
+    "lvs_margin_select_stats": (_i32, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
     "lvs_kmeans_accumulate_workspace_bytes": (_i64, [_i64, _i32]),
     "lvs_kmeans_accumulate": (_i32, [_vp, _i64, _i32, _i32, _vp, _i32, _vp, _vp, _vp, _i64, _vp]),
-    "lvs_kmeans_update_centroids": (_i32, [_vp, _vp, _i32, _i32, _vp, _vp]),
+    "lvs_kmeans_accumulate_keys": (_i32, [_vp, _i64, _i32, _i32, _vp, _i64, _i32, _vp, _vp, _vp, _i64, _vp]),
+    "lvs_kmeans_objective_workspace_bytes": (_i64, [_i32]),
+    "lvs_kmeans_objective": (_i32, [_vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _i64, _vp]),
+    "lvs_kmeans_pack_centroids": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
+    "lvs_kmeans_update_centroids": (_i32, [_vp, _vp, _i32, _i32, _i64, _vp, _vp, _i32, _vp, _vp, _vp, _vp]),
     "lvs_rand_perm_host": (_i32, [_i64, _i64, _vp]),
     "lvs_rand_perm_prefix_host": (_i32, [_i64, _i64, _i64, _vp]),
     "lvs_kmeans_split_clusters_host": (_i32, [_i32, _i32, _i64, _vp, _vp, ctypes.POINTER(_i32)]),

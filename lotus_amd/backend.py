@@ -61,8 +61,10 @@ class HipBackend:
         return self.torch.from_numpy(np.ascontiguousarray(arr)).to(self.device)
 
     # ---- packing ----
-    def pack(self, x, mode: int, normalize: bool = False) -> PackedRows:
-        """x: numpy [n,d] (float16/32/64) or a torch CUDA tensor (float16/float32)."""
+    def pack(self, x, mode: int, normalize: bool = False, check: bool = False) -> PackedRows:
+        """x: numpy [n,d] (float16/32/64) or a torch CUDA tensor (float16/float32).  ``check``: validate the values on the
+        device while packing - ``ValueError`` for inf / NaN or magnitudes beyond fp16's range (one read-back of a flag
+        word; faiss itself accepts any float32, the fp16-based rows here do not - DESIGN.md section 7)."""
         torch = self.torch
         is_tensor = torch.is_tensor(x)
         n, d = int(x.shape[0]), int(x.shape[1])
@@ -71,6 +73,7 @@ class HipBackend:
             raise LotusHipError(f"bad dimension d={d}")
         rows = torch.empty((n, ld), dtype=torch.float16, device=self.device)
         norms = torch.empty((n,), dtype=torch.float32, device=self.device)
+        flags = torch.zeros((1,), dtype=torch.int32, device=self.device) if check else None
         step = self.PACK_CHUNK_ROWS
         for r0 in range(0, n, step):
             r1 = min(n, r0 + step)
@@ -92,9 +95,16 @@ class HipBackend:
                 else:
                     chunk = torch.from_numpy(c).to(self.device)
             src_dtype = _capi.DTYPE_F16 if chunk.dtype == torch.float16 else _capi.DTYPE_F32
-            self._c("lvs_pack_rows", _ptr(chunk), src_dtype, r1 - r0, d, mode, int(bool(normalize)), _ptr(rows[r0:r1]),
-                    _ptr(norms[r0:r1]), self._stream())
+            self._c("lvs_pack_rows_checked", _ptr(chunk), src_dtype, r1 - r0, d, mode, int(bool(normalize)),
+                    _ptr(rows[r0:r1]), _ptr(norms[r0:r1]), _ptr(flags), self._stream())
             del chunk
+        if check:
+            f = int(flags.item())
+            if f & _capi.PACK_FLAG_NONFINITE:
+                raise ValueError("embeddings contain inf or NaN")
+            if f & _capi.PACK_FLAG_RANGE:
+                raise ValueError("embedding values exceed fp16's range (|x| > 65504): rescale the embeddings "
+                                 "(the device rows are fp16 or fp16 hi|lo pairs)")
         return PackedRows(rows=rows, norms=norms, n=n, d=d, mode=mode)
 
     def gather(self, src: PackedRows, ids_dev) -> PackedRows:
@@ -208,7 +218,7 @@ class HipBackend:
         return keys
 
     def nearest(self, corpus: PackedRows, queries: PackedRows, metric: int, id_offset: int = 0, stats: dict | None = None,
-                exact_scores: bool = True):
+                exact_scores: bool = True, corpus_stats=None):
         """Nearest corpus row of every query (k = 1) -> int64 key tensor [nq, 1], same winner as ``search_keys(.., 1, ..)``.
 
         fp32-accurate operands (fp16 hi|lo rows) cost two or three MFMA passes in the exact search.  Here ONE pass over
@@ -217,7 +227,9 @@ class HipBackend:
         above twice that bound certifies the winner.  Only the uncertified queries (``lvs_margin_select``: ties,
         near-ties) are searched again exactly.  This is the k-means assignment step (``lotus/utils.py:62,65``) with
         fp32-accurate centroids at the cost of fp16 ones.  ``exact_scores=False`` leaves the one-pass scores inside the
-        keys of certified queries (the ids are exact either way) and saves one pass over the queries."""
+        keys of certified queries (the ids are exact either way) and saves one pass over the queries.  ``corpus_stats``:
+        device float32 [2] = (largest |row|^2, largest |lo part of a row|^2) of the corpus as ``kmeans_pack_centroids`` /
+        ``kmeans_finish`` leave it - the certificate's bound is then evaluated on the device (no host round trip for it)."""
         torch = self.torch
         if corpus.mode == _capi.PACK_F16 and queries.mode == _capi.PACK_F16:
             return self.search_keys(corpus, queries, 1, metric, id_offset=id_offset)  # nothing to certify: already exact
@@ -228,23 +240,26 @@ class HipBackend:
         keys = torch.empty((nq, 1), dtype=torch.int64, device=self.device)
         if nq == 0 or corpus.n == 0:
             return self.search_keys(corpus, queries, 1, metric, **plain)
-        # error bound per unit of |q|: largest lo-part norm and largest norm over the corpus rows (a small matrix in the
-        # k-means use: the centroids)
+        # error bound per unit of |q|: E = largest lo-part norm and R = largest norm over the corpus rows (a small matrix in
+        # the k-means use: the centroids).  bound = scale |q| + slack with
+        #   scale = c (E + 2^-11 R [queries split] + 8e-6 R) + 2^-16 cm R     (c = 2 / 4, cm = 1 / 2 for IP / L2; 8e-6: fp32
+        #   slack = 1e-6 (1 + R^2) + [L2] 2^-16 R^2 + [queries split] c sqrt(d) 2^-25 R      accumulation noise of both searches)
+        # lvs_nearest_hi tags every running score in its low six mantissa bits (relative perturbation < 2^-17 of u = q.y or
+        # 2 q.y - |y|^2, for the winner and for the runner-up): the 2^-16 terms.  |lo_q| <= 2^-11 |q| + sqrt(d) 2^-25: the
+        # second term covers components in fp16's subnormal range.
         dpad = int(corpus.rows.shape[1]) // (2 if corpus.mode == _capi.PACK_SPLIT else 1)
-        R = float(corpus.norms.max().sqrt().item())
-        E = 0.0
-        if corpus.mode == _capi.PACK_SPLIT:
-            E = float(corpus.rows[:, dpad:].float().square().sum(dim=1).max().sqrt().item())
-        per_q = E + (2.0 ** -11) * R * (1.0 if queries.mode == _capi.PACK_SPLIT else 0.0)
-        c = 2.0 if metric == _capi.METRIC_IP else 4.0
-        scale = c * (per_q + 8e-6 * R)          # + fp32 accumulation noise of both searches, relative to |q| |row|
-        slack = 1e-6 * (1.0 + R * R)
-        if queries.mode == _capi.PACK_SPLIT:    # |lo_q| <= 2^-11 |q| + sqrt(d) 2^-25 (fp16 subnormal range)
-            slack += c * (dpad ** 0.5) * 2.0 ** -25 * R
-        # lvs_nearest_hi tags every running score in its low six mantissa bits (relative perturbation < 2^-17 of
-        # u = q.y or 2 q.y - |y|^2, for the winner and for the runner-up)
-        scale += 2.0 ** -16 * (1.0 if metric == _capi.METRIC_IP else 2.0) * R
-        slack += 0.0 if metric == _capi.METRIC_IP else 2.0 ** -16 * R * R
+        qsplit = 1.0 if queries.mode == _capi.PACK_SPLIT else 0.0
+        ip = metric == _capi.METRIC_IP
+        c = 2.0 if ip else 4.0
+        coef = [c, c * ((2.0 ** -11) * qsplit + 8e-6) + 2.0 ** -16 * (1.0 if ip else 2.0),
+                1e-6, qsplit * c * (dpad ** 0.5) * 2.0 ** -25, 1e-6 + (0.0 if ip else 2.0 ** -16)]
+        if corpus_stats is None:
+            R = float(corpus.norms.max().sqrt().item())
+            E = 0.0
+            if corpus.mode == _capi.PACK_SPLIT:
+                E = float(corpus.rows[:, dpad:].float().square().sum(dim=1).max().sqrt().item())
+            scale = coef[0] * E + coef[1] * R
+            slack = coef[2] + coef[3] * R + coef[4] * R * R
         sec = torch.empty((nq,), dtype=torch.float32, device=self.device)
         need = int(self.lib.lvs_nearest_hi_workspace_bytes(nq, corpus.n, corpus.d))
         ws = self._workspace(need)
@@ -253,9 +268,14 @@ class HipBackend:
                 int(ws.numel()), self._stream())
         idx = torch.empty((nq,), dtype=torch.int64, device=self.device)
         cnt = torch.zeros((1,), dtype=torch.int64, device=self.device)
-        self._c("lvs_margin_select", _ptr(keys), _ptr(sec), _ptr(queries.norms), nq, float(scale), float(slack), _ptr(idx),
-                _ptr(cnt), self._stream())
-        n_open = int(cnt.item())
+        if corpus_stats is None:
+            self._c("lvs_margin_select", _ptr(keys), _ptr(sec), _ptr(queries.norms), nq, float(scale), float(slack),
+                    _ptr(idx), _ptr(cnt), self._stream())
+        else:
+            coef5 = (ctypes.c_float * 5)(*coef)
+            self._c("lvs_margin_select_stats", _ptr(keys), _ptr(sec), _ptr(queries.norms), nq, _ptr(corpus_stats),
+                    ctypes.addressof(coef5), _ptr(idx), _ptr(cnt), self._stream())
+        n_open = int(cnt.item())  # the call's one host round trip: the exact search below is sized by it
         # the winners are certified, their scores are still the one-pass approximations: put the exact scores in
         # (one HBM-bound pass over the queries; the k-means objective sums them)
         if exact_scores:
@@ -372,10 +392,59 @@ class HipBackend:
                 _ptr(ws), int(ws.numel()), self._stream())
         return sums, counts
 
-    def kmeans_update_centroids(self, sums, counts, centroids) -> None:
-        """centroids (device float32 [k,d], in place) = sums / counts where counts > 0 (faiss compute_centroids)."""
+    def kmeans_accumulate_keys(self, x: PackedRows, keys, k: int, id_offset: int = 0):
+        """The same straight from the assignment search's result keys [n(,1)] (no decode pass in between)."""
+        torch = self.torch
+        sums = torch.zeros((k, x.d), dtype=torch.float32, device=self.device)
+        counts = torch.zeros((k,), dtype=torch.float32, device=self.device)
+        need = int(self.lib.lvs_kmeans_accumulate_workspace_bytes(x.n, k))
+        ws = self._workspace(need)
+        self._c("lvs_kmeans_accumulate_keys", _ptr(x.rows), x.n, x.d, x.mode, _ptr(keys), int(id_offset), k, _ptr(sums),
+                _ptr(counts), _ptr(ws), int(ws.numel()), self._stream())
+        return sums, counts
+
+    def kmeans_objective(self, centroids, sums, counts, x2, out) -> None:
+        """out[0] (device float64) = x2[0] - 2 sum_j <c_j, S_j> + sum_j n_j |c_j|^2: faiss's objective of the iteration
+        (sum of the assignment distances) from the sums, with the centroids BEFORE the update; float64 on the device."""
         k, d = int(centroids.shape[0]), int(centroids.shape[1])
-        self._c("lvs_kmeans_update_centroids", _ptr(sums), _ptr(counts), k, d, _ptr(centroids), self._stream())
+        need = int(self.lib.lvs_kmeans_objective_workspace_bytes(k))
+        if getattr(self, "_obj_ws", None) is None or self._obj_ws.numel() < need:
+            self._obj_ws = self.torch.empty(need, dtype=self.torch.uint8, device=self.device)
+        self._c("lvs_kmeans_objective", _ptr(centroids), _ptr(sums), _ptr(counts), k, d, _ptr(x2), _ptr(out),
+                _ptr(self._obj_ws), int(self._obj_ws.numel()), self._stream())
+
+    def kmeans_pack_centroids(self, centroids, mode: int):
+        """-> (PackedRows of the centroids, device float32 [2] = (largest |c|^2, largest |lo part|^2))."""
+        torch = self.torch
+        k, d = int(centroids.shape[0]), int(centroids.shape[1])
+        ld = int(self.lib.lvs_packed_ld(d, mode))
+        rows = torch.empty((k, ld), dtype=torch.float16, device=self.device)
+        norms = torch.empty((k,), dtype=torch.float32, device=self.device)
+        cstats = torch.empty((2,), dtype=torch.float32, device=self.device)
+        self._c("lvs_kmeans_pack_centroids", _ptr(centroids), k, d, mode, _ptr(rows), _ptr(norms), _ptr(cstats),
+                self._stream())
+        return PackedRows(rows=rows, norms=norms, n=k, d=d, mode=mode), cstats
+
+    def kmeans_finish(self, sums, counts, centroids, n_train: int, mode: int, nsplit_out=None):
+        """The rest of a faiss iteration after the sums, one C-ABI call, nothing read back: centroids (device float32
+        [k,d], in place) = sums / counts where counts > 0 (compute_centroids), faiss's empty-cluster split on the device
+        (``nsplit_out``: device int32 [1]), and the repacked centroids -> (PackedRows, stats) as ``kmeans_pack_centroids``."""
+        torch = self.torch
+        k, d = int(centroids.shape[0]), int(centroids.shape[1])
+        ld = int(self.lib.lvs_packed_ld(d, mode))
+        rows = torch.empty((k, ld), dtype=torch.float16, device=self.device)
+        norms = torch.empty((k,), dtype=torch.float32, device=self.device)
+        cstats = torch.empty((2,), dtype=torch.float32, device=self.device)
+        self._c("lvs_kmeans_update_centroids", _ptr(sums), _ptr(counts), k, d, int(n_train), _ptr(centroids),
+                _ptr(nsplit_out), mode, _ptr(rows), _ptr(norms), _ptr(cstats), self._stream())
+        return PackedRows(rows=rows, norms=norms, n=k, d=d, mode=mode), cstats
+
+    def kmeans_update_centroids(self, sums, counts, centroids) -> None:
+        """centroids (device float32 [k,d], in place) = sums / counts where counts > 0 (faiss compute_centroids) - the
+        division alone, for callers that split empty clusters on the host (``split_clusters``)."""
+        k, d = int(centroids.shape[0]), int(centroids.shape[1])
+        self._c("lvs_kmeans_update_centroids", _ptr(sums), _ptr(counts), k, d, 0, _ptr(centroids), None, 0, None, None,
+                None, self._stream())
 
     def rand_perm(self, n: int, seed: int, m: int | None = None) -> np.ndarray:
         """faiss ``rand_perm(n, seed)``; with ``m`` only its first ``m`` entries (O(m) host time instead of O(n))."""

@@ -33,14 +33,16 @@ class KMeansResult:
 def kmeans(x, k: int, niter: int = 20, seed: int = 1234, max_points_per_centroid: int | None = 256, backend=None,
            pack_mode: int | None = None, packed=None, shard: bool = False, process_group=None,
            final_assign: bool = True, centroid_precision: str = "fp32", n_total: int | None = None,
-           local_pos=None) -> KMeansResult:
+           local_pos=None, stats: dict | None = None) -> KMeansResult:
     """faiss-parity k-means (``faiss.Kmeans(d, k, niter).train(x)`` + ``index.search(x, 1)``, ``lotus/utils.py:61-65``).
 
     ``x``: host matrix [n,d] (float16/32/64) and/or ``packed``: its device image.  Everything after the packing runs
     on the device image: initial centroids are unpacked from it, assignment is the tile kernel in top-1 / squared-L2
-    mode, sums are accumulated in row order, the centroid division happens on the device; per iteration only the
-    ``[k]`` counts come back to the host (4 KB), where faiss's empty-cluster split decides whether anything is left
-    to do (it needs the centroids on the host only when a cluster is empty).
+    mode (certified one-pass form for fp32-accurate centroids), sums are accumulated in row order, and the objective,
+    the centroid division, faiss's empty-cluster split (its ``std::mt19937`` replayed by a device thread) and the
+    repacking of the centroids happen on the device too: an iteration is a chain of launches whose only host round trip
+    is the count of uncertified rows inside ``nearest``; objectives and split counts are read once, after the loop.
+    ``stats`` (dict) collects ``uncertified`` / ``queries`` of the certified assignments.
 
     Multi-GPU (``shard=True`` with ``torch.distributed`` initialised):
       * rows replicated (``packed`` holds all ``n`` rows on every rank): the training rows are dealt to the ranks in
@@ -131,35 +133,30 @@ def kmeans(x, k: int, niter: int = 20, seed: int = 1234, max_points_per_centroid
             train = packed
         else:
             train = be.gather(packed, be.to_device(train_ids))
-        objs = []
-        x2 = train.norms.double().sum()  # sum of |x_i|^2 over this rank's training rows (constant over the iterations)
+        import torch
+
+        dev = train.rows.device
+        x2 = train.norms.double().sum().reshape(1)  # sum of |x_i|^2 over this rank's training rows (constant over the iterations)
+        obj_dev = torch.zeros((max(niter, 1),), dtype=torch.float64, device=dev)
+        nsplit_dev = torch.zeros((max(niter, 1),), dtype=torch.int32, device=dev)
+        cpk, cstats = be.kmeans_pack_centroids(centroids, cmode)
         for it in range(niter):
-            cpk = be.pack(centroids, cmode)
-            keys = be.nearest(cpk, train, _capi.METRIC_L2, exact_scores=False)  # only the ids are needed ...
-            _, I = be.keys_to_result(keys, _capi.METRIC_L2)
-            sums, counts = be.kmeans_accumulate(train, I.reshape(-1), k)
+            keys = be.nearest(cpk, train, _capi.METRIC_L2, exact_scores=False, corpus_stats=cstats, stats=stats)  # ids only ...
+            sums, counts = be.kmeans_accumulate_keys(train, keys, k)
             # ... because the objective (faiss: sum of the assignment distances) follows from the sums the update needs
             # anyway:  sum_i |x_i - c_a(i)|^2 = sum_i |x_i|^2 - 2 sum_j c_j . S_j + sum_j n_j |c_j|^2   (float64, [k,d])
-            c64 = centroids.double()
-            o = (x2 - 2.0 * (c64 * sums.double()).sum() + (counts.double() * (c64 * c64).sum(dim=1)).sum()).float().reshape(1)
+            be.kmeans_objective(centroids, sums, counts, x2, obj_dev[it:it + 1])
             if dist is not None:
-                _dist.all_reduce_sum_([sums, counts, o], process_group)
-            objs.append(o)
-            hs = counts.cpu().numpy().astype(np.float32)  # the iteration's only device -> host copy (4 KB)
-            be.kmeans_update_centroids(sums, counts, centroids)
-            if (hs == 0).any():  # faiss split_clusters: re-seed empty clusters (host RNG, same on every rank)
-                ch = np.ascontiguousarray(centroids.cpu().numpy(), dtype=np.float32)
-                nsplit[it] = be.split_clusters(nt, hs, ch)
-                centroids.copy_(be.to_device(ch))
-        if objs:
-            import torch
-
-            obj[:] = torch.cat(objs).cpu().numpy()
+                _dist.all_reduce_sum_([sums, counts, obj_dev[it:it + 1]], process_group)
+            # centroid division + faiss split_clusters (same RNG stream on every rank) + repack, nothing read back
+            cpk, cstats = be.kmeans_finish(sums, counts, centroids, nt, cmode, nsplit_dev[it:it + 1])
+        obj[:] = obj_dev[:niter].cpu().numpy().astype(np.float32)
+        nsplit[:] = nsplit_dev[:niter].cpu().numpy()
     assign = np.zeros(0, np.int64)
     if final_assign:
-        cpk = be.pack(centroids, cmode)
+        cpk, cstats = be.kmeans_pack_centroids(centroids, cmode)
         if dist is None:
-            keys = be.nearest(cpk, packed, _capi.METRIC_L2, exact_scores=False)  # ids only: no rescoring pass
+            keys = be.nearest(cpk, packed, _capi.METRIC_L2, exact_scores=False, corpus_stats=cstats)  # ids only: no rescoring pass
             _, I = be.keys_to_result(keys, _capi.METRIC_L2)
             assign = np.asarray(I.reshape(-1).cpu().numpy(), dtype=np.int64)  # already int64: no copy
         else:
@@ -171,7 +168,7 @@ def kmeans(x, k: int, niter: int = 20, seed: int = 1234, max_points_per_centroid
                 per = -(-n // world)
                 lo, hi = min(n, rank * per), min(n, (rank + 1) * per)
                 mine, pos = be.slice_rows(packed, lo, hi), np.arange(lo, hi, dtype=np.int64)
-            keys = be.nearest(cpk, mine, _capi.METRIC_L2, exact_scores=False)
+            keys = be.nearest(cpk, mine, _capi.METRIC_L2, exact_scores=False, corpus_stats=cstats)
             _, I = be.keys_to_result(keys, _capi.METRIC_L2)
             # ranks may hold different numbers of rows: exchange (position, cluster id) pairs padded to the largest share
             cnt = torch.tensor([mine.n], dtype=torch.int64, device=I.device)

@@ -142,10 +142,22 @@ __device__ inline float wave_sum(float v) {
 }
 
 // one wave per row, one element per lane and step: the fallback for d % 8 != 0 (rows not 16-byte aligned)
+// flags (nullable device word): LVS_PACK_FLAG_NONFINITE when an input value is inf / NaN, LVS_PACK_FLAG_RANGE when a finite
+// value (after the optional normalisation) lies outside fp16's range (|x| > 65504 would be stored as inf)
+__device__ inline uint32_t pack_check(float x) {
+    const float ax = fabsf(x);
+    return !(ax <= 3.4028234663852886e38f) ? (uint32_t)LVS_PACK_FLAG_NONFINITE : (ax > 65504.0f ? (uint32_t)LVS_PACK_FLAG_RANGE : 0u);
+}
+__device__ inline void pack_report(uint32_t bad, uint32_t* flags) {
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) bad |= (uint32_t)__shfl_xor((int)bad, m, 64);
+    if (bad && flags && (threadIdx.x & 63) == 0) atomicOr(flags, bad);
+}
+
 template <typename SrcT>
 __global__ __launch_bounds__(256) void pack_rows_kernel(const SrcT* __restrict__ src, long long n, int d, int dpad,
                                                         int split, int normalize, _Float16* __restrict__ dst,
-                                                        float* __restrict__ norms) {
+                                                        float* __restrict__ norms, uint32_t* __restrict__ flags) {
     const int lane = threadIdx.x & 63;
     const long long row = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (row >= n) return;
@@ -163,8 +175,10 @@ __global__ __launch_bounds__(256) void pack_rows_kernel(const SrcT* __restrict__
         scale = ss > 0.f ? 1.0f / sqrtf(ss) : 0.f;
     }
     float nn = 0.f;
+    uint32_t bad = 0;
     for (int j = lane; j < dpad; j += 64) {
         float x = j < d ? (float)s[j] * scale : 0.f;
+        bad |= pack_check(x);
         _Float16 hi = (_Float16)x;
         float stored = (float)hi;
         o[j] = hi;
@@ -179,6 +193,7 @@ __global__ __launch_bounds__(256) void pack_rows_kernel(const SrcT* __restrict__
         nn = wave_sum(nn);
         if (lane == 0) norms[row] = nn;
     }
+    pack_report(bad, flags);
 }
 
 typedef _Float16 pk_half8 __attribute__((ext_vector_type(8)));
@@ -202,7 +217,7 @@ __device__ inline void pack_load8(const _Float16* s, float (&v)[8]) {
 template <typename SrcT, int SPLIT>
 __global__ __launch_bounds__(256) void pack_rows_vec_kernel(const SrcT* __restrict__ src, long long n, int d, int dpad,
                                                             int normalize, _Float16* __restrict__ dst,
-                                                            float* __restrict__ norms) {
+                                                            float* __restrict__ norms, uint32_t* __restrict__ flags) {
     const int lane = threadIdx.x & 63;
     const long long row = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (row >= n) return;
@@ -221,6 +236,7 @@ __global__ __launch_bounds__(256) void pack_rows_vec_kernel(const SrcT* __restri
         scale = ss > 0.f ? 1.0f / sqrtf(ss) : 0.f;
     }
     float nn = 0.f;
+    uint32_t bad = 0;
     for (int j = lane * 8; j < dpad; j += 512) {
         float v[8];
         if (j < d) {
@@ -233,6 +249,7 @@ __global__ __launch_bounds__(256) void pack_rows_vec_kernel(const SrcT* __restri
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
             float x = v[t] * scale;
+            bad |= pack_check(x);
             hi[t] = (_Float16)x;
             float stored = (float)hi[t];
             if (SPLIT) {
@@ -248,6 +265,7 @@ __global__ __launch_bounds__(256) void pack_rows_vec_kernel(const SrcT* __restri
         nn = wave_sum(nn);
         if (lane == 0) norms[row] = nn;
     }
+    pack_report(bad, flags);
 }
 
 __global__ __launch_bounds__(256) void gather_rows_kernel(const uint4* __restrict__ src, long long ld16,
@@ -305,6 +323,43 @@ __global__ __launch_bounds__(256) void merge_keys_kernel(const u64* __restrict__
             best = best > w ? best : w;          // top-64 of the union, bitonic
             best = lvs_wave_bitonic_merge_desc(best, lane);
         }
+    }
+    if (lane < k) out[q * out_ld + lane] = best;
+}
+
+// the same merge with ONE WORKGROUP per query: its four waves each merge a quarter of the parts, wave 0 merges the four
+// results.  For the small-batch kernel's 64 .. 256 partial lists of a few dozen queries, where one wave per query left the
+// merge longer than the scan it follows.
+__global__ __launch_bounds__(256) void merge_keys_wide_kernel(const u64* __restrict__ parts, int nparts, long long nq, int k,
+                                                              u64* __restrict__ out, long long out_ld) {
+    __shared__ u64 sm[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long q = blockIdx.x;
+    const int per = (nparts + 3) / 4;
+    const int p0 = wave * per, p1 = p0 + per < nparts ? p0 + per : nparts;
+    const long long total = p1 > p0 ? (long long)(p1 - p0) * k : 0;
+    u64 best = 0;
+    for (long long c0 = 0; c0 < total; c0 += 64) {
+        const long long c = c0 + lane;
+        u64 v = 0;
+        if (c < total) {
+            const long long p = p0 + c / k, j = c % k;
+            v = parts[(p * nq + q) * k + j];
+        }
+        if (__builtin_amdgcn_ballot_w64(v != 0) == 0ull) continue;  // empty lists (seeded thresholds): nothing to merge
+        v = lvs_wave_sort_desc(v, lane);
+        const u64 w = lvs_shfl_u64(v, 63 - lane);  // ascending copy
+        best = best > w ? best : w;                // top-64 of the union, bitonic
+        best = lvs_wave_bitonic_merge_desc(best, lane);
+    }
+    sm[wave][lane] = best;
+    __syncthreads();
+    if (wave != 0) return;
+#pragma unroll
+    for (int o = 1; o < 4; ++o) {
+        const u64 w = sm[o][63 - lane];
+        best = best > w ? best : w;
+        best = lvs_wave_bitonic_merge_desc(best, lane);
     }
     if (lane < k) out[q * out_ld + lane] = best;
 }
@@ -429,10 +484,22 @@ __global__ __launch_bounds__(256) void certify_topk_kernel(const u64* __restrict
 
 // queries whose winner is NOT certified by its margin: (best score - runner-up score) <= scale * |q| + slack.
 // Their indices are appended to out_idx (order unspecified), *out_count counts them.
+// With `stats` (device: [0] = R^2 largest squared row norm, [1] = E^2 largest squared lo-part norm of the corpus rows) the
+// bound is (coef[0] E + coef[1] R) |q| + coef[2] + coef[3] R + coef[4] R^2 - the k-means loop keeps those statistics on the
+// device (lvs_kmeans_update_centroids) so that no iteration waits for the host; without it: scale |q| + slack.
+struct MarginCoef {
+    float c[5];
+};
 __global__ __launch_bounds__(256) void margin_select_kernel(const u64* __restrict__ keys, const float* __restrict__ sec,
                                                             const float* __restrict__ qn, long long nq, float scale,
-                                                            float slack, long long per_block, long long* __restrict__ out_idx,
+                                                            float slack, const float* __restrict__ stats, MarginCoef coef,
+                                                            long long per_block, long long* __restrict__ out_idx,
                                                             unsigned long long* __restrict__ out_count) {
+    if (stats) {
+        const float R = sqrtf(stats[0]), E = sqrtf(stats[1]);
+        scale = coef.c[0] * E + coef.c[1] * R;
+        slack = coef.c[2] + coef.c[3] * R + coef.c[4] * R * R;
+    }
     // One workgroup owns `per_block` consecutive queries: it counts its uncertified ones, reserves their output range
     // with ONE atomic (10 M queries at 0.4 % uncertified were 30 000 same-address atomics = 1.2 ms when every wave
     // reserved its own), then writes them in a second sweep over the same 16 bytes per query.
@@ -467,6 +534,12 @@ __global__ __launch_bounds__(256) void margin_select_kernel(const u64* __restric
 
 extern "C" int32_t lvs_pack_rows(const void* src, int32_t src_dtype, int64_t n, int32_t d, int32_t pack_mode,
                                  int32_t normalize, void* dst, float* out_norms_sq, void* stream) {
+    return lvs_pack_rows_checked(src, src_dtype, n, d, pack_mode, normalize, dst, out_norms_sq, nullptr, stream);
+}
+
+extern "C" int32_t lvs_pack_rows_checked(const void* src, int32_t src_dtype, int64_t n, int32_t d, int32_t pack_mode,
+                                         int32_t normalize, void* dst, float* out_norms_sq, uint32_t* out_flags,
+                                         void* stream) {
     LVS_REQUIRE(n >= 0 && d > 0, "bad shape n=%lld d=%d", (long long)n, d);
     LVS_REQUIRE(pack_mode == LVS_PACK_F16 || pack_mode == LVS_PACK_SPLIT, "bad pack_mode %d", pack_mode);
     LVS_REQUIRE(src_dtype == LVS_DTYPE_F32 || src_dtype == LVS_DTYPE_F16, "bad src_dtype %d", src_dtype);
@@ -481,22 +554,22 @@ extern "C" int32_t lvs_pack_rows(const void* src, int32_t src_dtype, int64_t n, 
     _Float16* o = (_Float16*)dst;
     if (vec && src_dtype == LVS_DTYPE_F32 && split)
         hipLaunchKernelGGL((pack_rows_vec_kernel<float, 1>), grid, block, 0, st, (const float*)src, (long long)n, d,
-                           dpad, normalize, o, out_norms_sq);
+                           dpad, normalize, o, out_norms_sq, out_flags);
     else if (vec && src_dtype == LVS_DTYPE_F32)
         hipLaunchKernelGGL((pack_rows_vec_kernel<float, 0>), grid, block, 0, st, (const float*)src, (long long)n, d,
-                           dpad, normalize, o, out_norms_sq);
+                           dpad, normalize, o, out_norms_sq, out_flags);
     else if (vec && split)
         hipLaunchKernelGGL((pack_rows_vec_kernel<_Float16, 1>), grid, block, 0, st, (const _Float16*)src, (long long)n,
-                           d, dpad, normalize, o, out_norms_sq);
+                           d, dpad, normalize, o, out_norms_sq, out_flags);
     else if (vec)
         hipLaunchKernelGGL((pack_rows_vec_kernel<_Float16, 0>), grid, block, 0, st, (const _Float16*)src, (long long)n,
-                           d, dpad, normalize, o, out_norms_sq);
+                           d, dpad, normalize, o, out_norms_sq, out_flags);
     else if (src_dtype == LVS_DTYPE_F32)
         hipLaunchKernelGGL(pack_rows_kernel<float>, grid, block, 0, st, (const float*)src, (long long)n, d, dpad,
-                           split, normalize, o, out_norms_sq);
+                           split, normalize, o, out_norms_sq, out_flags);
     else
         hipLaunchKernelGGL(pack_rows_kernel<_Float16>, grid, block, 0, st, (const _Float16*)src, (long long)n, d,
-                           dpad, split, normalize, o, out_norms_sq);
+                           dpad, split, normalize, o, out_norms_sq, out_flags);
     LVS_HIP_CHECK(hipGetLastError());
     return LVS_OK;
 }
@@ -536,6 +609,12 @@ struct HiOnlyScope {
     HiOnlyScope() { g_hi_only = true; }
     ~HiOnlyScope() { g_hi_only = false; }
 };
+
+// bytes reserved for the small-batch kernel's candidate lists [ranges][nq][k]
+static inline int64_t lvs_stream_parts_bytes(int64_t nq, int k) {
+    return lvs_round_up((int64_t)((lvs_tune_set("LVS_STREAM_WGS") ? LVS_STREAM_MAXWG : 256) + 8) * (nq > 0 ? nq : 1) *
+                            (k > 0 ? k : 1) * 8, 256);
+}
 
 struct Plan {
     int dpad, nkd, nk, ldb, ldq, nseg;
@@ -673,9 +752,10 @@ int make_plan(int64_t nq, int64_t nb, int32_t d, int32_t xb_pack, int32_t xq_pac
     off += lvs_round_up((int64_t)p.nslab * nq * p.kpass * 8, 256);
     p.off_pass = off;  // [nq][kpass] merged keys of one pass (multi-pass only)
     off += p.npass > 1 ? lvs_round_up(nq * p.kpass * 8, 256) : 0;
-    // candidates of the small-batch kernel: one k-list per (workgroup, query), written from off_partial onwards
+    // the small-batch kernel: one k-list per (corpus range, query) written from off_partial onwards, then the score rows of
+    // the sample that seeds its thresholds
     if (nq <= LVS_STREAM_MAXQ && k <= LVS_KPASS)
-        off += (int64_t)((lvs_tune_set("LVS_STREAM_WGS") ? LVS_STREAM_MAXWG : 256) + 32 + 1) * (nq > 0 ? nq : 1) * (k > 0 ? k : 1) * 8;
+        off += lvs_stream_parts_bytes(nq, k) + lvs_round_up((int64_t)(nq > 0 ? nq : 1) * LVS_STREAM_SEED_MAX * 4, 256);
     p.total = off;
     return LVS_OK;
 }
@@ -842,11 +922,46 @@ bool make_two_phase_plan(int64_t nq, int64_t nb, int32_t d, int32_t xb_pack, int
     return true;
 }
 
-// shared threshold of query q = score part of the k-th best key of its merged sample list (0 = fewer than k rows seen)
-__global__ __launch_bounds__(256) void seed_gtau_kernel(const u64* __restrict__ lists, long long nq, int k,
-                                                        uint32_t* __restrict__ gtau) {
-    const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (q < nq) gtau[q] = (uint32_t)(lists[q * k + k - 1] >> 32);
+// Seed of the small-batch kernel's shared thresholds: gtau[q] = order key of the k-th largest of scores[q][0 .. S) (0 when
+// S < k).  One workgroup per query: radix select over the order keys, four 8-bit digits, histogram in LDS.  Any real row's
+// score is a valid lower bound of the query's final k-th best score, so the seeded search stays exact.
+__global__ __launch_bounds__(256) void seed_select_kernel(const float* __restrict__ scores, long long ld, int S, int k,
+                                                          uint32_t* __restrict__ gtau) {
+    __shared__ uint32_t hist[256];
+    __shared__ uint32_t s_prefix, s_k;
+    const int tid = threadIdx.x;
+    const float* row = scores + (long long)blockIdx.x * ld;
+    uint32_t prefix = 0, mask = 0, kk = (uint32_t)k;  // the kk-th largest among the keys with (key & mask) == prefix
+    for (int shift = 24; shift >= 0; shift -= 8) {
+        hist[tid] = 0;
+        __syncthreads();
+        for (int i = tid; i < S; i += 256) {
+            const uint32_t key = lvs_ord32(row[i]);
+            if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            uint32_t seen = 0;
+            int b = 255;
+            for (; b >= 0; --b) {
+                if (seen + hist[b] >= kk) break;
+                seen += hist[b];
+            }
+            if (b < 0) {  // fewer than k candidates: no threshold
+                s_prefix = 0;
+                s_k = 0;
+            } else {
+                s_prefix = prefix | ((uint32_t)b << shift);
+                s_k = kk - seen;
+            }
+        }
+        __syncthreads();
+        prefix = s_prefix;
+        kk = s_k;
+        mask |= 0xFFu << shift;
+        if (kk == 0) break;
+    }
+    if (tid == 0) gtau[blockIdx.x] = kk == 0 ? 0u : prefix;
 }
 
 __global__ void copy_pass_kernel(const u64* __restrict__ src, long long nq, int kp, u64* __restrict__ dst, int k,
@@ -1002,13 +1117,14 @@ extern "C" int32_t lvs_flat_search_keys(const void* xb, int32_t xb_pack, int64_t
     }
 #endif
 
-    // HBM-bound regime (the literal sem_search: one query per call): stream the corpus once, queries resident in LDS
+    // HBM-bound regime (the literal sem_search: one query per call; small batches up to 256 queries): stream the corpus
+    // once, queries resident in LDS
     {
         const int nqseg = (xq_pack == LVS_PACK_SPLIT && !g_hi_only) ? 2 : 1;
         const int jper = p.dpad / 16;
-        int kcap = 0;
-        const bool fits = lvs_stream_plan(nq, k, nqseg * jper, &kcap) > 0;
-        const bool want = lvs_tune("LVS_STREAM", 1) != 0;
+        int kcap = 0, nqb = 0, groups = 0;
+        const bool fits = lvs_stream_plan(nq, k, nqseg * jper, &kcap, &nqb, &groups) > 0;
+        const bool want = lvs_tune("LVS_STREAM", 1) != 0 && nq <= lvs_tune("LVS_STREAM_MAXQ_RT", LVS_STREAM_MAXQ);
         if (want && fits && nb >= 4096) {
             LvsStreamArgs sa;
             memset(&sa, 0, sizeof(sa));
@@ -1031,59 +1147,50 @@ extern "C" int32_t lvs_flat_search_keys(const void* xb, int32_t xb_pack, int64_t
             sa.nj = p.nseg * jper;
             sa.nbfrag = nqseg * jper;
             sa.kcap = kcap;
+            sa.nqb = nqb;
+            sa.groups = groups;
             for (int i = 0; i < 3; ++i) {
                 sa.seg_q[i] = p.seg_q[i];
                 sa.seg_c[i] = p.seg_c[i];
                 sa.seg_b[i] = p.seg_q[i] == 0 ? 0 : jper;
             }
             LVS_HIP_CHECK(hipMemsetAsync(gtau, 0, (size_t)nq * 4, st));
-            int nparts = 0;
-            // Every workgroup scans its own contiguous range, all at the same time: without help each of the 256 starts
-            // with empty lists and pays its own cold start (~k (1 + ln(range / k)) insertions per query and workgroup -
-            // with dozens of queries that, not HBM, sets the time).  So with several queries the first rows are scanned
-            // by a short SAMPLE pass, its lists are merged, and the k-th best key of the sample seeds the shared
-            // threshold of the main pass: a workgroup then only inserts rows that beat it (~k * nb / sample per query
-            // in total instead of per workgroup).  Exact: a threshold taken from real rows never excludes a top-k row.
-            const int64_t sample = lvs_round_up(nb / 64 > 8192 ? nb / 64 : 8192, 32);
-            // Measured (1 M rows, profiles/r02_tuning.md): pays from the second query block on (-4 % at 64 queries); with
-            // up to 32 queries the extra launches cost more than the cold starts they remove (+5 .. 11 %).
-            if (nq > 32 && nb >= 8 * sample && lvs_tune("LVS_STREAM_SEED", 1) != 0) {
-                LvsStreamArgs ss = sa;
-                ss.nb = sample;
-                ss.max_wgs = 32;
-                LVS_HIP_CHECK(lvs_stream_launch(ss, st));
-                const int sparts = (int)(((sample + 31) / 32 + ss.blocks_per_wg - 1) / ss.blocks_per_wg);
-                u64* seed_list = partial + (size_t)sparts * nq * k;  // [nq][k] merged sample candidates = part `sparts`
-                hipLaunchKernelGGL(merge_keys_kernel, dim3((unsigned)lvs_ceil_div(nq, 4)), dim3(256), 0, st, partial, sparts,
-                                   (long long)nq, k, seed_list, (long long)k, (const uint32_t*)nullptr);
-                hipLaunchKernelGGL(seed_gtau_kernel, dim3((unsigned)lvs_ceil_div(nq, 256)), dim3(256), 0, st, seed_list,
-                                   (long long)nq, k, gtau);
+            // Every workgroup scans its own contiguous range, all at the same time: without help each of them starts with
+            // empty lists and pays its own cold start (~k (1 + ln(range / k)) insertions per query and workgroup - with
+            // dozens of queries that, not HBM, set the time in round 2).  So with several queries the thresholds are
+            // SEEDED: the scores of the first `sample` rows go into a small matrix (the tile kernel's SCORES epilogue, a
+            // ~20 us GEMM), a radix select takes every query's k-th largest, and the scan starts from there: a workgroup
+            // then only inserts rows that beat it (~k * nb / sample per query over the WHOLE launch).  Exact: a threshold
+            // taken from real rows never excludes a top-k row; the sample rows themselves are scanned again with the rest.
+            int64_t sample = lvs_round_up(nb / 64 > 8192 ? nb / 64 : 8192, 256);
+            if (sample > LVS_STREAM_SEED_MAX) sample = LVS_STREAM_SEED_MAX;
+            if (nq >= lvs_tune("LVS_STREAM_SEED_MINQ", 2) && nb >= 8 * sample && k <= sample && lvs_tune("LVS_STREAM_SEED", 1) != 0) {
+                float* sc = (float*)((char*)partial + lvs_stream_parts_bytes(nq, k));  // [nq][sample]
+                Plan ps;
+                LVS_REQUIRE(make_plan(nq, sample, d, xb_pack, xq_pack, 1, ps, true) == LVS_OK, "bad sample plan");
+                LvsTileArgs ta;
+                fill_args(ta, ps, nullptr, nullptr);
+                ta.nb = sample;
+                ta.row_ids = nullptr;
+                ta.id_offset = 0;
+                ta.k = 1;
+                ta.scores = sc;
+                ta.ld_scores = sample;
+                LVS_HIP_CHECK(lvs_tile_launch(LVS_MODE_SCORES, ta, st));
+                hipLaunchKernelGGL(seed_select_kernel, dim3((unsigned)nq), dim3(256), 0, st, sc, (long long)sample,
+                                   (int)sample, k, gtau);
                 LVS_HIP_CHECK(hipGetLastError());
-                // main pass over the remaining rows; its parts follow the seed list
-                sa.xb = (const char*)xb + (size_t)sample * p.ldb * 2;
-                sa.bn = xb_norms_sq ? xb_norms_sq + sample : nullptr;
-                sa.row_ids = row_ids ? row_ids + sample : nullptr;
-                sa.id_offset = id_offset + sample;
-                sa.nb = nb - sample;
-                sa.out = seed_list + (size_t)nq * k;
-                {
-                    ScopedKernelTimer timer(st);
-                    LVS_HIP_CHECK(lvs_stream_launch(sa, st));
-                }
-                const int mparts = (int)(((sa.nb + 31) / 32 + sa.blocks_per_wg - 1) / sa.blocks_per_wg);
-                hipLaunchKernelGGL(merge_keys_kernel, dim3((unsigned)lvs_ceil_div(nq, 4)), dim3(256), 0, st, seed_list,
-                                   1 + mparts, (long long)nq, k, (u64*)out_keys, (long long)k, (const uint32_t*)nullptr);
-                LVS_HIP_CHECK(hipGetLastError());
-                return LVS_OK;
             }
             {
                 ScopedKernelTimer timer(st);
                 LVS_HIP_CHECK(lvs_stream_launch(sa, st));
-                const int64_t nblocks = (nb + 31) / 32;
-                nparts = (int)((nblocks + sa.blocks_per_wg - 1) / sa.blocks_per_wg);
             }
-            hipLaunchKernelGGL(merge_keys_kernel, dim3((unsigned)lvs_ceil_div(nq, 4)), dim3(256), 0, st, partial, nparts,
-                               (long long)nq, k, (u64*)out_keys, (long long)k, (const uint32_t*)nullptr);
+            if (sa.nparts >= 16 && k <= 64)
+                hipLaunchKernelGGL(merge_keys_wide_kernel, dim3((unsigned)nq), dim3(256), 0, st, partial, sa.nparts,
+                                   (long long)nq, k, (u64*)out_keys, (long long)k);
+            else
+                hipLaunchKernelGGL(merge_keys_kernel, dim3((unsigned)lvs_ceil_div(nq, 4)), dim3(256), 0, st, partial,
+                                   sa.nparts, (long long)nq, k, (u64*)out_keys, (long long)k, (const uint32_t*)nullptr);
             LVS_HIP_CHECK(hipGetLastError());
             return LVS_OK;
         }
@@ -1268,9 +1375,9 @@ extern "C" int32_t lvs_certify_topk(const uint64_t* approx_keys, const uint64_t*
     return LVS_OK;
 }
 
-extern "C" int32_t lvs_margin_select(const uint64_t* keys, const float* second, const float* q_norms_sq, int64_t nq,
-                                     float scale, float slack, int64_t* out_idx, uint64_t* out_count, void* stream) {
-    LVS_REQUIRE(nq >= 0 && scale >= 0.f && slack >= 0.f, "bad arguments");
+static int32_t margin_select_launch(const uint64_t* keys, const float* second, const float* q_norms_sq, int64_t nq, float scale,
+                                    float slack, const float* stats, const MarginCoef& coef, int64_t* out_idx,
+                                    uint64_t* out_count, void* stream) {
     if (nq == 0) return LVS_OK;
     LVS_REQUIRE(keys && second && out_idx && out_count, "NULL buffer");
     LVS_DEVICE_GUARD(stream);
@@ -1278,10 +1385,29 @@ extern "C" int32_t lvs_margin_select(const uint64_t* keys, const float* second, 
     long long per_block = lvs_ceil_div(nq, 2048);
     per_block = lvs_round_up(per_block < 1024 ? 1024 : per_block, 256);
     hipLaunchKernelGGL(margin_select_kernel, dim3((unsigned)lvs_ceil_div(nq, per_block)), dim3(256), 0, (hipStream_t)stream,
-                       (const u64*)keys, second, q_norms_sq, (long long)nq, scale, slack, per_block, (long long*)out_idx,
-                       (unsigned long long*)out_count);
+                       (const u64*)keys, second, q_norms_sq, (long long)nq, scale, slack, stats, coef, per_block,
+                       (long long*)out_idx, (unsigned long long*)out_count);
     LVS_HIP_CHECK(hipGetLastError());
     return LVS_OK;
+}
+
+extern "C" int32_t lvs_margin_select(const uint64_t* keys, const float* second, const float* q_norms_sq, int64_t nq,
+                                     float scale, float slack, int64_t* out_idx, uint64_t* out_count, void* stream) {
+    LVS_REQUIRE(nq >= 0 && scale >= 0.f && slack >= 0.f, "bad arguments");
+    return margin_select_launch(keys, second, q_norms_sq, nq, scale, slack, nullptr, MarginCoef{{0, 0, 0, 0, 0}}, out_idx,
+                                out_count, stream);
+}
+
+extern "C" int32_t lvs_margin_select_stats(const uint64_t* keys, const float* second, const float* q_norms_sq, int64_t nq,
+                                           const float* corpus_stats, const float* coef5, int64_t* out_idx,
+                                           uint64_t* out_count, void* stream) {
+    LVS_REQUIRE(nq >= 0 && corpus_stats && coef5, "bad arguments");
+    MarginCoef c;
+    for (int i = 0; i < 5; ++i) {
+        LVS_REQUIRE(coef5[i] >= 0.f, "negative coefficient");
+        c.c[i] = coef5[i];
+    }
+    return margin_select_launch(keys, second, q_norms_sq, nq, 0.f, 0.f, corpus_stats, c, out_idx, out_count, stream);
 }
 
 extern "C" int32_t lvs_merge_keys(const uint64_t* parts, int32_t nparts, int64_t nq, int32_t k, uint64_t* out_keys,
@@ -1419,6 +1545,9 @@ extern "C" int32_t lvs_range_join(const void* xb, int32_t xb_pack, int64_t nb, c
     a.threshold = threshold;
     a.qt_stride = qt_stride;
     a.qt_phase = qt_phase;
-    LVS_HIP_CHECK(lvs_tile_launch(LVS_MODE_RANGE, a, (hipStream_t)stream));
+    {
+        ScopedKernelTimer timer((hipStream_t)stream);
+        LVS_HIP_CHECK(lvs_tile_launch(LVS_MODE_RANGE, a, (hipStream_t)stream));
+    }
     return LVS_OK;
 }

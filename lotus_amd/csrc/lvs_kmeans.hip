@@ -1,41 +1,186 @@
 // k-means pieces behind lotus.utils.cluster (lotus/utils.py:61-65 -> faiss Kmeans.train + index.search(x, 1)).
 //
-// Assignment is the tile kernel in top-1 / squared-L2 mode (lvs_flat_search_keys with k = 1).  This file holds the
-// centroid update and the host-side pieces of faiss's Clustering::train that must match bit for bit:
-//   * lvs_kmeans_accumulate: rows are bucketed by centroid with a STABLE radix sort on the assignment bits
-//     (rocPRIM), then every (centroid, 512-dim chunk) is reduced by one wave that walks its bucket in row
-//     order - the accumulation order of faiss compute_centroids, so results are reproducible run to run;
-//   * lvs_rand_perm_host / lvs_kmeans_split_clusters_host: std::mt19937-driven subsample/init permutation and
-//     empty-cluster re-seeding exactly as faiss.
+// Assignment is the tile kernel in top-1 / squared-L2 mode (lvs_flat_search_keys with k = 1, or the certified one-pass
+// lvs_nearest_hi).  This file holds everything else of an iteration, all of it on the device so that the host only
+// enqueues launches:
+//   * lvs_kmeans_accumulate(_keys): rows are bucketed by centroid with a STABLE counting sort on the centroid ids
+//     (per-chunk histogram in LDS -> exclusive scan -> in-order scatter; hand-written - round 2 used rocPRIM's radix
+//     sort), then every (centroid, 512-dim chunk) is reduced by one wave that walks its bucket in row order - the
+//     accumulation order of faiss compute_centroids, so results are reproducible run to run;
+//   * lvs_kmeans_objective: faiss's objective (sum of the assignment distances) from the sums the update needs anyway;
+//   * lvs_kmeans_update_centroids: centroid division, faiss's empty-cluster split (std::mt19937 replayed by one device
+//     thread: same draws, same decisions as faiss split_clusters), repacking of the centroids as fp16 hi|lo rows and the
+//     two norms the one-pass assignment's certificate needs;
+//   * lvs_rand_perm_host / lvs_kmeans_split_clusters_host: the host twins (training subsample, initial centroids; the
+//     split routine is kept for callers that hold the centroids on the host) - SURVEY.md Appendix A.4.
 #include <cstring>
 #include <random>
 #include <vector>
-
-#include <rocprim/rocprim.hpp>
 
 #include "lvs_common.h"
 #include "lvs_tile.h"
 
 namespace {
 
-__global__ __launch_bounds__(256) void km_keys_kernel(const long long* __restrict__ assign, long long n, int k,
-                                                      uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
-    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    long long c = assign[i];
-    keys[i] = (c < 0 || c >= k) ? (uint32_t)k : (uint32_t)c;  // out-of-range assignments go to an ignored bucket
-    vals[i] = (uint32_t)i;
+// ---- stable counting sort of the rows by centroid id -----------------------------------------------------------------
+// bins = k + 1 (the last one collects assignments outside [0, k): ignored rows).  A launch works on chunks of KM_CHUNK
+// consecutive rows, one workgroup each:
+//   km_count_kernel    counts[bin][chunk] = rows of the chunk that go to `bin`          (histogram in LDS)
+//   km_scan*_kernel    exclusive scan over counts in (bin-major, chunk-minor) order = first output position of every
+//                      (bin, chunk) run; offsets[c] = start of bucket c, c = 0 .. k
+//   km_scatter_kernel  rows_out[position] = row, in row order inside a chunk (waves of a tile take turns, lanes rank
+//                      themselves among the lanes with the same bin by ballots over the bin's bits)
+// Rows keep their order inside a bucket, which is what makes the centroid sums independent of the launch shape.
+constexpr int KM_CHUNK = 8192;
+constexpr int KM_SCAN_SEG = 2048;   // entries per workgroup of the scan
+constexpr int KM_MAX_BINS = 24576;  // (k + 1) * 4 B of LDS per workgroup; larger k sorts by two digits
+
+template <typename KeyT>
+__device__ inline uint32_t km_bin_of(KeyT v, long long id_offset, int k);
+template <>
+__device__ inline uint32_t km_bin_of<long long>(long long c, long long, int k) {
+    return (c < 0 || c >= k) ? (uint32_t)k : (uint32_t)c;
+}
+template <>
+__device__ inline uint32_t km_bin_of<u64>(u64 key, long long id_offset, int k) {  // a result key: id in the low word
+    if (key == 0) return (uint32_t)k;
+    const long long c = (long long)(0xFFFFFFFFu - (uint32_t)(key & 0xFFFFFFFFull)) - id_offset;
+    return (c < 0 || c >= k) ? (uint32_t)k : (uint32_t)c;
 }
 
-// bucket boundaries from the SORTED keys: offsets[c] = first position whose key is >= c, c = 0..k
-// (no atomics: position i writes the offsets of every centroid whose bucket starts there; k + 1 writes in total)
-__global__ __launch_bounds__(256) void km_bounds_kernel(const uint32_t* __restrict__ sorted_keys, long long n, int k,
+// digit of a row: ((bin >> shift) & mask); rows are read through `order` (nullable: identity) so that a second pass can
+// sort the output of the first
+template <typename KeyT>
+__global__ __launch_bounds__(256) void km_count_kernel(const KeyT* __restrict__ assign, const uint32_t* __restrict__ order,
+                                                       long long n, int k, long long id_offset, int shift, uint32_t mask,
+                                                       int nbins, int nchunks, uint32_t* __restrict__ counts) {
+    extern __shared__ uint32_t km_hist[];
+    for (int b = threadIdx.x; b < nbins; b += 256) km_hist[b] = 0;
+    __syncthreads();
+    const long long r0 = (long long)blockIdx.x * KM_CHUNK;
+    const long long r1 = r0 + KM_CHUNK < n ? r0 + KM_CHUNK : n;
+    for (long long i = r0 + threadIdx.x; i < r1; i += 256) {
+        const long long row = order ? (long long)order[i] : i;
+        atomicAdd(&km_hist[(km_bin_of<KeyT>(assign[row], id_offset, k) >> shift) & mask], 1u);
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b < nbins; b += 256) counts[(long long)b * nchunks + blockIdx.x] = km_hist[b];
+}
+
+// exclusive scan, three launches: per-segment scan + segment totals, scan of the totals (one workgroup), add
+__global__ __launch_bounds__(256) void km_scan1_kernel(uint32_t* __restrict__ v, long long total, uint32_t* __restrict__ seg_sum) {
+    __shared__ uint32_t part[256];
+    const long long base = (long long)blockIdx.x * KM_SCAN_SEG + (long long)threadIdx.x * (KM_SCAN_SEG / 256);
+    uint32_t loc[KM_SCAN_SEG / 256], sum = 0;
+#pragma unroll
+    for (int i = 0; i < KM_SCAN_SEG / 256; ++i) {
+        loc[i] = base + i < total ? v[base + i] : 0u;
+        sum += loc[i];
+    }
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {  // Hillis-Steele inclusive scan of the 256 thread sums
+        const uint32_t add = threadIdx.x >= off ? part[threadIdx.x - off] : 0u;
+        __syncthreads();
+        part[threadIdx.x] += add;
+        __syncthreads();
+    }
+    uint32_t run = part[threadIdx.x] - sum;  // exclusive prefix of this thread inside the segment
+#pragma unroll
+    for (int i = 0; i < KM_SCAN_SEG / 256; ++i) {
+        if (base + i < total) v[base + i] = run;
+        run += loc[i];
+    }
+    if (threadIdx.x == 255) seg_sum[blockIdx.x] = part[255];
+}
+__global__ __launch_bounds__(256) void km_scan2_kernel(uint32_t* __restrict__ seg_sum, int nseg) {
+    __shared__ uint32_t part[256];
+    __shared__ uint32_t carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int s0 = 0; s0 < nseg; s0 += 256) {
+        const int i = s0 + threadIdx.x;
+        const uint32_t mine = i < nseg ? seg_sum[i] : 0u;
+        part[threadIdx.x] = mine;
+        __syncthreads();
+        for (int off = 1; off < 256; off <<= 1) {
+            const uint32_t add = threadIdx.x >= off ? part[threadIdx.x - off] : 0u;
+            __syncthreads();
+            part[threadIdx.x] += add;
+            __syncthreads();
+        }
+        if (i < nseg) seg_sum[i] = carry + part[threadIdx.x] - mine;
+        __syncthreads();
+        if (threadIdx.x == 255) carry += part[255];
+        __syncthreads();
+    }
+}
+// v += its segment's offset; offsets[b] = v[b * nchunks] for b = 0 .. nbuckets (start of every bucket; written only when
+// `offsets` is given - the last digit pass)
+__global__ __launch_bounds__(256) void km_scan3_kernel(uint32_t* __restrict__ v, long long total,
+                                                       const uint32_t* __restrict__ seg_sum, int nchunks,
+                                                       uint32_t* __restrict__ offsets, int nbuckets) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < total) {
+        const uint32_t val = v[i] + seg_sum[i / KM_SCAN_SEG];
+        v[i] = val;
+        if (offsets && i % nchunks == 0 && i / nchunks <= nbuckets) offsets[i / nchunks] = val;
+    }
+}
+
+// bucket boundaries from the SORTED rows (two-digit sorts only): offsets[c] = first position whose bin is >= c, c = 0..k
+// (no atomics: position i writes the offsets of every bucket that starts there; k + 1 writes in total)
+template <typename KeyT>
+__global__ __launch_bounds__(256) void km_bounds_kernel(const KeyT* __restrict__ assign, const uint32_t* __restrict__ rows,
+                                                        long long n, int k, long long id_offset,
                                                         uint32_t* __restrict__ offsets) {
-    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i > n) return;
-    const long long lo = i == 0 ? 0 : (long long)sorted_keys[i - 1] + 1;
-    const long long hi = i == n ? (long long)k : (long long)sorted_keys[i];
+    const long long lo = i == 0 ? 0 : (long long)km_bin_of<KeyT>(assign[rows[i - 1]], id_offset, k) + 1;
+    const long long hi = i == n ? (long long)k : (long long)km_bin_of<KeyT>(assign[rows[i]], id_offset, k);
     for (long long c = lo; c <= hi && c <= k; ++c) offsets[c] = (uint32_t)i;
+}
+
+template <typename KeyT>
+__global__ __launch_bounds__(256) void km_scatter_kernel(const KeyT* __restrict__ assign, const uint32_t* __restrict__ order,
+                                                         long long n, int k, long long id_offset, int shift, uint32_t mask,
+                                                         int nbins, int nbits, int nchunks,
+                                                         const uint32_t* __restrict__ counts, uint32_t* __restrict__ rows_out) {
+    extern __shared__ uint32_t km_pos[];  // next output position of every bin for this chunk
+    for (int b = threadIdx.x; b < nbins; b += 256) km_pos[b] = counts[(long long)b * nchunks + blockIdx.x];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long r0 = (long long)blockIdx.x * KM_CHUNK;
+    const long long r1 = r0 + KM_CHUNK < n ? r0 + KM_CHUNK : n;
+    for (long long t0 = r0; t0 < r1; t0 += 256) {
+        const long long i = t0 + threadIdx.x;
+        const bool live = i < r1;
+        uint32_t row = 0, bin = 0;
+        if (live) {
+            row = order ? order[i] : (uint32_t)i;
+            bin = (km_bin_of<KeyT>(assign[row], id_offset, k) >> shift) & mask;
+        }
+        // lanes of this wave holding the same bin (dead lanes match nobody)
+        u64 peers = __builtin_amdgcn_ballot_w64(live);
+        for (int b = 0; b < nbits; ++b) {
+            const u64 m = __builtin_amdgcn_ballot_w64(live && ((bin >> b) & 1u));
+            peers &= ((bin >> b) & 1u) ? m : ~m;
+        }
+        const int rank = __popcll(peers & ((1ull << lane) - 1ull));
+        const int cnt = __popcll(peers);
+        uint32_t base = 0;
+        for (int w = 0; w < 4; ++w) {  // waves take turns: rows of wave w come before those of wave w + 1
+            if (wave == w && live && rank == 0) {
+                base = km_pos[bin];
+                km_pos[bin] = base + (uint32_t)cnt;
+            }
+            __syncthreads();
+        }
+        // the leader's base -> its peers
+        const int leader = live ? __ffsll((long long)peers) - 1 : lane;
+        base = __shfl(base, leader, 64);
+        if (live) rows_out[base + (uint32_t)rank] = row;
+    }
 }
 
 typedef _Float16 km_half8 __attribute__((ext_vector_type(8)));
@@ -116,16 +261,202 @@ __global__ __launch_bounds__(256) void unpack_rows_kernel(const _Float16* __rest
 
 }  // namespace
 
-extern "C" int32_t lvs_kmeans_update_centroids(const float* sums, const float* counts, int32_t k, int32_t d,
-                                               float* centroids, void* stream) {
+// ---- objective, empty-cluster split and centroid statistics on the device ------------------------------------------------
+namespace {
+__device__ inline double km_wave_sum_d(double v) {
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) {
+        const long long b = __double_as_longlong(v);
+        const int lo = __shfl_xor((int)(b & 0xFFFFFFFFll), m, 64), hi = __shfl_xor((int)(b >> 32), m, 64);
+        v += __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+    }
+    return v;
+}
+// part[j] = -2 <c_j, S_j> + n_j |c_j|^2 in float64 (one wave per centroid; fixed summation order)
+__global__ __launch_bounds__(256) void km_obj_part_kernel(const float* __restrict__ c, const float* __restrict__ sums,
+                                                          const float* __restrict__ counts, int k, int d,
+                                                          double* __restrict__ part) {
+    const int lane = threadIdx.x & 63;
+    const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (j >= k) return;
+    double dot = 0.0, nn = 0.0;
+    for (int t = lane; t < d; t += 64) {
+        const double cv = (double)c[(long long)j * d + t];
+        dot += cv * (double)sums[(long long)j * d + t];
+        nn += cv * cv;
+    }
+    dot = km_wave_sum_d(dot);
+    nn = km_wave_sum_d(nn);
+    if (lane == 0) part[j] = -2.0 * dot + (double)counts[j] * nn;
+}
+// out[0] = x2 + sum_j part[j]  (one workgroup, fixed order)
+__global__ __launch_bounds__(256) void km_obj_sum_kernel(const double* __restrict__ part, int k, const double* __restrict__ x2,
+                                                         double* __restrict__ out) {
+    __shared__ double sm[256];
+    double acc = 0.0;
+    for (int j = threadIdx.x; j < k; j += 256) acc += part[j];
+    sm[threadIdx.x] = acc;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) sm[threadIdx.x] += sm[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = (x2 ? x2[0] : 0.0) + sm[0];
+}
+
+// faiss split_clusters on the device: ONE wave; lane 0 replays std::mt19937(1234) and takes every decision exactly as the
+// host twin (lvs_kmeans_split_clusters_host), all lanes copy / perturb the centroid rows.  hassign (= the counts) is
+// modified in place as faiss does.  Nothing happens - not even the generator's set-up - unless some cluster is empty.
+struct KmMt {
+    uint32_t* mt;
+    int idx;
+    __device__ void seed(uint32_t s) {
+        mt[0] = s;
+        for (int i = 1; i < 624; ++i) mt[i] = 1812433253u * (mt[i - 1] ^ (mt[i - 1] >> 30)) + (uint32_t)i;
+        idx = 624;
+    }
+    __device__ uint32_t next() {
+        if (idx >= 624) {
+            for (int i = 0; i < 624; ++i) {
+                const uint32_t y = (mt[i] & 0x80000000u) | (mt[(i + 1) % 624] & 0x7FFFFFFFu);
+                mt[i] = mt[(i + 397) % 624] ^ (y >> 1) ^ ((y & 1u) ? 0x9908B0DFu : 0u);
+            }
+            idx = 0;
+        }
+        uint32_t y = mt[idx++];
+        y ^= y >> 11;
+        y ^= (y << 7) & 0x9D2C5680u;
+        y ^= (y << 15) & 0xEFC60000u;
+        y ^= y >> 18;
+        return y;
+    }
+};
+__global__ __launch_bounds__(64) void km_split_kernel(int d, int k, long long n, float* hassign_, float* __restrict__ centroids,
+                                                      int* __restrict__ out_nsplit) {
+    __shared__ uint32_t state[624];
+    const int lane = threadIdx.x;
+    volatile float* hassign = hassign_;
+    bool any = false;
+    for (int c = lane; c < k; c += 64) any |= hassign[c] == 0.f;
+    if (__builtin_amdgcn_ballot_w64(any) == 0ull || n <= k) {
+        if (lane == 0 && out_nsplit) *out_nsplit = 0;
+        return;
+    }
+    KmMt rng{state, 624};
+    if (lane == 0) rng.seed(1234u);
+    const float EPS = 1.0f / 1024.0f;
+    int nsplit = 0;
+    for (int ci = 0; ci < k; ++ci) {
+        int cj = -1;
+        if (lane == 0 && hassign[ci] == 0.f) {
+            for (cj = 0;; cj = (cj + 1) % k) {
+                const float p = (hassign[cj] - 1.0f) / (float)(n - k);
+                const float r = (float)rng.next() / 4294967295.0f;  // faiss rand_float(): mt() / float(mt.max())
+                if (r < p) break;
+            }
+            const float half = hassign[cj] / 2;
+            hassign[ci] = half;
+            hassign[cj] = hassign[cj] - half;
+        }
+        cj = __shfl(cj, 0, 64);
+        if (cj < 0) continue;
+        float* a = centroids + (long long)ci * d;
+        float* b = centroids + (long long)cj * d;
+        for (int j = lane; j < d; j += 64) {  // a lane only ever touches its own columns: later splits see these writes
+            const float v = b[j];
+            if (j % 2 == 0) {
+                a[j] = v * (1 + EPS);
+                b[j] = v * (1 - EPS);
+            } else {
+                a[j] = v * (1 - EPS);
+                b[j] = v * (1 + EPS);
+            }
+        }
+        ++nsplit;
+    }
+    if (lane == 0 && out_nsplit) *out_nsplit = nsplit;
+}
+
+// stats[0] = max |row|^2 (of the stored values), stats[1] = max |lo part of a row|^2: what the one-pass assignment's
+// certificate needs of the centroids (non-negative floats order like their bit patterns: atomicMax on the bits)
+__global__ __launch_bounds__(256) void km_stats_kernel(const _Float16* __restrict__ rows, long long ld, int dpad, int split,
+                                                       const float* __restrict__ norms, int k, float* __restrict__ stats) {
+    const int lane = threadIdx.x & 63;
+    const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (j >= k) return;
+    float e = 0.f;
+    if (split)
+        for (int t = lane; t < dpad; t += 64) {
+            const float v = (float)rows[(long long)j * ld + dpad + t];
+            e += v * v;
+        }
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) e += __shfl_xor(e, m, 64);
+    if (lane == 0) {
+        atomicMax((unsigned int*)&stats[0], __float_as_uint(norms[j]));
+        atomicMax((unsigned int*)&stats[1], __float_as_uint(e));
+    }
+}
+
+int32_t km_pack_and_stats(const float* centroids, int32_t k, int32_t d, int32_t pack_mode, void* packed_out, float* norms_out,
+                          float* stats_out, hipStream_t st) {
+    int32_t rc = lvs_pack_rows(centroids, LVS_DTYPE_F32, k, d, pack_mode, 0, packed_out, norms_out, st);
+    if (rc != LVS_OK) return rc;
+    if (stats_out) {
+        const int dpad = (int)lvs_round_up(d, LVS_BK);
+        const int split = pack_mode == LVS_PACK_SPLIT;
+        LVS_HIP_CHECK(hipMemsetAsync(stats_out, 0, 2 * sizeof(float), st));
+        hipLaunchKernelGGL(km_stats_kernel, dim3((unsigned)lvs_ceil_div(k, 4)), dim3(256), 0, st, (const _Float16*)packed_out,
+                           (long long)(split ? 2 * dpad : dpad), dpad, split, (const float*)norms_out, k, stats_out);
+        LVS_HIP_CHECK(hipGetLastError());
+    }
+    return LVS_OK;
+}
+}  // namespace
+
+extern "C" int64_t lvs_kmeans_objective_workspace_bytes(int32_t k) { return k > 0 ? lvs_round_up((int64_t)k * 8, 256) : LVS_EINVAL; }
+
+extern "C" int32_t lvs_kmeans_objective(const float* centroids, const float* sums, const float* counts, int32_t k, int32_t d,
+                                        const double* x_norms_sq_sum, double* out_obj, void* workspace,
+                                        int64_t workspace_bytes, void* stream) {
+    LVS_REQUIRE(k > 0 && d > 0, "bad shape k=%d d=%d", k, d);
+    LVS_REQUIRE(centroids && sums && counts && out_obj && workspace, "NULL buffer");
+    LVS_REQUIRE(workspace_bytes >= lvs_kmeans_objective_workspace_bytes(k), "workspace too small");
+    LVS_DEVICE_GUARD(stream);
+    hipStream_t st = (hipStream_t)stream;
+    double* part = (double*)workspace;
+    hipLaunchKernelGGL(km_obj_part_kernel, dim3((unsigned)lvs_ceil_div(k, 4)), dim3(256), 0, st, centroids, sums, counts, k, d, part);
+    hipLaunchKernelGGL(km_obj_sum_kernel, dim3(1), dim3(256), 0, st, (const double*)part, k, x_norms_sq_sum, out_obj);
+    LVS_HIP_CHECK(hipGetLastError());
+    return LVS_OK;
+}
+
+extern "C" int32_t lvs_kmeans_pack_centroids(const float* centroids, int32_t k, int32_t d, int32_t pack_mode, void* packed_out,
+                                             float* norms_out, float* stats_out, void* stream) {
+    LVS_REQUIRE(k > 0 && d > 0, "bad shape k=%d d=%d", k, d);
+    LVS_REQUIRE(centroids && packed_out && norms_out, "NULL buffer");
+    LVS_DEVICE_GUARD(stream);
+    return km_pack_and_stats(centroids, k, d, pack_mode, packed_out, norms_out, stats_out, (hipStream_t)stream);
+}
+
+extern "C" int32_t lvs_kmeans_update_centroids(const float* sums, float* counts, int32_t k, int32_t d, int64_t n_train,
+                                               float* centroids, int32_t* out_nsplit, int32_t pack_mode, void* packed_out,
+                                               float* norms_out, float* stats_out, void* stream) {
     LVS_REQUIRE(k > 0 && d > 0, "bad shape k=%d d=%d", k, d);
     LVS_REQUIRE(sums && counts && centroids, "NULL buffer");
     LVS_DEVICE_GUARD(stream);
+    hipStream_t st = (hipStream_t)stream;
     const long long total = (long long)k * d;
     const long long blocks = lvs_ceil_div(total, 256);
-    hipLaunchKernelGGL(km_update_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0,
-                       (hipStream_t)stream, sums, counts, total, d, centroids);
+    hipLaunchKernelGGL(km_update_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, st, sums,
+                       (const float*)counts, total, d, centroids);
+    if (n_train > 0)  // faiss: split_clusters right after compute_centroids; n_train <= 0 skips it (caller splits on the host)
+        hipLaunchKernelGGL(km_split_kernel, dim3(1), dim3(64), 0, st, d, k, (long long)n_train, counts, centroids, out_nsplit);
     LVS_HIP_CHECK(hipGetLastError());
+    if (packed_out) {
+        LVS_REQUIRE(norms_out, "norms_out is NULL");
+        return km_pack_and_stats(centroids, k, d, pack_mode, packed_out, norms_out, stats_out, st);
+    }
     return LVS_OK;
 }
 
@@ -145,66 +476,154 @@ extern "C" int32_t lvs_unpack_rows(const void* src, int32_t d, int32_t pack_mode
     return LVS_OK;
 }
 
-extern "C" int64_t lvs_kmeans_accumulate_workspace_bytes(int64_t n, int32_t k) {
-    if (n < 0 || k <= 0) return LVS_EINVAL;
-    size_t tmp = 0;
-    uint32_t* nil = nullptr;
-    (void)rocprim::radix_sort_pairs(nullptr, tmp, nil, nil, nil, nil, (size_t)(n > 0 ? n : 1), 0u, 32u);
-    int64_t bytes = lvs_round_up((int64_t)tmp, 256);
-    bytes += 4 * lvs_round_up(n * 4, 256);             // keys in/out, vals in/out
-    bytes += 2 * lvs_round_up((int64_t)(k + 2) * 4, 256);  // bucket offsets (+ spare)
-    return bytes;
+namespace {
+int km_bits(int nbins) {
+    int b = 1;
+    while ((1 << b) < nbins) ++b;
+    return b;
+}
+struct KmSortPlan {
+    int nchunks, passes, nbins[2], shift[2];
+    uint32_t mask[2];
+    int64_t off_counts, off_seg, off_rows_a, off_rows_b, off_offs, total;
+};
+bool km_sort_plan(int64_t n, int32_t k, KmSortPlan& p) {
+    if (n < 0 || k <= 0 || n >= 0xFFFFFFFFll) return false;
+    p.nchunks = (int)lvs_ceil_div(n > 0 ? n : 1, KM_CHUNK);
+    if (k + 1 <= KM_MAX_BINS) {
+        p.passes = 1;
+        p.nbins[0] = k + 1;
+        p.shift[0] = 0;
+        p.mask[0] = 0xFFFFFFFFu;
+        p.nbins[1] = 0;
+        p.shift[1] = 0;
+        p.mask[1] = 0;
+    } else {  // two stable passes: low 12 bits, then the rest
+        p.passes = 2;
+        p.nbins[0] = 4096;
+        p.shift[0] = 0;
+        p.mask[0] = 4095u;
+        p.nbins[1] = (k >> 12) + 1;
+        p.shift[1] = 12;
+        p.mask[1] = 0xFFFFFFFFu;
+        if (p.nbins[1] > KM_MAX_BINS) return false;  // k >= 2^26.5: not a k-means anyone runs
+    }
+    const int64_t maxbins = p.nbins[0] > p.nbins[1] ? p.nbins[0] : p.nbins[1];
+    int64_t off = 0;
+    p.off_counts = off;
+    off += lvs_round_up(maxbins * p.nchunks * 4, 256);
+    p.off_seg = off;
+    off += lvs_round_up(lvs_ceil_div(maxbins * p.nchunks, KM_SCAN_SEG) * 4 + 4, 256);
+    p.off_rows_a = off;
+    off += lvs_round_up(n * 4, 256);
+    p.off_rows_b = off;
+    off += p.passes > 1 ? lvs_round_up(n * 4, 256) : 0;
+    p.off_offs = off;
+    off += lvs_round_up((int64_t)(k + 2) * 4, 256);
+    p.total = off;
+    return true;
 }
 
-extern "C" int32_t lvs_kmeans_accumulate(const void* x, int64_t n, int32_t d, int32_t pack_mode, const int64_t* assign,
-                                         int32_t k, float* sums, float* counts, void* workspace, int64_t workspace_bytes,
-                                         void* stream) {
+// rows bucketed by centroid: *rows_out [n] = row numbers, bucket after bucket, ascending inside a bucket; *offs_out [k + 1]
+template <typename KeyT>
+int32_t km_bucket_rows(const KeyT* assign, int64_t n, int32_t k, int64_t id_offset, const KmSortPlan& p, char* w,
+                       hipStream_t st, const uint32_t** rows_out, const uint32_t** offs_out) {
+    uint32_t* counts = (uint32_t*)(w + p.off_counts);
+    uint32_t* seg = (uint32_t*)(w + p.off_seg);
+    uint32_t* rows[2] = {(uint32_t*)(w + p.off_rows_a), (uint32_t*)(w + p.off_rows_b)};
+    uint32_t* offs = (uint32_t*)(w + p.off_offs);
+    const uint32_t* order = nullptr;
+    for (int ps = 0; ps < p.passes; ++ps) {
+        const int nbins = p.nbins[ps];
+        const size_t lds = (size_t)nbins * 4;
+        const long long total = (long long)nbins * p.nchunks;
+        const int nseg = (int)lvs_ceil_div(total, KM_SCAN_SEG);
+        const bool last = ps + 1 == p.passes;
+        hipLaunchKernelGGL((km_count_kernel<KeyT>), dim3((unsigned)p.nchunks), dim3(256), lds, st, assign, order,
+                           (long long)n, k, (long long)id_offset, p.shift[ps], p.mask[ps], nbins, p.nchunks, counts);
+        hipLaunchKernelGGL(km_scan1_kernel, dim3((unsigned)nseg), dim3(256), 0, st, counts, total, seg);
+        hipLaunchKernelGGL(km_scan2_kernel, dim3(1), dim3(256), 0, st, seg, nseg);
+        hipLaunchKernelGGL(km_scan3_kernel, dim3((unsigned)lvs_ceil_div(total, 256)), dim3(256), 0, st, counts, total,
+                           (const uint32_t*)seg, p.nchunks, (p.passes == 1 && last) ? offs : (uint32_t*)nullptr, k);
+        hipLaunchKernelGGL((km_scatter_kernel<KeyT>), dim3((unsigned)p.nchunks), dim3(256), lds, st, assign, order,
+                           (long long)n, k, (long long)id_offset, p.shift[ps], p.mask[ps], nbins, km_bits(nbins),
+                           p.nchunks, (const uint32_t*)counts, rows[ps]);
+        order = rows[ps];
+    }
+    if (p.passes > 1)
+        hipLaunchKernelGGL((km_bounds_kernel<KeyT>), dim3((unsigned)lvs_ceil_div(n + 1, 256)), dim3(256), 0, st, assign,
+                           order, (long long)n, k, (long long)id_offset, offs);
+    LVS_HIP_CHECK(hipGetLastError());
+    *rows_out = order;
+    *offs_out = offs;
+    return LVS_OK;
+}
+
+template <typename KeyT>
+int32_t km_accumulate(const void* x, int64_t n, int32_t d, int32_t pack_mode, const KeyT* assign, int64_t id_offset,
+                      int32_t k, float* sums, float* counts, void* workspace, int64_t workspace_bytes, void* stream) {
     LVS_REQUIRE(n >= 0 && d > 0 && k > 0, "bad shape n=%lld d=%d k=%d", (long long)n, d, k);
     LVS_REQUIRE(pack_mode == LVS_PACK_F16 || pack_mode == LVS_PACK_SPLIT, "bad pack_mode");
     LVS_REQUIRE(n < 0xFFFFFFFFll, "n must be below 2^32");
     if (n == 0) return LVS_OK;
     LVS_REQUIRE(x && assign && sums && counts && workspace, "NULL buffer");
-    const int64_t need = lvs_kmeans_accumulate_workspace_bytes(n, k);
-    if (workspace_bytes < need) {
-        lvs_set_error("workspace too small: need %lld bytes", (long long)need);
+    KmSortPlan p;
+    LVS_REQUIRE(km_sort_plan(n, k, p), "k=%d is beyond the bucket sort", k);
+    if (workspace_bytes < p.total) {
+        lvs_set_error("workspace too small: need %lld bytes", (long long)p.total);
         return LVS_ENOMEM;
     }
     LVS_DEVICE_GUARD(stream);
     hipStream_t st = (hipStream_t)stream;
-    size_t tmp = 0;
-    uint32_t* nil = nullptr;
-    (void)rocprim::radix_sort_pairs(nullptr, tmp, nil, nil, nil, nil, (size_t)n, 0u, 32u);
-    char* w = (char*)workspace;
-    void* d_tmp = w;
-    w += lvs_round_up((int64_t)tmp, 256);
-    uint32_t* keys_in = (uint32_t*)w;
-    w += lvs_round_up(n * 4, 256);
-    uint32_t* keys_out = (uint32_t*)w;
-    w += lvs_round_up(n * 4, 256);
-    uint32_t* vals_in = (uint32_t*)w;
-    w += lvs_round_up(n * 4, 256);
-    uint32_t* vals_out = (uint32_t*)w;
-    w += lvs_round_up(n * 4, 256);
-    uint32_t* offs = (uint32_t*)w;
-
-    hipLaunchKernelGGL(km_keys_kernel, dim3((unsigned)lvs_ceil_div(n, 256)), dim3(256), 0, st, (const long long*)assign,
-                       (long long)n, k, keys_in, vals_in);
-    unsigned bits = 1;
-    while ((1u << bits) < (unsigned)(k + 1)) ++bits;
-    LVS_HIP_CHECK(rocprim::radix_sort_pairs(d_tmp, tmp, keys_in, keys_out, vals_in, vals_out, (size_t)n, 0u, bits, st));
-    hipLaunchKernelGGL(km_bounds_kernel, dim3((unsigned)lvs_ceil_div(n + 1, 256)), dim3(256), 0, st, keys_out,
-                       (long long)n, k, offs);
+    static LvsPerDeviceOnce attr_count, attr_scatter;  // > 64 KB of dynamic LDS needs the attribute (per device)
+    {
+        int dev = 0;
+        LVS_HIP_CHECK(hipGetDevice(&dev));
+        const size_t lds = (size_t)KM_MAX_BINS * 4;
+        if (!attr_count.done(dev, lds)) {
+            LVS_HIP_CHECK(hipFuncSetAttribute((const void*)km_count_kernel<KeyT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr_count.set(dev, lds);
+        }
+        if (!attr_scatter.done(dev, lds)) {
+            LVS_HIP_CHECK(hipFuncSetAttribute((const void*)km_scatter_kernel<KeyT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr_scatter.set(dev, lds);
+        }
+    }
+    const uint32_t *rows = nullptr, *offs = nullptr;
+    const int32_t rc = km_bucket_rows<KeyT>(assign, n, k, id_offset, p, (char*)workspace, st, &rows, &offs);
+    if (rc != LVS_OK) return rc;
     const int dpad = (int)lvs_round_up(d, LVS_BK);
     const long long ld = pack_mode == LVS_PACK_SPLIT ? 2 * dpad : dpad;
     const dim3 grid((unsigned)k, (unsigned)lvs_ceil_div(dpad, 512));
     if (pack_mode == LVS_PACK_SPLIT)
-        hipLaunchKernelGGL(km_reduce_kernel<1>, grid, dim3(64), 0, st, (const _Float16*)x, ld, d, dpad, vals_out, offs,
-                           sums, counts);
+        hipLaunchKernelGGL(km_reduce_kernel<1>, grid, dim3(64), 0, st, (const _Float16*)x, ld, d, dpad, rows, offs, sums,
+                           counts);
     else
-        hipLaunchKernelGGL(km_reduce_kernel<0>, grid, dim3(64), 0, st, (const _Float16*)x, ld, d, dpad, vals_out, offs,
-                           sums, counts);
+        hipLaunchKernelGGL(km_reduce_kernel<0>, grid, dim3(64), 0, st, (const _Float16*)x, ld, d, dpad, rows, offs, sums,
+                           counts);
     LVS_HIP_CHECK(hipGetLastError());
     return LVS_OK;
+}
+}  // namespace
+
+extern "C" int64_t lvs_kmeans_accumulate_workspace_bytes(int64_t n, int32_t k) {
+    KmSortPlan p;
+    if (!km_sort_plan(n, k, p)) return LVS_EINVAL;
+    return p.total;
+}
+
+extern "C" int32_t lvs_kmeans_accumulate(const void* x, int64_t n, int32_t d, int32_t pack_mode, const int64_t* assign,
+                                         int32_t k, float* sums, float* counts, void* workspace, int64_t workspace_bytes,
+                                         void* stream) {
+    return km_accumulate<long long>(x, n, d, pack_mode, (const long long*)assign, 0, k, sums, counts, workspace,
+                                    workspace_bytes, stream);
+}
+
+extern "C" int32_t lvs_kmeans_accumulate_keys(const void* x, int64_t n, int32_t d, int32_t pack_mode, const uint64_t* keys,
+                                              int64_t id_offset, int32_t k, float* sums, float* counts, void* workspace,
+                                              int64_t workspace_bytes, void* stream) {
+    return km_accumulate<u64>(x, n, d, pack_mode, (const u64*)keys, id_offset, k, sums, counts, workspace, workspace_bytes,
+                              stream);
 }
 
 // ---- host-side pieces of faiss Clustering (bit-exact: std::mt19937 is the generator faiss uses) -------------

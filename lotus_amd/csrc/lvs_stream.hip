@@ -1,46 +1,60 @@
-// Small-batch search kernel: up to 64 queries (LVS_STREAM_MAXQ) against the whole corpus shard - the HBM-bound regime of the path
-// (the literal `sem_search` operator issues ONE query per call: lotus/sem_ops/sem_search.py:121-122 -> faiss_vs.py:75;
-// small sim-joins and batched searches send a few dozen).
+// Small-batch search kernel: up to LVS_STREAM_MAXQ (256) queries against the whole corpus shard - the HBM-bound regime of the
+// path (the literal `sem_search` operator issues ONE query per call: lotus/sem_ops/sem_search.py:121-122 -> faiss_vs.py:75;
+// its K-doubling loop, small sim-joins and batched searches send a few dozen to a few hundred).
 //
 // Roofline: HBM.  Algorithmic bytes per launch = nb * ld * 2 (every corpus byte exactly once) + O(nq * ld);
 // at 1 M x 768 fp16 that is 1.536 GB -> 0.19 ms at 8 TB/s.  Nothing is staged through LDS except the queries:
 //   * the queries live in LDS for the whole kernel, laid out as ready-made MFMA B fragments, one set per block of 32
-//     queries ([NQB][K/16][64 lanes][16 B], lane-linear -> conflict-free ds_read_b128); NQB = 1, 2 or 3 blocks, as many
-//     as LDS holds (d = 768 fp16: 48 KB per block);
+//     queries ([NQB][K/16][64 lanes][16 B], lane-linear -> conflict-free ds_read_b128); NQB = 1 or 2 blocks per workgroup
+//     (d = 768 fp16: 48 KB per block);
 //   * corpus rows stream from HBM straight into registers as A fragments (lane (r, h) reads 16 B of row r; the two
 //     half-wave lanes of a row cover 32 contiguous bytes, four consecutive K-slices one 128-B line), UNROLL loads
-//     (1 KB each per wave) in flight ahead of the MFMAs; every fragment feeds NQB MFMAs (one per query block), so up to
-//     96 queries ride on ONE pass over the corpus;
+//     (1 KB each per wave) in flight ahead of the MFMAs; every fragment feeds NQB MFMAs (one per query block);
+//   * WAVES = 4 (one query block: 2-3 workgroups per CU) or 8 (two query blocks: 96 KB of fragments leave room for one
+//     workgroup per CU, so the workgroup itself carries the 128 KB of loads in flight that HBM needs - round 2's 4 waves
+//     x 16 KB were latency-bound);
+//   * more than 64 queries: G = 2 or 4 SIBLING workgroups (same XCD, consecutive dispatch slots) stream the SAME corpus
+//     range, each with its own 64 queries in LDS.  The first sibling to touch a line pulls it from HBM, the others find it
+//     in that XCD's L2 (or the memory-side cache): HBM still sees every corpus byte once, the L2 -> CU path carries it G
+//     times (G x 31 GB/s per CU at 8 TB/s - within the 64 B / clock of a CU's vector memory path for G <= 4);
 //   * each wave owns 32-row blocks: 32 x 32 x K product per query block on v_mfma_f32_32x32x16_f16, operands swapped as
 //     in the tile kernels (corpus = A, queries = B) so that a lane owns one query column and its threshold is a register;
 //   * hits go through the same wave-cooperative sorted insertion into per-query lists (LDS, a.kcap slots per query, one
-//     lock per query because the 4 waves of a workgroup share the queries); thresholds are shared across workgroups
-//     through the global per-query word; every workgroup writes its k candidates and lvs_merge_keys finishes.
+//     lock per query because the waves of a workgroup share the queries).  With several queries the thresholds are SEEDED
+//     (lvs_flat_search_keys): the k-th best score of the first ~nb/64 rows, taken from a small score matrix, so that a
+//     workgroup only inserts rows that beat it (~k nb / sample per query over the whole launch) instead of building its
+//     lists from cold (~k (1 + ln(rows / k)) insertions per query AND workgroup - with dozens of queries that, not HBM, set
+//     the time in round 2).  Exact: a threshold taken from real rows never excludes a top-k row.  Thresholds are also
+//     shared across workgroups through the global per-query word; every workgroup writes its k candidates and the merge
+//     kernel finishes.
 #include "lvs_common.h"
 #include "lvs_tile.h"
 
 namespace {
 
 constexpr int SQ = 32;          // queries per query block (MFMA N)
-constexpr int WAVES = 4;        // waves per workgroup
 // UNROLL = A-fragment loads in flight per wave (1 KB each) = fragments per inner-loop iteration: a template parameter so
 // that the branch-free fast path exists for every row length whose fragment count per K segment is a multiple of 8:
 //   16 (d = 256, 512, 768, 1024, ...), 24 (d = 384 - BASELINE configs[0]'s dimension -, 1152), 8 (d = 128, 640, ...)
 
 __device__ inline float tau_float(uint32_t ord) { return ord == 0 ? -INFINITY : lvs_unord32(ord); }
 
+// scores are finite or -inf, never NaN: v_max3_f32 without fmaxf's canonicalisation (8 instructions for 16 values)
+__device__ inline float max3(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
 __device__ inline float max16(const f32x16& v) {
-    float a = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
-    float b = fmaxf(fmaxf(v[4], v[5]), fmaxf(v[6], v[7]));
-    float c = fmaxf(fmaxf(v[8], v[9]), fmaxf(v[10], v[11]));
-    float d = fmaxf(fmaxf(v[12], v[13]), fmaxf(v[14], v[15]));
-    return fmaxf(fmaxf(a, b), fmaxf(c, d));
+    const float a = max3(v[0], v[1], v[2]), b = max3(v[3], v[4], v[5]), c = max3(v[6], v[7], v[8]);
+    const float d = max3(v[9], v[10], v[11]), e = max3(v[12], v[13], v[14]);
+    return max3(max3(a, b, c), max3(d, e, v[15]), v[15]);
 }
 
 }  // namespace
 
-template <int UNROLL, int NQB>
-__global__ __launch_bounds__(WAVES * 64, 2) void lvs_stream_kernel(const LvsStreamArgs a) {
+template <int UNROLL, int NQB, int WAVES>
+__global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void lvs_stream_kernel(const LvsStreamArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -50,14 +64,24 @@ __global__ __launch_bounds__(WAVES * 64, 2) void lvs_stream_kernel(const LvsStre
     u64* lists = (u64*)(smem + (size_t)NQB * a.nbfrag * 1024);                // [NQ][KCAP]
     uint32_t* locks = (uint32_t*)((char*)lists + (size_t)NQ * KCAP * 8);      // [NQ]
     const int k = a.k;
+    // blockIdx -> (corpus range, sibling group).  Blocks are dealt to the XCDs round-robin (b % 8, observed; used for speed
+    // only): consecutive slots of ONE XCD are the G siblings of a range, so they share its lines through that XCD's L2.
+    const int G = a.groups;
+    int range = blockIdx.x, grp = 0;
+    if (G > 1) {
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        grp = slot % G;
+        range = (slot / G) * 8 + xcd;
+    }
+    const int qbase = grp * NQ;  // first query of this workgroup
 
-    // ---- queries -> LDS as B fragments: block qb, fragment f, lane l = query qb*32 + (l & 31), halfs .. + (l>>5)*8
+    // ---- queries -> LDS as B fragments: block qb, fragment f, lane l = query qbase + qb*32 + (l & 31), halfs .. + (l>>5)*8
     const _Float16* xq = (const _Float16*)a.xq;
     for (int idx = tid; idx < NQB * a.nbfrag * 64; idx += WAVES * 64) {
         const int l = idx & 63, fq = idx >> 6;
         const int qb = fq / a.nbfrag, f = fq - qb * a.nbfrag;
         const int part = f / a.jper, jj = f - part * a.jper;  // part 0: columns [0, dpad), part 1: [dpad, 2 dpad)
-        int qrow = qb * SQ + (l & 31);
+        int qrow = qbase + qb * SQ + (l & 31);
         if (qrow > a.nq - 1) qrow = a.nq - 1;
         bfrag[idx] = *(const half8*)(xq + (long long)qrow * a.ldq + part * a.jper * 16 + jj * 16 + (l >> 5) * 8);
     }
@@ -66,24 +90,24 @@ __global__ __launch_bounds__(WAVES * 64, 2) void lvs_stream_kernel(const LvsStre
     __syncthreads();
 
     // per query block: this lane's query, its validity, running threshold, shared threshold, |q|^2
-    int qi[NQB];
+    int qi[NQB];   // list index inside this workgroup; the query is qbase + qi
     bool qvalid[NQB];
     float tauf[NQB], qnv[NQB];
     uint32_t gord[NQB];
 #pragma unroll
     for (int qb = 0; qb < NQB; ++qb) {
         qi[qb] = qb * SQ + (lane & 31);
-        qvalid[qb] = qi[qb] < a.nq;
+        qvalid[qb] = qbase + qi[qb] < a.nq;
         tauf[qb] = -INFINITY;
-        // start from the shared threshold: zero on a fresh call, the k-th best of the sample pass on a seeded one
-        gord[qb] = qvalid[qb] ? a.gtau[qi[qb]] : 0u;
+        // start from the shared threshold: zero on a fresh call, the k-th best score of the sample on a seeded one
+        gord[qb] = qvalid[qb] ? a.gtau[qbase + qi[qb]] : 0u;
         tauf[qb] = tau_float(gord[qb]);
-        qnv[qb] = (a.metric == LVS_METRIC_L2 && qvalid[qb]) ? a.qn[qi[qb]] : 0.f;
+        qnv[qb] = (a.metric == LVS_METRIC_L2 && qvalid[qb]) ? a.qn[qbase + qi[qb]] : 0.f;
     }
 
     const _Float16* xb = (const _Float16*)a.xb;
     const long long nblocks = (a.nb + 31) / 32;
-    const long long b0 = (long long)blockIdx.x * a.blocks_per_wg;
+    const long long b0 = (long long)range * a.blocks_per_wg;
     const long long b1 = b0 + a.blocks_per_wg < nblocks ? b0 + a.blocks_per_wg : nblocks;
     const int nj = a.nj, jper = a.jper;
     const long long qbstride = (long long)a.nbfrag * 64;  // half8 elements between the fragment sets of two query blocks
@@ -279,8 +303,8 @@ __global__ __launch_bounds__(WAVES * 64, 2) void lvs_stream_kernel(const LvsStre
         for (int qb = 0; qb < NQB; ++qb) {
             if (exch && qvalid[qb] && lane < 32) {
                 const uint32_t lo = (uint32_t)(lists[qi[qb] * KCAP + k - 1] >> 32);
-                if (lo > gord[qb]) atomicMax(&a.gtau[qi[qb]], lo);
-                const uint32_t g = a.gtau[qi[qb]];
+                if (lo > gord[qb]) atomicMax(&a.gtau[qbase + qi[qb]], lo);
+                const uint32_t g = a.gtau[qbase + qi[qb]];
                 gord[qb] = g > gord[qb] ? g : gord[qb];
             }
             const uint32_t gl = __shfl(gord[qb], lane & 31, 64);  // lanes l and l+32 share the query
@@ -289,81 +313,107 @@ __global__ __launch_bounds__(WAVES * 64, 2) void lvs_stream_kernel(const LvsStre
         }
     }
     __syncthreads();
-    for (int i = tid; i < a.nq * k; i += WAVES * 64) {
+    for (int i = tid; i < NQ * k; i += WAVES * 64) {
         const int qq = i / k, j = i - qq * k;
-        a.out[((long long)blockIdx.x * a.nq + qq) * k + j] = lists[qq * KCAP + j];
+        if (qbase + qq < a.nq) a.out[((long long)range * a.nq + qbase + qq) * k + j] = lists[qq * KCAP + j];
     }
-    for (int qq = tid; qq < a.nq; qq += WAVES * 64) {
+    for (int qq = tid; qq < NQ; qq += WAVES * 64) {
         const uint32_t lo = (uint32_t)(lists[qq * KCAP + k - 1] >> 32);
-        if (lo) atomicMax(&a.gtau[qq], lo);
+        if (lo && qbase + qq < a.nq) atomicMax(&a.gtau[qbase + qq], lo);
     }
 }
 
 // host side -----------------------------------------------------------------------------------------------------
-int lvs_stream_blocks(int64_t nb) {
+// corpus ranges of a launch: one per CU when every workgroup has its own range, 256 / G with G sibling groups
+int lvs_stream_ranges(int64_t nb, int groups) {
     const int64_t nblocks = (nb + 31) / 32;
-    int64_t wgs = 256;  // one per CU: fewest partial lists to merge, cold start amortised over ~120 row blocks
-    if (lvs_tune("LVS_STREAM_WGS", 0) > 0) wgs = lvs_tune("LVS_STREAM_WGS", 0);  // -DLVS_TUNING builds only
-    if (wgs > LVS_STREAM_MAXWG) wgs = LVS_STREAM_MAXWG;
-    if (wgs > (nblocks + 3) / 4) wgs = (nblocks + 3) / 4;
-    if (wgs < 1) wgs = 1;
-    return (int)wgs;
+    int64_t r = 256 / (groups > 0 ? groups : 1);
+    if (groups <= 1 && lvs_tune("LVS_STREAM_WGS", 0) > 0) r = lvs_tune("LVS_STREAM_WGS", 0);  // -DLVS_TUNING builds only
+    if (r > LVS_STREAM_MAXWG) r = LVS_STREAM_MAXWG;
+    if (groups > 1) {
+        // siblings are consecutive slots of one XCD: ranges come in multiples of 8 (one per XCD and slot group)
+        int64_t cap = (nblocks + 3) / 4;
+        cap = cap / 8 * 8;
+        if (r > cap) r = cap;
+        if (r < 8) r = 8;
+    } else {
+        if (r > (nblocks + 3) / 4) r = (nblocks + 3) / 4;
+        if (r < 1) r = 1;
+    }
+    return (int)r;
 }
 
 size_t lvs_stream_lds_bytes(int nbfrag, int nqb, int kcap) {
     return (size_t)nqb * nbfrag * 1024 + (size_t)nqb * SQ * kcap * 8 + (size_t)nqb * SQ * 4;
 }
 
-// how many 32-query blocks ride on one corpus pass, and with how many list slots per query; 0 = this call does not fit
-// the streaming kernel (too many queries / k for the LDS left beside the query fragments)
-int lvs_stream_plan(int64_t nq, int k, int nbfrag, int* out_kcap) {
+// How a call is laid out: *out_nqb = 32-query blocks per workgroup (1 or 2), *out_groups = sibling workgroups per corpus
+// range (1, 2 or 4), *out_kcap = list slots per query.  Returns 0 when the call does not fit the streaming kernel (too many
+// queries / k for the LDS left beside the query fragments).
+int lvs_stream_plan(int64_t nq, int k, int nbfrag, int* out_kcap, int* out_nqb, int* out_groups) {
     if (nq < 1 || nq > LVS_STREAM_MAXQ || k < 1 || k > LVS_KPASS) return 0;
-    const int nqb = (int)((nq + SQ - 1) / SQ);
-    // one block keeps the full 64 slots (any k <= 56 costs the same insertion step); more blocks trade slots for queries
-    int kcap = nqb == 1 ? 64 : (k <= 16 ? 16 : (k <= 32 ? 32 : 64));
-    if (lvs_stream_lds_bytes(nbfrag, nqb, kcap) > 160 * 1024) return 0;  // a workgroup may use the whole 160 KiB
-    if (out_kcap) *out_kcap = kcap;
-    return nqb;
+    const int blocks = (int)((nq + SQ - 1) / SQ);
+    // one block keeps the full 64 slots (any k <= 56 costs the same insertion step); two blocks trade slots for queries
+    for (int nqb = blocks >= 2 ? 2 : 1; nqb >= 1; --nqb) {
+        const int kcap = nqb == 1 ? 64 : (k <= 16 ? 16 : (k <= 32 ? 32 : 64));
+        if (lvs_stream_lds_bytes(nbfrag, nqb, kcap) > 160 * 1024) continue;  // a workgroup may use the whole 160 KiB
+        const int need = (blocks + nqb - 1) / nqb;
+        const int groups = need <= 1 ? 1 : (need <= 2 ? 2 : 4);
+        if (need > 4) continue;
+        if (out_kcap) *out_kcap = kcap;
+        if (out_nqb) *out_nqb = nqb;
+        if (out_groups) *out_groups = groups;
+        return nqb;
+    }
+    return 0;
 }
 
-template <int U, int NQB>
+template <int U, int NQB, int WAVES>
 static hipError_t stream_launch_one(const LvsStreamArgs& a, int grid, size_t lds, hipStream_t stream) {
     static LvsPerDeviceOnce attr;  // the attribute is a per-device property (one per instantiation)
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
     if (!attr.done(dev, lds)) {
-        e = hipFuncSetAttribute((const void*)lvs_stream_kernel<U, NQB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        e = hipFuncSetAttribute((const void*)lvs_stream_kernel<U, NQB, WAVES>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds);
         if (e != hipSuccess) return e;
         attr.set(dev, lds);
     }
-    hipLaunchKernelGGL((lvs_stream_kernel<U, NQB>), dim3(grid), dim3(WAVES * 64), lds, stream, a);
+    hipLaunchKernelGGL((lvs_stream_kernel<U, NQB, WAVES>), dim3(grid), dim3(WAVES * 64), lds, stream, a);
     return hipGetLastError();
 }
 
-template <int NQB>
+template <int NQB, int WAVES>
 static hipError_t stream_launch_nqb(const LvsStreamArgs& a, int grid, size_t lds, hipStream_t stream) {
     // fragments in flight: the largest of 16 / 24 / 8 that divides the fragments per K segment gives the branch-free
     // inner loop; anything else runs the general state machine with 16
-    if (a.jper % 16 == 0) return stream_launch_one<16, NQB>(a, grid, lds, stream);
-    if constexpr (NQB == 1) {  // 24 fragment registers + 2..3 accumulator sets would spill: several blocks use 8
-        if (a.jper % 24 == 0) return stream_launch_one<24, NQB>(a, grid, lds, stream);
+    if (a.jper % 16 == 0) return stream_launch_one<16, NQB, WAVES>(a, grid, lds, stream);
+    if constexpr (NQB == 1) {  // 24 fragment registers + 2 accumulator sets: one query block only
+        if (a.jper % 24 == 0) return stream_launch_one<24, NQB, WAVES>(a, grid, lds, stream);
     }
-    if (a.jper % 8 == 0) return stream_launch_one<8, NQB>(a, grid, lds, stream);
-    return stream_launch_one<16, NQB>(a, grid, lds, stream);
+    if (a.jper % 8 == 0) return stream_launch_one<8, NQB, WAVES>(a, grid, lds, stream);
+    return stream_launch_one<16, NQB, WAVES>(a, grid, lds, stream);
 }
 
+// a.nqb / a.groups / a.kcap come from lvs_stream_plan.  On return a.nparts = candidate lists per query in a.out
+// ([nparts][nq][k]).
 hipError_t lvs_stream_launch(LvsStreamArgs& a, hipStream_t stream) {
     const int64_t nblocks = (a.nb + 31) / 32;
-    int wgs = lvs_stream_blocks(a.nb);
-    if (a.max_wgs > 0 && wgs > a.max_wgs) wgs = a.max_wgs;
-    a.blocks_per_wg = (int)((nblocks + wgs - 1) / wgs);
+    if (a.groups != 1 && a.groups != 2 && a.groups != 4) return hipErrorInvalidValue;
+    if (a.nqb < 1 || a.nqb > 2 || a.kcap < a.k || a.kcap > 64) return hipErrorInvalidValue;
+    if ((long long)a.nqb * SQ * a.groups < a.nq) return hipErrorInvalidValue;
+    int ranges = lvs_stream_ranges(a.nb, a.groups);
+    a.blocks_per_wg = (int)((nblocks + ranges - 1) / ranges);
     a.debug = (int)lvs_tune("LVS_STREAM_DEBUG", 0);
-    const int grid = (int)((nblocks + a.blocks_per_wg - 1) / a.blocks_per_wg);
-    const int nqb = (a.nq + SQ - 1) / SQ;
-    if (nqb < 1 || nqb > 3 || a.kcap < a.k || a.kcap > 64) return hipErrorInvalidValue;
-    const size_t lds = lvs_stream_lds_bytes(a.nbfrag, nqb, a.kcap);
-    if (nqb == 1) return stream_launch_nqb<1>(a, grid, lds, stream);
-    if (nqb == 2) return stream_launch_nqb<2>(a, grid, lds, stream);
-    return stream_launch_nqb<3>(a, grid, lds, stream);
+    if (a.groups > 1) {
+        ranges = (int)((((nblocks + a.blocks_per_wg - 1) / a.blocks_per_wg) + 7) / 8 * 8);  // empty ranges write empty lists
+    } else {
+        ranges = (int)((nblocks + a.blocks_per_wg - 1) / a.blocks_per_wg);
+    }
+    a.nparts = ranges;
+    const int grid = ranges * a.groups;
+    const size_t lds = lvs_stream_lds_bytes(a.nbfrag, a.nqb, a.kcap);
+    if (a.nqb == 1) return stream_launch_nqb<1, 4>(a, grid, lds, stream);
+    return stream_launch_nqb<2, 8>(a, grid, lds, stream);
 }

@@ -147,19 +147,19 @@ inline int lvs_tile_xcd_rounds(int nqt, int nslab, int gq, int lead_slabs) {
 }
 hipError_t lvs_tile_launch(int mode, const LvsTileArgs& a, hipStream_t stream);
 
-// ---- small-batch streaming kernel (lvs_stream.hip): nq <= 64 (1..2 blocks of 32 queries per corpus pass), k <= LVS_KPASS.
-// The kernel itself takes three blocks, but measured at 1 M rows x 768 (profiles/r02_tuning.md) 96 queries cost 0.71 ms there
-// against 0.67 ms on the 128-query tile kernel: every workgroup pays its own list cold start per query. ----
-#define LVS_STREAM_MAXQ 64
-#define LVS_STREAM_MAXWG 768   // most workgroups (= partial candidate lists) a launch may use
+// ---- small-batch streaming kernel (lvs_stream.hip): nq <= 256, k <= LVS_KPASS.  One or two blocks of 32 queries per
+// workgroup; beyond 64 queries 2 or 4 sibling workgroups share a corpus range through their XCD's L2. ----
+#define LVS_STREAM_MAXQ 256
+#define LVS_STREAM_MAXWG 768   // most corpus ranges (= partial candidate lists per query) a launch may use
+#define LVS_STREAM_SEED_MAX 16384  // most sample rows whose scores seed the thresholds of a multi-query call
 struct LvsStreamArgs {
     const void* xb;
     const void* xq;
     const float* bn;
     const float* qn;
     const uint32_t* row_ids;
-    uint32_t* gtau;  // [nq] zero-initialised
-    u64* out;        // [nblocks][nq][k]
+    uint32_t* gtau;  // [nq] zero-initialised, or seeded with a valid lower bound of every query's k-th best score
+    u64* out;        // [nparts][nq][k]
     long long nb, ldb, ldq, id_offset;
     int nq, k, metric;
     int nj;                  // MFMAs per 32-row block = nseg * dpad / 16
@@ -167,14 +167,16 @@ struct LvsStreamArgs {
     int nseg;
     int seg_q[3], seg_c[3];  // column offsets (halfs) of each K segment
     int seg_b[3];            // first B-fragment index of each K segment (segments sharing query columns share fragments)
-    int nbfrag;              // B fragments held in LDS
-    int blocks_per_wg;       // 32-row blocks per workgroup (contiguous)
+    int nbfrag;              // B fragments held in LDS per query block
+    int blocks_per_wg;       // 32-row blocks per corpus range (contiguous)
     int kcap;                // list slots per query in LDS (k <= kcap <= 64), from lvs_stream_plan
-    int max_wgs;             // > 0: at most this many workgroups (the short sample pass)
+    int nqb;                 // 32-query blocks per workgroup (1 or 2), from lvs_stream_plan
+    int groups;              // sibling workgroups per corpus range (1, 2 or 4), from lvs_stream_plan
+    int nparts;              // out: corpus ranges of the launch = candidate lists per query
     int debug;               // -DLVS_TUNING builds only (env LVS_STREAM_DEBUG): 1 no MFMA / B reads, 2 no block epilogue
 };
 
-int lvs_stream_blocks(int64_t nb);
+int lvs_stream_ranges(int64_t nb, int groups);
 size_t lvs_stream_lds_bytes(int nbfrag, int nqb, int kcap);
-int lvs_stream_plan(int64_t nq, int k, int nbfrag, int* out_kcap);
+int lvs_stream_plan(int64_t nq, int k, int nbfrag, int* out_kcap, int* out_nqb, int* out_groups);
 hipError_t lvs_stream_launch(LvsStreamArgs& a, hipStream_t stream);

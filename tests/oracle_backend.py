@@ -36,9 +36,14 @@ class OracleBackend:
     def to_device(self, arr):
         return torch.from_numpy(np.ascontiguousarray(arr))
 
-    def pack(self, x, mode, normalize=False):
+    def pack(self, x, mode, normalize=False, check=False):
         x = x.numpy() if torch.is_tensor(x) else np.asarray(x)
         x = x.astype(np.float32)
+        if check:
+            if not np.isfinite(x).all():
+                raise ValueError("embeddings contain inf or NaN")
+            if np.abs(x).max(initial=0.0) > 65504.0:
+                raise ValueError("embedding values exceed fp16's range")
         if normalize:
             x = x / np.linalg.norm(x, axis=1, keepdims=True)
         vals = _emulate_storage(x, mode)
@@ -72,7 +77,7 @@ class OracleBackend:
             keys = np.concatenate([keys, np.zeros((keys.shape[0], k - keys.shape[1]), np.uint64)], axis=1)
         return torch.from_numpy(np.array(keys, dtype=np.uint64, order="C", copy=True).view(np.int64))
 
-    def nearest(self, corpus, queries, metric, id_offset=0, stats=None, exact_scores=True):
+    def nearest(self, corpus, queries, metric, id_offset=0, stats=None, exact_scores=True, corpus_stats=None):
         return self.search_keys(corpus, queries, 1, metric, id_offset=id_offset)
 
     def merge_keys(self, parts):
@@ -142,6 +147,31 @@ class OracleBackend:
         np.add.at(sums, a[ok], vals[ok])  # unbuffered: in row order, like the device kernel
         counts = np.bincount(a[ok], minlength=k).astype(np.float32)
         return torch.from_numpy(sums), torch.from_numpy(counts)
+
+    def kmeans_accumulate_keys(self, x, keys, k, id_offset=0):
+        kk = keys.numpy().view(np.uint64).reshape(-1)
+        ids = (np.uint64(0xFFFFFFFF) - (kk & np.uint64(0xFFFFFFFF))).astype(np.int64) - id_offset
+        ids[kk == 0] = -1
+        return self.kmeans_accumulate(x, torch.from_numpy(ids), k)
+
+    def kmeans_objective(self, centroids, sums, counts, x2, out):
+        c = centroids.numpy().astype(np.float64)
+        o = x2.numpy()[0] - 2.0 * (c * sums.numpy().astype(np.float64)).sum() + (counts.numpy().astype(np.float64) * (c * c).sum(1)).sum()
+        out[0] = float(o)
+
+    def kmeans_pack_centroids(self, centroids, mode):
+        pk = self.pack(centroids, mode)
+        return pk, torch.zeros(2)
+
+    def kmeans_finish(self, sums, counts, centroids, n_train, mode, nsplit_out=None):
+        self.kmeans_update_centroids(sums, counts, centroids)
+        hs = counts.numpy()
+        ns = 0
+        if n_train > 0 and (hs == 0).any():
+            ns = self.split_clusters(n_train, hs, centroids.numpy())
+        if nsplit_out is not None:
+            nsplit_out[0] = ns
+        return self.kmeans_pack_centroids(centroids, mode)
 
     def rand_perm(self, n, seed, m=None):
         perm = oracle.rand_perm(n, seed)

@@ -108,10 +108,18 @@ def test_mixed_precision_operands(hip_backend, cmode, qmode, k):
     (40, 200_000, 256, 10, F16, IP),   # long corpus + several queries: sample pass seeds the shared thresholds
     (96, 150_000, 128, 15, F16, L2),
     (8, 70_000, 768, 56, F16, IP),
-    (96, 90_000, 768, 10, F16, IP),    # three query blocks at d = 768 use (almost) the whole 160 KiB of LDS
+    (96, 90_000, 768, 10, F16, IP),    # two sibling workgroups per corpus range (64 + 32 queries), seeded thresholds
+    (128, 140_000, 768, 10, F16, IP),  # 2 groups x 2 blocks, seeded from 8 192 sample rows
+    (129, 70_000, 256, 10, F16, L2),   # 4 groups, the last three nearly / entirely empty
+    (200, 66_000, 384, 15, F16, IP),   # d = 384: the 8-deep pipeline with two blocks per workgroup
+    (256, 100_000, 768, 10, F16, IP),  # the largest small batch: 4 groups x 64 queries
+    (256, 30_000, 128, 56, F16, L2),   # 64-slot lists for 64 queries per workgroup, unseeded (short corpus)
+    (100, 80_000, 768, 10, SPLIT, IP), # fp32-accurate queries: one block per workgroup (96 KB of fragments), 4 groups
+    (130, 20_000, 768, 10, SPLIT, IP), # ... five blocks do not fit four groups: the tile kernel
+    (2, 300_000, 768, 10, F16, IP),    # two queries are seeded too
 ])
 def test_small_batch_streaming_kernel(hip_backend, nq, nb, d, k, mode, metric):
-    """nq <= 96 takes the HBM-streaming kernel (lvs_stream.hip) when the query fragments fit the LDS: same results as
+    """nq <= 256 takes the HBM-streaming kernel (lvs_stream.hip) when the query fragments fit the LDS: same results as
     the tile kernels / the oracle."""
     xb = synth.corpus(nb, d, seed=nb % 89)
     xq, _ = synth.queries(xb, nq, seed=13)
