@@ -349,16 +349,30 @@ __global__ __launch_bounds__(64) void km_split_kernel(int d, int k, long long n,
     for (int ci = 0; ci < k; ++ci) {
         int cj = -1;
         if (lane == 0 && hassign[ci] == 0.f) {
+            // the acceptance probabilities of one round over the clusters sum to 1, so a split takes ~k draws; the cap only
+            // guards the device against counts that do not describe n points (faiss itself would spin forever)
+            long long draws = 0;
+            const long long cap = 4096ll * k + (1ll << 20);
             for (cj = 0;; cj = (cj + 1) % k) {
                 const float p = (hassign[cj] - 1.0f) / (float)(n - k);
                 const float r = (float)rng.next() / 4294967295.0f;  // faiss rand_float(): mt() / float(mt.max())
                 if (r < p) break;
+                if (++draws > cap) {
+                    cj = -2;
+                    break;
+                }
             }
-            const float half = hassign[cj] / 2;
-            hassign[ci] = half;
-            hassign[cj] = hassign[cj] - half;
+            if (cj >= 0) {
+                const float half = hassign[cj] / 2;
+                hassign[ci] = half;
+                hassign[cj] = hassign[cj] - half;
+            }
         }
         cj = __shfl(cj, 0, 64);
+        if (cj == -2) {  // inconsistent counts: report and stop
+            if (lane == 0 && out_nsplit) *out_nsplit = -1;
+            return;
+        }
         if (cj < 0) continue;
         float* a = centroids + (long long)ci * d;
         float* b = centroids + (long long)cj * d;

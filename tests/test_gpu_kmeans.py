@@ -224,3 +224,103 @@ def test_certified_nearest_zero_scores_ragged_rows_and_every_tile_position(hip_b
             assert np.array_equal(Ig, Iw), (nb, metric)
             if metric == L2:
                 assert np.array_equal(Ig[:, 0], pick) and np.abs(Dg).max() <= 1e-5
+
+
+def test_kmeans_parity_at_the_configs_cluster_count_with_faiss_subsample(hip_backend):
+    """K = 1 024 on 300 000 rows: n > K * 256, so faiss's 262 144-row training subsample engages (lotus/utils.py:61-62,
+    SURVEY.md Appendix A.4).  Same subsample, same initial centroids, then 10 iterations + the final assignment of ALL
+    rows against oracle.kmeans_faiss: train ids equal, assignment agreement >= 1 - 1e-4, objective within 1e-5 (SURVEY.md
+    8(c)); the certified one-pass assignment's uncertified re-search is what makes this exact at scale."""
+    import benchdata
+    from lotus_amd.cluster import kmeans
+
+    K, n, d = 1024, 300_000, 128
+    x, _ = benchdata.blobs(benchdata.CFG_KMEANS, n, d, K)      # fp16 storage: identical values on both sides
+    stats = {}
+    r = kmeans(x, K, niter=10, backend=hip_backend, stats=stats)
+    ref = oracle.kmeans_faiss(x.astype(np.float32), K, niter=10)
+    assert len(r.train_ids) == K * 256 and np.array_equal(r.train_ids, ref.train_ids)
+    assert r.nsplit.tolist() == ref.nsplit.tolist()
+    assert np.allclose(r.obj, ref.obj, rtol=1e-5), np.abs(r.obj / ref.obj - 1).max()
+    assert (r.assign == ref.assign).mean() >= 1 - 1e-4
+    assert np.abs(r.centroids - ref.centroids).max() <= 1e-4
+    assert stats["queries"] == 10 * K * 256  # every training assignment went through the certificate
+
+
+def test_device_split_replays_faiss_rng(hip_backend):
+    """lvs_kmeans_update_centroids runs faiss split_clusters on the device (mt19937(1234) replayed by one thread): same
+    decisions, same perturbed centroids, same hassign as the host twin / the oracle's restatement."""
+    import torch
+    from oracle.kmeans import _split_clusters
+
+    be = hip_backend
+    rng = np.random.default_rng(4)
+    for k, d, n, empties in ((9, 11, 90, [0, 2, 5]), (300, 96, 40_000, list(range(0, 300, 7))), (64, 768, 5000, [63]),
+                             (16, 8, 1000, [])):
+        counts = rng.integers(1, 50, k).astype(np.float32)
+        counts[empties] = 0
+        sums = rng.standard_normal((k, d)).astype(np.float32) * counts[:, None]
+        cent = rng.standard_normal((k, d)).astype(np.float32)
+        # oracle: compute_centroids' division, then the split
+        ref_c, ref_h = cent.copy(), counts.copy()
+        nz = ref_h > 0
+        ref_c[nz] = sums[nz] * (np.float32(1.0) / ref_h[nz])[:, None]
+        ref_n = _split_clusters(n, ref_h, ref_c, False)
+        c_dev, h_dev = be.to_device(cent), be.to_device(counts)
+        ns = torch.zeros(1, dtype=torch.int32, device=be.device)
+        pk, st = be.kmeans_finish(be.to_device(sums), h_dev, c_dev, n, SPLIT, ns)
+        assert int(ns.item()) == ref_n == len(empties)
+        assert np.array_equal(c_dev.cpu().numpy(), ref_c) and np.array_equal(h_dev.cpu().numpy(), ref_h)
+        # the repacked centroids and the certificate's statistics describe the UPDATED centroids
+        assert np.array_equal(be.unpack(pk).cpu().numpy(), _stored(ref_c, SPLIT))
+        vals = _stored(ref_c, SPLIT)
+        lo = (ref_c - ref_c.astype(np.float16).astype(np.float32)).astype(np.float16).astype(np.float32)
+        R2, E2 = st.cpu().numpy()
+        assert abs(R2 - (vals ** 2).sum(1).max()) <= 1e-5 * R2 and abs(E2 - (lo ** 2).sum(1).max()) <= 1e-5 * max(E2, 1e-12)
+
+
+def test_objective_kernel_matches_the_sum_of_assignment_distances(hip_backend):
+    import torch
+
+    be = hip_backend
+    rng = np.random.default_rng(6)
+    n, d, k = 30_000, 96, 50
+    x = rng.standard_normal((n, d)).astype(np.float16)
+    cent = rng.standard_normal((k, d)).astype(np.float32)
+    p = be.pack(x, F16)
+    D, I = oracle.flat_search(cent, x.astype(np.float32), 1, 1)
+    keys = be.search_keys(be.pack(cent, SPLIT), p, 1, L2)
+    sums, counts = be.kmeans_accumulate_keys(p, keys, k)
+    ref = np.zeros((k, d), np.float32)
+    np.add.at(ref, I[:, 0], x.astype(np.float32))
+    assert np.array_equal(sums.cpu().numpy(), ref) and np.array_equal(counts.cpu().numpy(), np.bincount(I[:, 0], minlength=k))
+    out = torch.zeros(1, dtype=torch.float64, device=be.device)
+    be.kmeans_objective(be.to_device(cent), sums, counts, p.norms.double().sum().reshape(1), out)
+    want = float(D[:, 0].astype(np.float64).sum())
+    assert abs(out.item() - want) <= 1e-5 * want
+
+
+def test_counting_sort_two_digit_path_and_ignored_rows(hip_backend):
+    """More than 24 575 centroids bucket the rows with two stable digit passes; sums stay in row order (bit-identical)."""
+    be = hip_backend
+    rng = np.random.default_rng(9)
+    n, d, k = 70_000, 16, 30_000
+    x = rng.standard_normal((n, d)).astype(np.float16)
+    assign = rng.integers(0, k, n).astype(np.int64)
+    assign[rng.integers(0, n, 300)] = k + 5   # out of range: ignored
+    assign[rng.integers(0, n, 300)] = -2
+    p = be.pack(x, F16)
+    sums, counts = be.kmeans_accumulate(p, be.to_device(assign), k)
+    ok = (assign >= 0) & (assign < k)
+    ref = np.zeros((k, d), np.float32)
+    np.add.at(ref, assign[ok], x.astype(np.float32)[ok])
+    assert np.array_equal(counts.cpu().numpy(), np.bincount(assign[ok], minlength=k).astype(np.float32))
+    assert np.array_equal(sums.cpu().numpy(), ref)
+    # ragged chunk boundaries of the one-digit path: n = 1, a chunk + 1 row, every row in one bucket
+    for n2, k2 in ((1, 3), (8193, 5), (20_000, 1)):
+        x2 = rng.standard_normal((n2, 8)).astype(np.float16)
+        a2 = rng.integers(0, k2, n2).astype(np.int64)
+        s2, c2 = be.kmeans_accumulate(be.pack(x2, F16), be.to_device(a2), k2)
+        r2 = np.zeros((k2, 8), np.float32)
+        np.add.at(r2, a2, x2.astype(np.float32))
+        assert np.array_equal(s2.cpu().numpy(), r2) and np.array_equal(c2.cpu().numpy(), np.bincount(a2, minlength=k2))

@@ -515,3 +515,31 @@ def test_planner_shapes_sampled_parity(hip_backend, nq, nb, d):
     assert err <= 1e-5 and hard == 0 and recall >= 0.9999, (err, hard, recall)
     assert (I[pick] == Ir).mean() > 0.999
     assert (I >= 0).all() and (np.diff(D, axis=1) <= 0).all()  # every list full and best-first
+
+
+@pytest.mark.parametrize("mode,nq,nb,d,k", [(F16, 2000, 60_000, 768, 10), (F16, 40, 120_000, 384, 10), (SPLIT, 1500, 50_000, 256, 5)])
+def test_l2_on_unit_norm_rows_at_1e5(hip_backend, mode, nq, nb, d, k):
+    """north_star's bar for L2: scores within 1e-5 - on unit-norm rows (squared distances in [0, 4], the planted neighbour
+    at ~0.58), not the looser 4e-5 the scaled-data cases above allow."""
+    xb = synth.corpus(nb, d, seed=31)
+    xq, _ = synth.queries(xb, nq, seed=32)
+    D, I, _ = _run(hip_backend, xb, xq, k, mode, L2)
+    Dr, Ir = oracle.flat_search(_stored(xb, mode), _stored(xq, mode), k, L2)
+    err, hard, recall = synth.compare_topk(Dr, Ir, D, I, atol=1e-5)
+    assert err <= 1e-5, err
+    assert hard == 0 and recall >= 0.9999
+
+
+def test_pack_validation_flags_non_finite_and_out_of_range_values(hip_backend):
+    """faiss takes any float32 (faiss_vs.py:24); the fp16-based device rows do not: inf / NaN and |x| > 65504 are detected
+    while packing instead of silently producing NaN scores."""
+    be = hip_backend
+    x = synth.corpus(3000, 96, seed=1)
+    be.pack(x, SPLIT, check=True)
+    be.pack((x * 6.0e4).astype(np.float32), F16, check=True)  # largest component ~ 0.4 * 6e4: still inside fp16's range
+    for bad, what in ((np.inf, "inf"), (np.nan, "inf"), (7.0e4, "range"), (-1.0e9, "range")):
+        y = x.copy()
+        y[1234, 17] = bad
+        for mode in (F16, SPLIT):
+            with pytest.raises(ValueError, match=what):
+                be.pack(y, mode, check=True)

@@ -1,0 +1,20 @@
+#!/bin/bash
+# usage (GPU box, repo root): tools/r03_run.sh <tag> [pytest|bench|prof|kern ...]   - one gpurun call, everything under gpurun_out/<tag>/
+tag=${1:-r03}; shift
+what=${*:-pytest bench}
+cd "${GRAFT_REPO_ROOT:-.}"; export TMPDIR=/tmp
+out=gpurun_out/$tag; mkdir -p $out
+for w in $what; do
+  case $w in
+    pytest) timeout -k 10 1500 python -m pytest tests -m gpu -q --maxfail=25 --timeout 600 -p no:cacheprovider > $out/pytest_gpu.log 2>&1; tail -40 $out/pytest_gpu.log ;;
+    bench) timeout -k 10 900 python bench.py > $out/bench.json 2> $out/bench.err; tail -c 1500 $out/bench.json; echo; tail -5 $out/bench.err ;;
+    benchq) timeout -k 10 600 python bench.py --dedup-rows 0 --kmeans-rows 0 --no-cpu-baseline > $out/bench_quick.json 2> $out/bench_quick.err; tail -c 1500 $out/bench_quick.json; echo; tail -5 $out/bench_quick.err ;;
+    prof) timeout -k 10 1500 tools/profile_bench.sh $tag/prof > $out/prof.log 2>&1; tail -30 $out/prof.log ;;
+    kern) timeout -k 10 1500 tools/profile_kernels.sh $tag/kern > $out/kern.log 2>&1; tail -30 $out/kern.log ;;
+    kmprof) timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kmprof -o km -- python tools/kmeans_iter_workload.py > $out/kmprof.log 2>&1; tail -5 $out/kmprof.log ;;
+    smoke) timeout -k 10 300 python -c 'import __graft_entry__ as g; g.smoke()' > $out/smoke.log 2>&1; tail -3 $out/smoke.log ;;
+    *) echo "unknown step $w" ;;
+  esac
+done
+find $out -name "*.db" -delete 2>/dev/null
+echo done
