@@ -57,12 +57,15 @@ class HipVS(VS):
             (fp32-accurate scores); ``"fp16"`` - round everything to fp16 (half the HBM, 3x the speed,
             ~1e-4 score error on fp32 inputs); ``"fp32"`` - always the hi|lo pair.
         device: torch device string; default current CUDA device.
-        shard: ``True`` / ``"rows"`` - row-shard the corpus across the ``torch.distributed`` ranks, queries replicated,
-            one all-gather of the per-shard candidate keys + merge (BASELINE's configuration; scales the corpus beyond
-            one GPU's HBM).  ``"queries"`` - every rank keeps the WHOLE corpus and searches its slice of the queries;
-            the finished lists are all-gathered, nothing is merged.  For a corpus that fits one GPU this is the faster
-            split of a big join: each rank streams the long corpus (fewer threshold events per flop - 12.5 k x 1 M
-            runs at ~38 % of the MFMA roof where the 100 k x 125 k shard of the row split runs at ~35 %).
+        shard: how a join is split over the ``torch.distributed`` ranks.  ``True`` / ``"rows"`` - row-shard the corpus,
+            queries replicated, one all-gather of the per-shard candidate keys + merge (BASELINE's configuration; scales the
+            corpus beyond one GPU's HBM).  ``"queries"`` - every rank keeps the WHOLE corpus and searches its slice of the
+            queries; the finished lists are all-gathered, nothing is merged.  ``(gq, gc)`` - the 2-D split: ``gq`` query
+            groups x ``gc`` corpus shards (``gq * gc`` = ranks; rank r is in query group r // gc and holds corpus shard
+            r % gc): every GPU searches Q / gq queries against N / gc rows, the lists are merged inside a corpus group and
+            concatenated across the query groups.  ``"auto"`` - ``lotus_amd.plan.pick_split`` chooses (gq, gc) from the
+            per-GPU shapes' measured rates (8 GPUs: 2 x 4 - 50 k x 250 k per GPU at configs[2] - where the fused top-k runs
+            closer to its long-stream rate than on the 100 k x 125 k shards of the pure row split).
         max_resident: how many indexes stay on the GPU.
         backend: injected device backend (tests); default ``HipBackend``.
     """
@@ -81,11 +84,14 @@ class HipVS(VS):
         self._backend = backend
         self._resident: "OrderedDict[str, _Resident]" = OrderedDict()
         self._max_resident = max(1, int(max_resident))
-        if shard not in (False, True, "rows", "queries"):
-            raise ValueError("shard must be False, True, 'rows' or 'queries'")
+        is_pair = (isinstance(shard, (tuple, list)) and len(shard) == 2 and all(isinstance(v, int) and v >= 1 for v in shard))
+        if not is_pair and shard not in (False, True, "rows", "queries", "auto"):
+            raise ValueError("shard must be False, True, 'rows', 'queries', 'auto' or a (query groups, corpus shards) pair")
+        self._split = tuple(shard) if is_pair else shard
         self._shard = shard in (True, "rows")      # corpus rows split across the ranks
         self._shard_queries = shard == "queries"   # corpus replicated, queries split
         self._pg = process_group
+        self._lay = None                           # resolved layout, see _layout()
 
     # ------------------------------------------------------------------------------------------------ helpers
     @property
@@ -96,20 +102,66 @@ class HipVS(VS):
             self._backend = HipBackend(self._device)
         return self._backend
 
-    def _dist(self):
-        """(rank, world) of the sharding group; (0, 1) when not sharded."""
-        if not self._shard:
-            return 0, 1
+    def _layout(self):
+        """-> (qg, gq, cs, gc, pg_query, pg_corpus): this rank's query group / corpus shard under the configured split and
+        the process groups its two exchange steps run in (None: nothing to exchange in that direction).  Resolved once,
+        at first use: a 2-D split creates its sub-groups here (a collective call - every rank reaches it together, like
+        every other step of a sharded operator)."""
+        if self._lay is not None:
+            return self._lay
+        if self._split is False:
+            return (0, 1, 0, 1, None, None)
         import torch.distributed as dist
 
         if not (dist.is_available() and dist.is_initialized()):
-            return 0, 1
-        return dist.get_rank(self._pg), dist.get_world_size(self._pg)
+            return (0, 1, 0, 1, None, None)
+        rank, world = dist.get_rank(self._pg), dist.get_world_size(self._pg)
+        split = self._split
+        if split == "auto":
+            from .plan import pick_split
+
+            split = pick_split(world)
+        if split in (True, "rows"):
+            lay = (0, 1, rank, world, None, self._pg)
+        elif split == "queries":
+            lay = (rank, world, 0, 1, self._pg, None)
+        else:
+            gq, gc = int(split[0]), int(split[1])
+            if gq * gc != world:
+                raise ValueError(f"shard={split}: {gq} query groups x {gc} corpus shards need {gq * gc} ranks, the group has {world}")
+            if gq == 1:
+                lay = (0, 1, rank, world, None, self._pg)
+            elif gc == 1:
+                lay = (rank, world, 0, 1, self._pg, None)
+            else:
+                members = dist.get_process_group_ranks(self._pg) if self._pg is not None else list(range(world))
+                qg, cs = rank // gc, rank % gc
+                pg_corpus = pg_query = None
+                for g in range(gq):  # every rank creates every group, in the same order
+                    grp = dist.new_group([members[g * gc + c] for c in range(gc)])
+                    if g == qg:
+                        pg_corpus = grp
+                for c in range(gc):
+                    grp = dist.new_group([members[g * gc + c] for g in range(gq)])
+                    if c == cs:
+                        pg_query = grp
+                lay = (qg, gq, cs, gc, pg_query, pg_corpus)
+        self._lay = lay
+        return lay
+
+    def _dist(self):
+        """(rank, world) of the corpus sharding - which contiguous block of rows this rank holds; (0, 1) when every rank
+        holds all rows."""
+        lay = self._layout()
+        return lay[2], lay[3]
+
+    def _pg_corpus(self):
+        return self._layout()[5]
 
     def _group(self):
         """(rank, world) of the process group this store works in under EITHER split (rows or queries) - what decides who
         writes an index directory and which collectives every rank must enter; (0, 1) when not distributed."""
-        if not (self._shard or self._shard_queries):
+        if self._split is False:
             return 0, 1
         from . import _dist
 
@@ -252,21 +304,15 @@ class HipVS(VS):
                 sub = None  # every row, in order: same as an unfiltered search (sem_sim_join.py:132-134)
         n_eff = ent.n if sub is None else int(sub.size)
         k_eff = min(K, n_eff)
-        D = np.full((nq, K), pad_d, np.float32)
-        I = np.full((nq, K), -1, np.int64)
         if k_eff == 0:
-            return RMOutput(distances=D, indices=I)
+            return RMOutput(distances=np.full((nq, K), pad_d, np.float32), indices=np.full((nq, K), -1, np.int64))
         rank_all = k_eff > _capi.MAX_K  # K = N callers (sem_dedup.py:45, sem_filter.py:491-497): full score rows + sort
-        rank, world = self._dist()
-        qrank, qworld, q_all = 0, 1, nq
-        if self._shard_queries:
-            from . import _dist
-
-            _, qrank, qworld = _dist.context(True, self._pg)
-            if qworld > 1:  # this rank's contiguous slice of the queries (possibly empty)
-                per = -(-nq // qworld)
-                q = q[min(nq, qrank * per):min(nq, (qrank + 1) * per)]
-                nq = int(q.shape[0])
+        qrank, qworld, rank, world, pg_query, pg_corpus = self._layout()
+        q_all = nq
+        if qworld > 1:  # this rank's contiguous slice of the queries (possibly empty)
+            per = -(-nq // qworld)
+            q = q[min(nq, qrank * per):min(nq, (qrank + 1) * per)]
+            nq = int(q.shape[0])
 
         queries = be.pack(q, ent.packed.mode)
         id_map = None
@@ -290,20 +336,28 @@ class HipVS(VS):
             id_map = be.to_device(sub)
         if world > 1:
             keys = self._allgather_merge(keys, world)
-        if qworld > 1:  # finished lists of every rank's query slice, side by side: one all-gather, no merge
+        if qworld > 1:  # finished lists of every query group's slice, side by side: one all-gather, no merge
             import torch
             from . import _dist
 
             per = -(-q_all // qworld)
             pad = torch.zeros((per, k_eff), dtype=keys.dtype, device=keys.device)
             pad[:nq] = keys
-            keys = _dist.all_gather_rows(pad, self._pg).reshape(qworld * per, k_eff)[:q_all].contiguous()
+            keys = _dist.all_gather_rows(pad, pg_query).reshape(qworld * per, k_eff)[:q_all].contiguous()
             nq = q_all
         Dd, Id = be.keys_to_result(keys, self.metric, id_map)
         if return_device and k_eff == K:  # results stay in HBM (torch tensors) for a GPU-side consumer
             return RMOutput(distances=Dd, indices=Id)
-        D[:, :k_eff] = Dd.cpu().numpy()
-        I[:, :k_eff] = Id.cpu().numpy()
+        if hasattr(be, "to_host"):  # both copies in flight together, one synchronisation, pinned-backed result arrays
+            Dh, Ih = be.to_host(Dd, Id)
+        else:
+            Dh, Ih = Dd.cpu().numpy(), Id.cpu().numpy()
+        if k_eff == K:
+            return RMOutput(distances=Dh, indices=Ih)
+        D = np.full((nq, K), pad_d, np.float32)  # fewer than K rows exist: faiss pads with -1 / -+FLT_MAX (Appendix A.2)
+        I = np.full((nq, K), -1, np.int64)
+        D[:, :k_eff] = Dh
+        I[:, :k_eff] = Ih
         return RMOutput(distances=D, indices=I)
 
     def scores(self, query_vectors, ids: list[int] | None = None):
@@ -365,7 +419,7 @@ class HipVS(VS):
         block = torch.full((nq, wmax), float("-inf"), dtype=torch.float32, device=queries.rows.device)
         if corpus.n:
             block[:, :corpus.n] = be.scores(corpus, queries, self.metric)
-        parts = _dist.all_gather_rows(block, self._pg)  # [world, nq, wmax]
+        parts = _dist.all_gather_rows(block, self._pg_corpus())  # [world, nq, wmax]
         sc = torch.cat([parts[r][:, :widths[r]] for r in range(world)], dim=1).contiguous()
         if sub is None:
             return sc, None
@@ -408,7 +462,7 @@ class HipVS(VS):
         # (with ceil(n / world) >= n rank 0 holds everything while the others still enter the collectives)
         if self._dist()[1] == 1:  # the whole index lives on this rank
             packed = ent.packed if sub is None else be.gather(ent.packed, be.to_device(sub))
-            res = _kmeans(None, ncentroids, niter=niter, backend=be, packed=packed, process_group=self._pg, **kw)
+            res = _kmeans(None, ncentroids, niter=niter, backend=be, packed=packed, process_group=self._pg_corpus(), **kw)
         else:
             if sub is None:
                 packed, local_pos, n_total = ent.packed, np.arange(ent.lo, ent.hi, dtype=np.int64), ent.n
@@ -417,8 +471,8 @@ class HipVS(VS):
                 packed = be.gather(ent.packed, be.to_device(sub[local_pos] - ent.lo))
                 n_total = int(sub.size)
             kw.pop("shard", None)
-            res = _kmeans(None, ncentroids, niter=niter, backend=be, packed=packed, shard=True, process_group=self._pg,
-                          n_total=n_total, local_pos=local_pos, **kw)
+            res = _kmeans(None, ncentroids, niter=niter, backend=be, packed=packed, shard=True,
+                          process_group=self._pg_corpus(), n_total=n_total, local_pos=local_pos, **kw)
         return res if return_result else res.assign
 
     # ------------------------------------------------------------------------------------------ multi-GPU
@@ -427,4 +481,4 @@ class HipVS(VS):
         through the host for any other process-group backend) and merge them on every rank (``lvs_merge_keys``)."""
         from . import _dist
 
-        return self.backend.merge_keys(_dist.all_gather_rows(keys, self._pg))
+        return self.backend.merge_keys(_dist.all_gather_rows(keys, self._pg_corpus()))

@@ -89,6 +89,13 @@ def worker(rank, world, port, tmp, out_q, backend_kind):
         res["q_bounds"] = (entq.lo, entq.hi, entq.packed.n)
         for name, out in (("q_full", vq(xq[:299], 7)), ("q_sub", vq(xq[:299], 7, ids=ids)), ("q_one", vq(xq[:1], 5))):
             res[name] = (np.asarray(out.distances), np.asarray(out.indices))
+        # the same two splits written as (query groups, corpus shards) pairs, and the planner's choice for 2 ranks
+        for name, shard in (("t_1x2", (1, 2)), ("t_2x1", (2, 1)), ("t_auto", "auto")):
+            vt = HipVS(backend=be, shard=shard)
+            vt.load_index(os.path.join(tmp, "idx"))
+            out = vt(xq[:299], 7)
+            entt = vt._resident[vt.index_dir]
+            res[name] = (np.asarray(out.distances), np.asarray(out.indices), (entt.lo, entt.hi))
         # index() under the query split: every rank holds the whole corpus, ONE rank writes the directory
         import lotus_amd.store as store_mod
 
@@ -187,6 +194,12 @@ def check(res, exact: bool):
         same_topk(r["q_full"], ref_qf, 7)
         same_topk(r["q_sub"], ref_qs, 7)
         same_topk(r["q_one"], ref_q1, 5)    # fewer queries than ranks: one rank's slice is empty
+    for r in res:
+        same_topk(r["t_1x2"][:2], ref_qf, 7)
+        same_topk(r["t_2x1"][:2], ref_qf, 7)
+        same_topk(r["t_auto"][:2], ref_qf, 7)
+        assert r["t_2x1"][2] == (0, NB)
+    assert [r["t_1x2"][2] for r in res] == [(0, per), (per, NB)]
     ref_qi = oracle.flat_search(xb32[:500], xq32[:9], 3)
     assert [r["q_index"][0] for r in res] == [1, 0]           # only the group's rank 0 wrote the directory
     assert res[0]["q_index"][1] == res[1]["q_index"][1]       # ... and both recorded the finished directory's signature
@@ -228,3 +241,100 @@ def check(res, exact: bool):
             sd = (xd.astype(np.float32) @ xd.astype(np.float32).T)
             for a, b in got ^ ref:
                 assert abs(sd[a, b] - 0.97) <= 2e-5, (a, b, sd[a, b])
+
+
+# ---- 2-D split: 2 query groups x 2 corpus shards on 4 ranks ------------------------------------------------------------
+def worker_2d(rank, world, port, tmp, out_q, backend_kind):
+    sys.path.insert(0, os.path.dirname(HERE))
+    sys.path.insert(0, HERE)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch
+    import torch.distributed as dist
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from lotus_amd import HipVS
+
+        if backend_kind == "hip":
+            from lotus_amd.backend import HipBackend
+
+            torch.cuda.set_device(0)
+            be = HipBackend("cuda:0")
+        else:
+            from oracle_backend import OracleBackend
+
+            be = OracleBackend()
+        xb, xq = search_data()
+        vs = HipVS(backend=be, shard=(2, 2))
+        vs.index(None, xb, os.path.join(tmp, "idx2d"))
+        ent = vs._resident[vs.index_dir]
+        res = {"rank": rank, "bounds": (ent.lo, ent.hi, ent.packed.n), "layout": vs._layout()[:4]}
+        ids = subset_ids()
+        for name, out in (("full", vs(xq[:299], 7)), ("sub", vs(xq[:299], 7, ids=ids)), ("one", vs(xq[:1], 5)),
+                          ("k1000", vs(xq[:40], 1000))):
+            res[name] = (np.asarray(out.distances), np.asarray(out.indices))
+        res["scores"] = vs.scores(xq[:6])
+        xk = km_data()
+        vk = HipVS(backend=be, shard=(2, 2))
+        vk.index(None, xk, os.path.join(tmp, "km2d"))
+        r = vk.kmeans(None, KM_K, niter=4, return_result=True, max_points_per_centroid=128)
+        res["km"] = (r.centroids, r.assign, r.obj)
+        out_q.put(res)
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def run_2d(tmp, backend_kind):
+    import torch.multiprocessing as mp
+
+    world = 4
+    port = 31500 + (os.getpid() % 2000) + (7 if backend_kind == "hip" else 0)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=worker_2d, args=(r, world, port, str(tmp), q, backend_kind)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=600) for _ in range(world)], key=lambda t: t["rank"])
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    return res
+
+
+def check_2d(res, exact: bool):
+    import oracle
+    import synth
+    from lotus_amd.cluster import kmeans
+    from oracle_backend import OracleBackend
+
+    xb, xq = search_data()
+    xb32, xq32 = xb.astype(np.float32), xq.astype(np.float32)
+    per = -(-NB // 2)
+    # rank r: query group r // 2, corpus shard r % 2
+    assert [r["layout"] for r in res] == [(0, 2, 0, 2), (0, 2, 1, 2), (1, 2, 0, 2), (1, 2, 1, 2)]
+    assert [r["bounds"][:2] for r in res] == [(0, per), (per, NB), (0, per), (per, NB)]
+
+    def same_topk(got, ref):
+        D, I = got
+        Dr, Ir = ref
+        if exact:
+            assert np.array_equal(I, Ir) and np.allclose(D, Dr, atol=1e-6)
+        else:
+            err, hard, recall = synth.compare_topk(Dr, Ir, D, I, atol=1e-5)
+            assert err <= 1e-5 and hard == 0 and recall >= 0.9999, (err, hard, recall)
+
+    ids = subset_ids()
+    refs = {"full": oracle.flat_search(xb32, xq32[:299], 7), "sub": oracle.flat_search(xb32, xq32[:299], 7, ids=ids),
+            "one": oracle.flat_search(xb32, xq32[:1], 5), "k1000": oracle.flat_search(xb32, xq32[:40], 1000)}
+    S = xq32[:6] @ xb32.T
+    for r in res:
+        for name, ref in refs.items():
+            same_topk(r[name], ref)  # every rank ends with the complete answer
+        assert np.abs(r["scores"] - S).max() <= 1e-5
+    one = kmeans(km_data(), KM_K, niter=4, backend=OracleBackend(), max_points_per_centroid=128)
+    for r in res:  # k-means runs inside a corpus group (2 shards); the two query groups repeat it
+        c, a, o = r["km"]
+        assert np.allclose(c, one.centroids, atol=2e-5) and (a == one.assign).mean() >= 0.999 and np.allclose(o, one.obj, rtol=1e-5)

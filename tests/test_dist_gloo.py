@@ -7,3 +7,10 @@ import dist_cases
 def test_sharded_operators_equal_single_process(tmp_path):
     res = dist_cases.run(tmp_path, "oracle")
     dist_cases.check(res, exact=True)
+
+
+def test_2d_split_on_four_ranks(tmp_path):
+    """2 query groups x 2 corpus shards (HipVS(shard=(2, 2))): merge inside a corpus group, concatenation across the
+    query groups, sub-groups for the k-means / score-row collectives."""
+    res = dist_cases.run_2d(tmp_path, "oracle")
+    dist_cases.check_2d(res, exact=True)
