@@ -31,7 +31,8 @@ extern "C" {
 
 #define LVS_ABI_VERSION 3 /* 2: pack modes in lvs_flat_search_workspace_bytes, lvs_build_flags, k-means device update;
                              3: k-means iteration entirely on the device (objective, split, repack, accumulate from keys),
-                                lvs_pack_rows_checked, lvs_margin_select_stats */
+                                lvs_pack_rows_checked (validation + power-of-two scale), lvs_absmax, lvs_margin_select_stats;
+                                scale exponents in lvs_unpack_rows / lvs_keys_to_result / lvs_scores / lvs_range_join */
 
 #define LVS_OK 0
 #define LVS_EINVAL (-1)   /* bad argument */
@@ -75,20 +76,30 @@ int32_t lvs_packed_ld(int32_t d, int32_t pack_mode);        /* leading dimension
  * out_norms_sq (nullable): [n] float32 |x_i|^2 of the stored (rounded) values, used by the L2 metric. */
 int32_t lvs_pack_rows(const void* src, int32_t src_dtype, int64_t n, int32_t d, int32_t pack_mode,
                       int32_t normalize, void* dst, float* out_norms_sq, void* stream);
-/* The same with input validation (faiss takes any float32, faiss_vs.py:24; fp16-based rows do not): *out_flags (device word,
- * nullable, OR-ed into - zero it first) receives LVS_PACK_FLAG_NONFINITE when an input value is inf / NaN and
- * LVS_PACK_FLAG_RANGE when a finite value lies outside fp16's range (|x| > 65504 after the optional normalisation). */
+/* The same with input validation and an exact scale (faiss takes any float32, faiss_vs.py:24; fp16-based rows do not):
+ * every value is multiplied by 2^scale_exp before it is rounded (a power of two: exact), so a caller can move its
+ * embeddings into the middle of fp16's range whatever their magnitude - the hi|lo pair then keeps ~22 significant bits
+ * for row norms of 1e-2 as for 1e+2 (unscaled, the lo half of small values falls into fp16's subnormals).  Norms and
+ * scores downstream are those of the scaled values: 2^(e_b + e_q) x the true inner product, 2^(2e) x the true squared
+ * distance when both sides share e (required for L2); lvs_keys_to_result / lvs_scores / lvs_range_join / lvs_unpack_rows
+ * take the exponent to undo it.  *out_flags (device word, nullable, OR-ed into - zero it first) receives
+ * LVS_PACK_FLAG_NONFINITE when an input value is inf / NaN and LVS_PACK_FLAG_RANGE when a finite value lies outside fp16's
+ * range after scaling (|x 2^scale_exp| > 65504). */
 #define LVS_PACK_FLAG_NONFINITE 1
 #define LVS_PACK_FLAG_RANGE 2
 int32_t lvs_pack_rows_checked(const void* src, int32_t src_dtype, int64_t n, int32_t d, int32_t pack_mode, int32_t normalize,
-                              void* dst, float* out_norms_sq, uint32_t* out_flags, void* stream);
+                              int32_t scale_exp, void* dst, float* out_norms_sq, uint32_t* out_flags, void* stream);
+/* *inout_bits (device word) = max(*inout_bits, bit pattern of the largest |x| of src [n][d]): non-negative floats order like
+ * their bit patterns, so chunks accumulate with atomicMax; inf / NaN show up as patterns >= 0x7F800000.  How a caller
+ * picks scale_exp. */
+int32_t lvs_absmax(const void* src, int32_t src_dtype, int64_t n, int32_t d, uint32_t* inout_bits, void* stream);
 /* dst[i] = src[ids[i]] for packed rows (the `ids` branch gather, faiss_vs.py:59-64). */
 int32_t lvs_gather_rows(const void* src, int32_t ld, const int64_t* ids, int64_t n_ids, void* dst, void* stream);
 /* dst[i][0..d) = float32 value (hi + lo) of packed row ids[i] (row i when ids is NULL): the inverse of lvs_pack_rows
- * up to its rounding - serves `get_vectors_from_index` (faiss_vs.py:38-41) for device-resident indexes and the initial
+ * up to its rounding (values x 2^-scale_exp: the exponent the rows were packed with) - serves `get_vectors_from_index` (faiss_vs.py:38-41) for device-resident indexes and the initial
  * k-means centroids (lotus/utils.py:62) without a host copy of the matrix. */
-int32_t lvs_unpack_rows(const void* src, int32_t d, int32_t pack_mode, const int64_t* ids, int64_t n, float* dst,
-                        void* stream);
+int32_t lvs_unpack_rows(const void* src, int32_t d, int32_t pack_mode, const int64_t* ids, int64_t n, int32_t scale_exp,
+                        float* dst, void* stream);
 /* dst[i] = src[ids[i]] for a float32 vector (row norms of a gathered subset). */
 int32_t lvs_gather_f32(const float* src, const int64_t* ids, int64_t n_ids, float* dst, void* stream);
 
@@ -131,15 +142,16 @@ int32_t lvs_merge_keys(const uint64_t* parts, int32_t nparts, int64_t nq, int32_
                        void* stream);
 /* keys -> faiss-shaped result (faiss_vs.py:67,75 return values): D float32 [nq][k], I int64 [nq][k];
  * empty slots become I = -1, D = -FLT_MAX (IP) / +FLT_MAX (L2).  id_map (nullable): I = id_map[id]
- * (the sub-index -> global id remap of faiss_vs.py:71-72). */
+ * (the sub-index -> global id remap of faiss_vs.py:71-72).  score_exp: D is multiplied by 2^-score_exp (the sum of the two
+ * operands' pack exponents; 0 for unscaled rows). */
 int32_t lvs_keys_to_result(const uint64_t* keys, int64_t nq, int32_t k, int32_t metric, const int64_t* id_map,
-                           float* out_D, int64_t* out_I, void* stream);
+                           int32_t score_exp, float* out_D, int64_t* out_I, void* stream);
 
 /* ---- full score rows (callers that ask for K = N: sem_dedup.py:45, sem_filter.py:491-497, sem_join.py:367):
  * out [nq][ld_out] float32 "better" scores (IP: the product; L2: minus the squared distance). ---- */
 int32_t lvs_scores(const void* xb, int32_t xb_pack, int64_t nb, const void* xq, int32_t xq_pack, int64_t nq, int32_t d,
-                   int32_t metric, const float* xb_norms_sq, const float* xq_norms_sq, float* out, int64_t ld_out,
-                   void* stream);
+                   int32_t metric, const float* xb_norms_sq, const float* xq_norms_sq, int32_t score_exp, float* out,
+                   int64_t ld_out, void* stream);
 /* Rank every score row best-first: scores [nq][ld] (from lvs_scores) -> out_keys [nq][nb], ids = id_offset + column.
  * nq * nb must stay below 2^32.  Serves K = N callers beyond LVS_MAX_K. */
 int64_t lvs_sort_rows_workspace_bytes(int64_t nq, int64_t nb);
@@ -152,11 +164,12 @@ int32_t lvs_sort_rows_desc(const float* scores, int64_t nq, int64_t nb, int64_t 
  * corpus row q_row0 + r and only pairs with id > q_row0 + r are kept (each unordered pair once), tiles below the
  * diagonal are skipped.  qt_stride / qt_phase deal 256-query tiles round-robin to ranks (multi-GPU, corpus replicated).
  * out_count (device uint64, zeroed by the caller) receives the number of qualifying pairs; pairs beyond `capacity`
- * are counted but not stored, so a caller can size the buffers and run again.  Pair order is unspecified. ---- */
+ * are counted but not stored, so a caller can size the buffers and run again.  Pair order is unspecified.  threshold and
+ * out_s are in the caller's units: score_exp (sum of the operands' pack exponents) is applied on the way in and out. ---- */
 int32_t lvs_range_join(const void* xb, int32_t xb_pack, int64_t nb, const void* xq, int32_t xq_pack, int64_t nq,
                        int32_t d, int32_t metric, const float* xb_norms_sq, const float* xq_norms_sq, float threshold,
-                       int64_t q_row0, int64_t id_offset, int32_t qt_stride, int32_t qt_phase, int64_t capacity,
-                       int64_t* out_q, int64_t* out_j, float* out_s, uint64_t* out_count, void* stream);
+                       int32_t score_exp, int64_t q_row0, int64_t id_offset, int32_t qt_stride, int32_t qt_phase,
+                       int64_t capacity, int64_t* out_q, int64_t* out_j, float* out_s, uint64_t* out_count, void* stream);
 
 /* ---- k-means pieces: replace faiss `Kmeans(d, k, niter).train(x)` (lotus/utils.py:61-62); the assignment step and
  * the final `kmeans.index.search(x, 1)` (utils.py:65) are lvs_flat_search_keys with k = 1 and LVS_METRIC_L2 - or, in ONE

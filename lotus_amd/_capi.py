@@ -32,19 +32,20 @@ SIGNATURES = {
     "lvs_device_info": (_i32, [_i32, ctypes.c_char_p, _i32, ctypes.POINTER(_i32), ctypes.POINTER(_i64)]),
     "lvs_packed_ld": (_i32, [_i32, _i32]),
     "lvs_pack_rows": (_i32, [_vp, _i32, _i64, _i32, _i32, _i32, _vp, _vp, _vp]),
-    "lvs_pack_rows_checked": (_i32, [_vp, _i32, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
+    "lvs_pack_rows_checked": (_i32, [_vp, _i32, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
+    "lvs_absmax": (_i32, [_vp, _i32, _i64, _i32, _vp, _vp]),
     "lvs_gather_rows": (_i32, [_vp, _i32, _vp, _i64, _vp, _vp]),
     "lvs_gather_f32": (_i32, [_vp, _vp, _i64, _vp, _vp]),
-    "lvs_unpack_rows": (_i32, [_vp, _i32, _i32, _vp, _i64, _vp, _vp]),
+    "lvs_unpack_rows": (_i32, [_vp, _i32, _i32, _vp, _i64, _i32, _vp, _vp]),
     "lvs_flat_search_workspace_bytes": (_i64, [_i64, _i64, _i32, _i32, _i32, _i32]),
     "lvs_flat_search_keys": (_i32, [_vp, _i32, _i64, _vp, _i32, _i64, _i32, _i32, _i32, _vp, _vp, _i64, _vp, _vp,
                                     _vp, _i64, _vp]),
     "lvs_merge_keys": (_i32, [_vp, _i32, _i64, _i32, _vp, _vp]),
-    "lvs_keys_to_result": (_i32, [_vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp]),
-    "lvs_scores": (_i32, [_vp, _i32, _i64, _vp, _i32, _i64, _i32, _i32, _vp, _vp, _vp, _i64, _vp]),
+    "lvs_keys_to_result": (_i32, [_vp, _i64, _i32, _i32, _vp, _i32, _vp, _vp, _vp]),
+    "lvs_scores": (_i32, [_vp, _i32, _i64, _vp, _i32, _i64, _i32, _i32, _vp, _vp, _i32, _vp, _i64, _vp]),
     "lvs_sort_rows_workspace_bytes": (_i64, [_i64, _i64]),
     "lvs_sort_rows_desc": (_i32, [_vp, _i64, _i64, _i64, _i64, _vp, _vp, _i64, _vp]),
-    "lvs_range_join": (_i32, [_vp, _i32, _i64, _vp, _i32, _i64, _i32, _i32, _vp, _vp, ctypes.c_float, _i64, _i64, _i32,
+    "lvs_range_join": (_i32, [_vp, _i32, _i64, _vp, _i32, _i64, _i32, _i32, _vp, _vp, ctypes.c_float, _i32, _i64, _i64, _i32,
                               _i32, _i64, _vp, _vp, _vp, _vp, _vp]),
     "lvs_nearest_hi_workspace_bytes": (_i64, [_i64, _i64, _i32]),
     "lvs_nearest_hi": (_i32, [_vp, _i32, _i64, _vp, _i32, _i64, _i32, _i32, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp]),

@@ -16,10 +16,12 @@ class PackedRows:
     """Device image of an embedding matrix: fp16 rows [n, ld] (+ |x|^2 per row)."""
 
     rows: "object"  # torch.Tensor float16 [n, ld]
-    norms: "object"  # torch.Tensor float32 [n]
+    norms: "object"  # torch.Tensor float32 [n]: |row|^2 of the STORED (scaled) values
     n: int
     d: int
     mode: int  # _capi.PACK_F16 | _capi.PACK_SPLIT
+    exp: int = 0  # the rows hold x * 2^exp (an exact power-of-two scale chosen at pack time; 0 = as given)
+    flags: "object" = None  # device int32 [1] of LVS_PACK_FLAG_* when the pack was validated lazily (check="lazy")
 
 
 def _ptr(t) -> int:
@@ -127,44 +129,100 @@ class HipBackend:
         return tuple(h.numpy() for h in outs)
 
     # ---- packing ----
-    def pack(self, x, mode: int, normalize: bool = False, check: bool = False) -> PackedRows:
-        """x: numpy [n,d] (float16/32/64) or a torch CUDA tensor (float16/float32).  ``check``: validate the values on the
-        device while packing - ``ValueError`` for inf / NaN or magnitudes beyond fp16's range (one read-back of a flag
-        word; faiss itself accepts any float32, the fp16-based rows here do not - DESIGN.md section 7)."""
+    SCALE_TARGET_EXP = 6  # exp="auto": the largest |x| lands in [2^6, 2^7) - components ~10x smaller still have their lo half
+                          # in fp16's normal range, values up to 500x larger than the sampled maximum still fit
+
+    def absmax(self, x) -> float:
+        """Largest |value| of a device tensor (float16 / float32) through ``lvs_absmax``."""
+        torch = self.torch
+        bits = torch.zeros((1,), dtype=torch.int32, device=self.device)
+        t = x.contiguous()
+        if t.dtype not in (torch.float16, torch.float32):
+            t = t.to(torch.float32)
+        n, d = (int(t.shape[0]), int(t.shape[1])) if t.dim() == 2 else (1, int(t.numel()))
+        self._c("lvs_absmax", _ptr(t), _capi.DTYPE_F16 if t.dtype == torch.float16 else _capi.DTYPE_F32, n, d, _ptr(bits),
+                self._stream())
+        return float(np.array([int(bits.item())], np.uint32).view(np.float32)[0])
+
+    @classmethod
+    def exp_for(cls, absmax: float) -> int:
+        """The pack exponent that moves ``absmax`` to [2^SCALE_TARGET_EXP, 2^(SCALE_TARGET_EXP + 1))."""
+        if not np.isfinite(absmax) or absmax <= 0.0:
+            return 0
+        return int(np.clip(cls.SCALE_TARGET_EXP - int(np.floor(np.log2(absmax))), -60, 60))
+
+    def pack(self, x, mode: int, normalize: bool = False, check=False, exp=0) -> PackedRows:
+        """x: numpy [n,d] (float16/32/64) or a torch CUDA tensor (float16/float32).
+
+        ``exp``: every value is multiplied by 2^exp before it is rounded (exact).  ``"auto"`` picks the exponent from the
+        data (hi|lo rows only: fp32-accurate rows keep ~22 significant bits whatever the embeddings' magnitude; fp16 rows
+        are stored as given): from the first chunk's largest magnitude, with 500x headroom - should a later chunk exceed
+        it, everything is packed again with the exponent of the true maximum.
+        ``check``: validate the values on the device while packing.  ``True`` raises ``ValueError`` for inf / NaN or for
+        magnitudes beyond fp16's range (one read-back of a flag word; faiss itself accepts any float32, the fp16-based
+        rows here do not - DESIGN.md section 7); ``"lazy"`` leaves the flag word on the device (``PackedRows.flags``) for
+        the caller to read together with its results (``raise_for_flags``)."""
         torch = self.torch
         is_tensor = torch.is_tensor(x)
         n, d = int(x.shape[0]), int(x.shape[1])
         ld = int(self.lib.lvs_packed_ld(d, mode))
         if ld <= 0:
             raise LotusHipError(f"bad dimension d={d}")
+        auto = isinstance(exp, str)
+        if auto and exp != "auto":
+            raise ValueError("exp must be an int or 'auto'")
+        if auto and (mode != _capi.PACK_SPLIT or n == 0 or normalize):
+            auto, exp = False, 0
         rows = torch.empty((n, ld), dtype=torch.float16, device=self.device)
         norms = torch.empty((n,), dtype=torch.float32, device=self.device)
-        flags = torch.zeros((1,), dtype=torch.int32, device=self.device) if check else None
+        flags = torch.zeros((1,), dtype=torch.int32, device=self.device) if (check or auto) else None
+        amax_bits = torch.zeros((1,), dtype=torch.int32, device=self.device) if auto else None
         step = self.PACK_CHUNK_ROWS
-        for r0 in range(0, n, step):
-            r1 = min(n, r0 + step)
+
+        def chunk_of(r0, r1):
             if is_tensor:
                 chunk = x[r0:r1].contiguous()
                 if chunk.dtype not in (torch.float16, torch.float32):
                     chunk = chunk.to(torch.float32)
                 if chunk.device != self.device:
                     chunk = chunk.to(self.device)
-            else:
-                c = x[r0:r1]
-                c = np.ascontiguousarray(c, dtype=np.float16 if c.dtype == np.float16 else np.float32)
-                chunk = self._h2d(c)
-            src_dtype = _capi.DTYPE_F16 if chunk.dtype == torch.float16 else _capi.DTYPE_F32
-            self._c("lvs_pack_rows_checked", _ptr(chunk), src_dtype, r1 - r0, d, mode, int(bool(normalize)),
-                    _ptr(rows[r0:r1]), _ptr(norms[r0:r1]), _ptr(flags), self._stream())
-            del chunk
-        if check:
+                return chunk
+            c = x[r0:r1]
+            c = np.ascontiguousarray(c, dtype=np.float16 if c.dtype == np.float16 else np.float32)
+            return self._h2d(c)
+
+        def run(e: int):
+            for r0 in range(0, n, step):
+                r1 = min(n, r0 + step)
+                chunk = chunk_of(r0, r1)
+                src_dtype = _capi.DTYPE_F16 if chunk.dtype == torch.float16 else _capi.DTYPE_F32
+                if auto:
+                    self._c("lvs_absmax", _ptr(chunk), src_dtype, r1 - r0, d, _ptr(amax_bits), self._stream())
+                    if r0 == 0 and e is None:  # the exponent comes from the first chunk (one read-back per index build)
+                        e = self.exp_for(float(np.array([int(amax_bits.item())], np.uint32).view(np.float32)[0]))
+                self._c("lvs_pack_rows_checked", _ptr(chunk), src_dtype, r1 - r0, d, mode, int(bool(normalize)), int(e),
+                        _ptr(rows[r0:r1]), _ptr(norms[r0:r1]), _ptr(flags), self._stream())
+                del chunk
+            return e
+
+        e = run(None if auto else int(exp))
+        if auto and n > step:  # a later chunk may have exceeded the first chunk's range: pack again with the true maximum's
             f = int(flags.item())
-            if f & _capi.PACK_FLAG_NONFINITE:
-                raise ValueError("embeddings contain inf or NaN")
-            if f & _capi.PACK_FLAG_RANGE:
-                raise ValueError("embedding values exceed fp16's range (|x| > 65504): rescale the embeddings "
-                                 "(the device rows are fp16 or fp16 hi|lo pairs)")
-        return PackedRows(rows=rows, norms=norms, n=n, d=d, mode=mode)
+            if f & _capi.PACK_FLAG_RANGE and not f & _capi.PACK_FLAG_NONFINITE:
+                flags.zero_()
+                e = run(self.exp_for(float(np.array([int(amax_bits.item())], np.uint32).view(np.float32)[0])))
+        out = PackedRows(rows=rows, norms=norms, n=n, d=d, mode=mode, exp=int(e or 0), flags=flags if check == "lazy" else None)
+        if check is True or (auto and check != "lazy"):
+            self.raise_for_flags(int(flags.item()))
+        return out
+
+    @staticmethod
+    def raise_for_flags(f: int, what: str = "embeddings") -> None:
+        if f & _capi.PACK_FLAG_NONFINITE:
+            raise ValueError(f"{what} contain inf or NaN")
+        if f & _capi.PACK_FLAG_RANGE:
+            raise ValueError(f"{what}: values exceed fp16's range (|x| > 65504 after the index's power-of-two scale): "
+                             "rescale them (the device rows are fp16 or fp16 hi|lo pairs)")
 
     def gather(self, src: PackedRows, ids_dev) -> PackedRows:
         torch = self.torch
@@ -174,20 +232,22 @@ class HipBackend:
         norms = torch.empty((m,), dtype=torch.float32, device=self.device)
         self._c("lvs_gather_rows", _ptr(src.rows), ld, _ptr(ids_dev), m, _ptr(rows), self._stream())
         self._c("lvs_gather_f32", _ptr(src.norms), _ptr(ids_dev), m, _ptr(norms), self._stream())
-        return PackedRows(rows=rows, norms=norms, n=m, d=src.d, mode=src.mode)
+        return PackedRows(rows=rows, norms=norms, n=m, d=src.d, mode=src.mode, exp=src.exp)
 
-    def unpack(self, src: PackedRows, ids_dev=None):
-        """float32 values [m, d] of the packed rows ``ids_dev`` (all rows when None), as a device tensor."""
+    def unpack(self, src: PackedRows, ids_dev=None, raw: bool = False):
+        """float32 values [m, d] of the packed rows ``ids_dev`` (all rows when None), as a device tensor - the caller's
+        values (pack scale undone); ``raw=True``: the stored values x 2^exp as they are (k-means works on those)."""
         torch = self.torch
         m = src.n if ids_dev is None else int(ids_dev.numel())
         out = torch.empty((m, src.d), dtype=torch.float32, device=self.device)
-        self._c("lvs_unpack_rows", _ptr(src.rows), src.d, src.mode, _ptr(ids_dev), m, _ptr(out), self._stream())
+        self._c("lvs_unpack_rows", _ptr(src.rows), src.d, src.mode, _ptr(ids_dev), m, 0 if raw else int(src.exp), _ptr(out),
+                self._stream())
         return out
 
     @staticmethod
     def slice_rows(src: PackedRows, r0: int, r1: int) -> PackedRows:
         """Rows [r0, r1) of a packed matrix (a view: same HBM)."""
-        return PackedRows(rows=src.rows[r0:r1], norms=src.norms[r0:r1], n=r1 - r0, d=src.d, mode=src.mode)
+        return PackedRows(rows=src.rows[r0:r1], norms=src.norms[r0:r1], n=r1 - r0, d=src.d, mode=src.mode, exp=src.exp)
 
     # ---- search ----
     CERT_MIN_PAIRS = 1 << 26  # below this many (query, row) pairs the extra launches cost more than the two passes saved
@@ -204,6 +264,8 @@ class HipBackend:
         torch = self.torch
         if corpus.d != queries.d:
             raise ValueError("corpus / query dimension mismatch")
+        if metric == _capi.METRIC_L2 and corpus.exp != queries.exp:
+            raise ValueError("squared L2 needs both operands packed with the same scale exponent")
         split = corpus.mode == _capi.PACK_SPLIT or queries.mode == _capi.PACK_SPLIT
         if one_pass is None:
             one_pass = queries.n * corpus.n >= self.CERT_MIN_PAIRS
@@ -261,7 +323,7 @@ class HipBackend:
         per_q += sub * int(corpus.mode == _capi.PACK_SPLIT)
         c = 1.0 if metric == _capi.METRIC_IP else 2.0
         scale = per_q * c
-        slack = 1e-6 * (1.0 + R * R) + c * sub * R * int(queries.mode == _capi.PACK_SPLIT)
+        slack = 1e-6 * (2.0 ** (corpus.exp + queries.exp) + R * R) + c * sub * R * int(queries.mode == _capi.PACK_SPLIT)
         idx = torch.empty((nq,), dtype=torch.int64, device=self.device)
         cnt = torch.zeros((1,), dtype=torch.int64, device=self.device)
         self._c("lvs_certify_topk", _ptr(approx), _ptr(exact), _ptr(queries.norms), nq, k1, k, float(scale), float(slack),
@@ -311,7 +373,8 @@ class HipBackend:
         ip = metric == _capi.METRIC_IP
         c = 2.0 if ip else 4.0
         coef = [c, c * ((2.0 ** -11) * qsplit + 8e-6) + 2.0 ** -16 * (1.0 if ip else 2.0),
-                1e-6, qsplit * c * (dpad ** 0.5) * 2.0 ** -25, 1e-6 + (0.0 if ip else 2.0 ** -16)]
+                1e-6 * 2.0 ** (corpus.exp + queries.exp), qsplit * c * (dpad ** 0.5) * 2.0 ** -25,
+                1e-6 + (0.0 if ip else 2.0 ** -16)]
         if corpus_stats is None:
             R = float(corpus.norms.max().sqrt().item())
             E = 0.0
@@ -356,19 +419,29 @@ class HipBackend:
         self._c("lvs_merge_keys", _ptr(parts.contiguous()), P, nq, k, _ptr(out), self._stream())
         return out
 
-    def keys_to_result(self, keys, metric: int, id_map=None):
+    def keys_to_result(self, keys, metric: int, id_map=None, score_exp: int = 0):
+        """keys -> (D float32, I int64) device tensors.  ``score_exp``: sum of the two operands' pack exponents - the scores
+        inside the keys are 2^score_exp x the caller's (``score_exp_of``)."""
         torch = self.torch
         nq, k = int(keys.shape[0]), int(keys.shape[1])
         D = torch.empty((nq, k), dtype=torch.float32, device=self.device)
         I = torch.empty((nq, k), dtype=torch.int64, device=self.device)
-        self._c("lvs_keys_to_result", _ptr(keys), nq, k, metric, _ptr(id_map), _ptr(D), _ptr(I), self._stream())
+        self._c("lvs_keys_to_result", _ptr(keys), nq, k, metric, _ptr(id_map), int(score_exp), _ptr(D), _ptr(I),
+                self._stream())
         return D, I
+
+    @staticmethod
+    def score_exp_of(corpus: PackedRows, queries: PackedRows) -> int:
+        return int(corpus.exp) + int(queries.exp)
 
     def scores(self, corpus: PackedRows, queries: PackedRows, metric: int):
         torch = self.torch
         out = torch.empty((queries.n, corpus.n), dtype=torch.float32, device=self.device)
+        if metric == _capi.METRIC_L2 and corpus.exp != queries.exp:
+            raise ValueError("squared L2 needs both operands packed with the same scale exponent")
         self._c("lvs_scores", _ptr(corpus.rows), corpus.mode, corpus.n, _ptr(queries.rows), queries.mode, queries.n,
-                corpus.d, metric, _ptr(corpus.norms), _ptr(queries.norms), _ptr(out), corpus.n, self._stream())
+                corpus.d, metric, _ptr(corpus.norms), _ptr(queries.norms), self.score_exp_of(corpus, queries), _ptr(out),
+                corpus.n, self._stream())
         return out
 
     def rank_scores(self, sc, id_offset: int = 0):
@@ -426,7 +499,8 @@ class HipBackend:
                 cnt.zero_()
                 self._c("lvs_range_join", _ptr(corpus.rows), corpus.mode, corpus.n, _ptr(qs.rows), qs.mode, qs.n,
                         corpus.d, metric, _ptr(corpus.norms), _ptr(qs.norms), float(threshold),
-                        int(q_row0 + c0) if q_row0 >= 0 else -1, int(id_offset), int(stride), int(phase), int(cap),
+                        self.score_exp_of(corpus, qs), int(q_row0 + c0) if q_row0 >= 0 else -1, int(id_offset), int(stride),
+                        int(phase), int(cap),
                         _ptr(oq), _ptr(oj), _ptr(os_), _ptr(cnt), self._stream())
                 n = int(cnt.item())
                 if n <= cap:
@@ -472,8 +546,9 @@ class HipBackend:
         self._c("lvs_kmeans_objective", _ptr(centroids), _ptr(sums), _ptr(counts), k, d, _ptr(x2), _ptr(out),
                 _ptr(self._obj_ws), int(self._obj_ws.numel()), self._stream())
 
-    def kmeans_pack_centroids(self, centroids, mode: int):
-        """-> (PackedRows of the centroids, device float32 [2] = (largest |c|^2, largest |lo part|^2))."""
+    def kmeans_pack_centroids(self, centroids, mode: int, exp: int = 0):
+        """-> (PackedRows of the centroids, device float32 [2] = (largest |c|^2, largest |lo part|^2)).  ``centroids`` are
+        in the points' scaled domain already (``exp``: the points' pack exponent, recorded on the result)."""
         torch = self.torch
         k, d = int(centroids.shape[0]), int(centroids.shape[1])
         ld = int(self.lib.lvs_packed_ld(d, mode))
@@ -482,9 +557,9 @@ class HipBackend:
         cstats = torch.empty((2,), dtype=torch.float32, device=self.device)
         self._c("lvs_kmeans_pack_centroids", _ptr(centroids), k, d, mode, _ptr(rows), _ptr(norms), _ptr(cstats),
                 self._stream())
-        return PackedRows(rows=rows, norms=norms, n=k, d=d, mode=mode), cstats
+        return PackedRows(rows=rows, norms=norms, n=k, d=d, mode=mode, exp=int(exp)), cstats
 
-    def kmeans_finish(self, sums, counts, centroids, n_train: int, mode: int, nsplit_out=None):
+    def kmeans_finish(self, sums, counts, centroids, n_train: int, mode: int, nsplit_out=None, exp: int = 0):
         """The rest of a faiss iteration after the sums, one C-ABI call, nothing read back: centroids (device float32
         [k,d], in place) = sums / counts where counts > 0 (compute_centroids), faiss's empty-cluster split on the device
         (``nsplit_out``: device int32 [1]), and the repacked centroids -> (PackedRows, stats) as ``kmeans_pack_centroids``."""
@@ -496,7 +571,7 @@ class HipBackend:
         cstats = torch.empty((2,), dtype=torch.float32, device=self.device)
         self._c("lvs_kmeans_update_centroids", _ptr(sums), _ptr(counts), k, d, int(n_train), _ptr(centroids),
                 _ptr(nsplit_out), mode, _ptr(rows), _ptr(norms), _ptr(cstats), self._stream())
-        return PackedRows(rows=rows, norms=norms, n=k, d=d, mode=mode), cstats
+        return PackedRows(rows=rows, norms=norms, n=k, d=d, mode=mode, exp=int(exp)), cstats
 
     def kmeans_update_centroids(self, sums, counts, centroids) -> None:
         """centroids (device float32 [k,d], in place) = sums / counts where counts > 0 (faiss compute_centroids) - the

@@ -67,8 +67,10 @@ def kmeans(x, k: int, niter: int = 20, seed: int = 1234, max_points_per_centroid
             raise ValueError("x must be 2-D")
         if pack_mode is None:
             pack_mode = _capi.PACK_F16 if x.dtype == np.float16 else _capi.PACK_SPLIT
-        packed = be.pack(x, pack_mode)
+        packed = be.pack(x, pack_mode, exp="auto", check=True)
     d = packed.d
+    pexp = int(getattr(packed, "exp", 0))  # the device rows hold x * 2^pexp: centroids, sums and objectives below live in
+    # that scaled domain (power-of-two scaling commutes with every float32 operation of the loop) and are unscaled at the end
     n = int(n_total) if n_total is not None else packed.n
     k = int(k)
     if n < k:
@@ -107,12 +109,12 @@ def kmeans(x, k: int, niter: int = 20, seed: int = 1234, max_points_per_centroid
         """float32 [len(ids), d] values of the rows `ids` on the device (every rank gets all of them)."""
         held, rows = local_rows(ids)
         if not sharded_rows:
-            return be.unpack(packed, be.to_device(rows))
+            return be.unpack(packed, be.to_device(rows), raw=True)
         import torch
 
         vals = torch.zeros((len(ids), d), dtype=torch.float32, device=packed.rows.device)
         if held.any():
-            vals[be.to_device(np.flatnonzero(held))] = be.unpack(packed, be.to_device(rows))
+            vals[be.to_device(np.flatnonzero(held))] = be.unpack(packed, be.to_device(rows), raw=True)
         _dist.all_reduce_sum_([vals], process_group)  # every row is held by exactly one rank: x + 0 + ... is exact
         return vals
 
@@ -139,7 +141,7 @@ def kmeans(x, k: int, niter: int = 20, seed: int = 1234, max_points_per_centroid
         x2 = train.norms.double().sum().reshape(1)  # sum of |x_i|^2 over this rank's training rows (constant over the iterations)
         obj_dev = torch.zeros((max(niter, 1),), dtype=torch.float64, device=dev)
         nsplit_dev = torch.zeros((max(niter, 1),), dtype=torch.int32, device=dev)
-        cpk, cstats = be.kmeans_pack_centroids(centroids, cmode)
+        cpk, cstats = be.kmeans_pack_centroids(centroids, cmode, exp=pexp)
         for it in range(niter):
             keys = be.nearest(cpk, train, _capi.METRIC_L2, exact_scores=False, corpus_stats=cstats, stats=stats)  # ids only ...
             sums, counts = be.kmeans_accumulate_keys(train, keys, k)
@@ -149,12 +151,12 @@ def kmeans(x, k: int, niter: int = 20, seed: int = 1234, max_points_per_centroid
             if dist is not None:
                 _dist.all_reduce_sum_([sums, counts, obj_dev[it:it + 1]], process_group)
             # centroid division + faiss split_clusters (same RNG stream on every rank) + repack, nothing read back
-            cpk, cstats = be.kmeans_finish(sums, counts, centroids, nt, cmode, nsplit_dev[it:it + 1])
-        obj[:] = obj_dev[:niter].cpu().numpy().astype(np.float32)
+            cpk, cstats = be.kmeans_finish(sums, counts, centroids, nt, cmode, nsplit_dev[it:it + 1], exp=pexp)
+        obj[:] = (obj_dev[:niter].cpu().numpy() * 2.0 ** (-2 * pexp)).astype(np.float32)
         nsplit[:] = nsplit_dev[:niter].cpu().numpy()
     assign = np.zeros(0, np.int64)
     if final_assign:
-        cpk, cstats = be.kmeans_pack_centroids(centroids, cmode)
+        cpk, cstats = be.kmeans_pack_centroids(centroids, cmode, exp=pexp)
         if dist is None:
             keys = be.nearest(cpk, packed, _capi.METRIC_L2, exact_scores=False, corpus_stats=cstats)  # ids only: no rescoring pass
             _, I = be.keys_to_result(keys, _capi.METRIC_L2)
@@ -181,8 +183,10 @@ def kmeans(x, k: int, niter: int = 20, seed: int = 1234, max_points_per_centroid
             for r in range(world):
                 ok = allp[r, 0] >= 0
                 assign[allp[r, 0][ok]] = allp[r, 1][ok]
-    return KMeansResult(centroids=np.asarray(centroids.cpu().numpy(), np.float32), assign=assign, obj=obj, nsplit=nsplit,
-                        train_ids=train_ids)
+    cent = np.asarray(centroids.cpu().numpy(), np.float32)
+    if pexp:
+        cent = (cent * np.float32(2.0 ** -pexp)).astype(np.float32)  # exact
+    return KMeansResult(centroids=cent, assign=assign, obj=obj, nsplit=nsplit, train_ids=train_ids)
 
 
 def cluster(col_name: str, ncentroids: int):

@@ -156,7 +156,7 @@ __device__ inline void pack_report(uint32_t bad, uint32_t* flags) {
 
 template <typename SrcT>
 __global__ __launch_bounds__(256) void pack_rows_kernel(const SrcT* __restrict__ src, long long n, int d, int dpad,
-                                                        int split, int normalize, _Float16* __restrict__ dst,
+                                                        int split, int normalize, float pw, _Float16* __restrict__ dst,
                                                         float* __restrict__ norms, uint32_t* __restrict__ flags) {
     const int lane = threadIdx.x & 63;
     const long long row = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -177,7 +177,7 @@ __global__ __launch_bounds__(256) void pack_rows_kernel(const SrcT* __restrict__
     float nn = 0.f;
     uint32_t bad = 0;
     for (int j = lane; j < dpad; j += 64) {
-        float x = j < d ? (float)s[j] * scale : 0.f;
+        float x = j < d ? ((float)s[j] * scale) * pw : 0.f;  // pw is a power of two: exact
         bad |= pack_check(x);
         _Float16 hi = (_Float16)x;
         float stored = (float)hi;
@@ -216,7 +216,7 @@ __device__ inline void pack_load8(const _Float16* s, float (&v)[8]) {
 // one wave per row, 8 consecutive elements per lane and step (16-byte stores, 16/32-byte loads): d % 8 == 0
 template <typename SrcT, int SPLIT>
 __global__ __launch_bounds__(256) void pack_rows_vec_kernel(const SrcT* __restrict__ src, long long n, int d, int dpad,
-                                                            int normalize, _Float16* __restrict__ dst,
+                                                            int normalize, float pw, _Float16* __restrict__ dst,
                                                             float* __restrict__ norms, uint32_t* __restrict__ flags) {
     const int lane = threadIdx.x & 63;
     const long long row = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -248,7 +248,7 @@ __global__ __launch_bounds__(256) void pack_rows_vec_kernel(const SrcT* __restri
         pk_half8 hi, lo;
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
-            float x = v[t] * scale;
+            float x = (v[t] * scale) * pw;  // pw is a power of two: exact
             bad |= pack_check(x);
             hi[t] = (_Float16)x;
             float stored = (float)hi[t];
@@ -266,6 +266,23 @@ __global__ __launch_bounds__(256) void pack_rows_vec_kernel(const SrcT* __restri
         if (lane == 0) norms[row] = nn;
     }
     pack_report(bad, flags);
+}
+
+// largest |x| over a matrix as the bit pattern of a non-negative float (atomicMax on the bits; inf / NaN propagate as the
+// largest patterns, so the caller sees them)
+template <typename SrcT>
+__global__ __launch_bounds__(256) void absmax_kernel(const SrcT* __restrict__ src, long long total, uint32_t* __restrict__ out) {
+    uint32_t m = 0;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const uint32_t b = __float_as_uint(fabsf((float)src[i])) & 0x7FFFFFFFu;
+        m = b > m ? b : m;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const uint32_t v = (uint32_t)__shfl_xor((int)m, o, 64);
+        m = v > m ? v : m;
+    }
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
 }
 
 __global__ __launch_bounds__(256) void gather_rows_kernel(const uint4* __restrict__ src, long long ld16,
@@ -365,7 +382,7 @@ __global__ __launch_bounds__(256) void merge_keys_wide_kernel(const u64* __restr
 }
 
 __global__ __launch_bounds__(256) void keys_to_result_kernel(const u64* __restrict__ keys, long long n, int metric,
-                                                             const long long* __restrict__ id_map,
+                                                             const long long* __restrict__ id_map, float unscale,
                                                              float* __restrict__ D, long long* __restrict__ I) {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -376,7 +393,7 @@ __global__ __launch_bounds__(256) void keys_to_result_kernel(const u64* __restri
         I[i] = -1;
         return;
     }
-    float better = lvs_unord32((uint32_t)(key >> 32));
+    float better = lvs_unord32((uint32_t)(key >> 32)) * unscale;  // a power of two (operands packed with a scale): exact
     long long id = (long long)(0xFFFFFFFFu - (uint32_t)(key & 0xFFFFFFFFull));
     D[i] = metric == LVS_METRIC_IP ? better : (0.0f - better);
     I[i] = id_map ? id_map[id] : id;
@@ -534,12 +551,14 @@ __global__ __launch_bounds__(256) void margin_select_kernel(const u64* __restric
 
 extern "C" int32_t lvs_pack_rows(const void* src, int32_t src_dtype, int64_t n, int32_t d, int32_t pack_mode,
                                  int32_t normalize, void* dst, float* out_norms_sq, void* stream) {
-    return lvs_pack_rows_checked(src, src_dtype, n, d, pack_mode, normalize, dst, out_norms_sq, nullptr, stream);
+    return lvs_pack_rows_checked(src, src_dtype, n, d, pack_mode, normalize, 0, dst, out_norms_sq, nullptr, stream);
 }
 
 extern "C" int32_t lvs_pack_rows_checked(const void* src, int32_t src_dtype, int64_t n, int32_t d, int32_t pack_mode,
-                                         int32_t normalize, void* dst, float* out_norms_sq, uint32_t* out_flags,
-                                         void* stream) {
+                                         int32_t normalize, int32_t scale_exp, void* dst, float* out_norms_sq,
+                                         uint32_t* out_flags, void* stream) {
+    LVS_REQUIRE(scale_exp >= -100 && scale_exp <= 100, "scale_exp %d out of range", scale_exp);
+    const float pw = ldexpf(1.0f, scale_exp);
     LVS_REQUIRE(n >= 0 && d > 0, "bad shape n=%lld d=%d", (long long)n, d);
     LVS_REQUIRE(pack_mode == LVS_PACK_F16 || pack_mode == LVS_PACK_SPLIT, "bad pack_mode %d", pack_mode);
     LVS_REQUIRE(src_dtype == LVS_DTYPE_F32 || src_dtype == LVS_DTYPE_F16, "bad src_dtype %d", src_dtype);
@@ -554,22 +573,39 @@ extern "C" int32_t lvs_pack_rows_checked(const void* src, int32_t src_dtype, int
     _Float16* o = (_Float16*)dst;
     if (vec && src_dtype == LVS_DTYPE_F32 && split)
         hipLaunchKernelGGL((pack_rows_vec_kernel<float, 1>), grid, block, 0, st, (const float*)src, (long long)n, d,
-                           dpad, normalize, o, out_norms_sq, out_flags);
+                           dpad, normalize, pw, o, out_norms_sq, out_flags);
     else if (vec && src_dtype == LVS_DTYPE_F32)
         hipLaunchKernelGGL((pack_rows_vec_kernel<float, 0>), grid, block, 0, st, (const float*)src, (long long)n, d,
-                           dpad, normalize, o, out_norms_sq, out_flags);
+                           dpad, normalize, pw, o, out_norms_sq, out_flags);
     else if (vec && split)
         hipLaunchKernelGGL((pack_rows_vec_kernel<_Float16, 1>), grid, block, 0, st, (const _Float16*)src, (long long)n,
-                           d, dpad, normalize, o, out_norms_sq, out_flags);
+                           d, dpad, normalize, pw, o, out_norms_sq, out_flags);
     else if (vec)
         hipLaunchKernelGGL((pack_rows_vec_kernel<_Float16, 0>), grid, block, 0, st, (const _Float16*)src, (long long)n,
-                           d, dpad, normalize, o, out_norms_sq, out_flags);
+                           d, dpad, normalize, pw, o, out_norms_sq, out_flags);
     else if (src_dtype == LVS_DTYPE_F32)
         hipLaunchKernelGGL(pack_rows_kernel<float>, grid, block, 0, st, (const float*)src, (long long)n, d, dpad,
-                           split, normalize, o, out_norms_sq, out_flags);
+                           split, normalize, pw, o, out_norms_sq, out_flags);
     else
         hipLaunchKernelGGL(pack_rows_kernel<_Float16>, grid, block, 0, st, (const _Float16*)src, (long long)n, d,
-                           dpad, split, normalize, o, out_norms_sq, out_flags);
+                           dpad, split, normalize, pw, o, out_norms_sq, out_flags);
+    LVS_HIP_CHECK(hipGetLastError());
+    return LVS_OK;
+}
+
+extern "C" int32_t lvs_absmax(const void* src, int32_t src_dtype, int64_t n, int32_t d, uint32_t* inout_bits, void* stream) {
+    LVS_REQUIRE(n >= 0 && d > 0 && inout_bits, "bad arguments");
+    LVS_REQUIRE(src_dtype == LVS_DTYPE_F32 || src_dtype == LVS_DTYPE_F16, "bad src_dtype %d", src_dtype);
+    if (n == 0) return LVS_OK;
+    LVS_REQUIRE(src, "NULL buffer");
+    LVS_DEVICE_GUARD(stream);
+    const long long total = (long long)n * d;
+    const unsigned grid = (unsigned)(lvs_ceil_div(total, 256 * 8) < 4096 ? lvs_ceil_div(total, 256 * 8) : 4096);
+    if (src_dtype == LVS_DTYPE_F32)
+        hipLaunchKernelGGL(absmax_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)src, total, inout_bits);
+    else
+        hipLaunchKernelGGL(absmax_kernel<_Float16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const _Float16*)src, total,
+                           inout_bits);
     LVS_HIP_CHECK(hipGetLastError());
     return LVS_OK;
 }
@@ -1176,6 +1212,7 @@ extern "C" int32_t lvs_flat_search_keys(const void* xb, int32_t xb_pack, int64_t
                 ta.k = 1;
                 ta.scores = sc;
                 ta.ld_scores = sample;
+                ta.out_scale = 1.0f;
                 LVS_HIP_CHECK(lvs_tile_launch(LVS_MODE_SCORES, ta, st));
                 hipLaunchKernelGGL(seed_select_kernel, dim3((unsigned)nq), dim3(256), 0, st, sc, (long long)sample,
                                    (int)sample, k, gtau);
@@ -1440,23 +1477,26 @@ extern "C" int32_t lvs_merge_keys(const uint64_t* parts, int32_t nparts, int64_t
 }
 
 extern "C" int32_t lvs_keys_to_result(const uint64_t* keys, int64_t nq, int32_t k, int32_t metric,
-                                      const int64_t* id_map, float* out_D, int64_t* out_I, void* stream) {
+                                      const int64_t* id_map, int32_t score_exp, float* out_D, int64_t* out_I, void* stream) {
     LVS_REQUIRE(nq >= 0 && k >= 0, "bad shape");
+    LVS_REQUIRE(score_exp >= -120 && score_exp <= 120, "score_exp %d out of range", score_exp);
     LVS_REQUIRE(metric == LVS_METRIC_IP || metric == LVS_METRIC_L2, "bad metric %d", metric);
     long long n = (long long)nq * k;
     if (n == 0) return LVS_OK;
     LVS_REQUIRE(keys && out_D && out_I, "NULL buffer");
     LVS_DEVICE_GUARD(stream);
     hipLaunchKernelGGL(keys_to_result_kernel, dim3((unsigned)lvs_ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream,
-                       (const u64*)keys, n, metric, (const long long*)id_map, out_D, (long long*)out_I);
+                       (const u64*)keys, n, metric, (const long long*)id_map, ldexpf(1.0f, -score_exp), out_D,
+                       (long long*)out_I);
     LVS_HIP_CHECK(hipGetLastError());
     return LVS_OK;
 }
 
 extern "C" int32_t lvs_scores(const void* xb, int32_t xb_pack, int64_t nb, const void* xq, int32_t xq_pack, int64_t nq,
-                              int32_t d, int32_t metric, const float* xb_norms_sq, const float* xq_norms_sq, float* out,
-                              int64_t ld_out, void* stream) {
+                              int32_t d, int32_t metric, const float* xb_norms_sq, const float* xq_norms_sq,
+                              int32_t score_exp, float* out, int64_t ld_out, void* stream) {
     Plan p;
+    LVS_REQUIRE(score_exp >= -120 && score_exp <= 120, "score_exp %d out of range", score_exp);
     LVS_REQUIRE(make_plan(nq, nb, d, xb_pack, xq_pack, 1, p, true) == LVS_OK, "bad shape");
     LVS_REQUIRE(metric == LVS_METRIC_IP || metric == LVS_METRIC_L2, "bad metric %d", metric);
     if (nq == 0 || nb == 0) return LVS_OK;
@@ -1471,6 +1511,7 @@ extern "C" int32_t lvs_scores(const void* xb, int32_t xb_pack, int64_t nb, const
     a.qn = xq_norms_sq;
     a.scores = out;
     a.ld_scores = ld_out;
+    a.out_scale = ldexpf(1.0f, -score_exp);
     a.nb = nb;
     a.nq = nq;
     a.ldb = p.ldb;
@@ -1497,10 +1538,11 @@ extern "C" int32_t lvs_scores(const void* xb, int32_t xb_pack, int64_t nb, const
 
 extern "C" int32_t lvs_range_join(const void* xb, int32_t xb_pack, int64_t nb, const void* xq, int32_t xq_pack, int64_t nq,
                                   int32_t d, int32_t metric, const float* xb_norms_sq, const float* xq_norms_sq,
-                                  float threshold, int64_t q_row0, int64_t id_offset, int32_t qt_stride,
-                                  int32_t qt_phase, int64_t capacity, int64_t* out_q, int64_t* out_j, float* out_s,
-                                  uint64_t* out_count, void* stream) {
+                                  float threshold, int32_t score_exp, int64_t q_row0, int64_t id_offset,
+                                  int32_t qt_stride, int32_t qt_phase, int64_t capacity, int64_t* out_q, int64_t* out_j,
+                                  float* out_s, uint64_t* out_count, void* stream) {
     Plan p;
+    LVS_REQUIRE(score_exp >= -120 && score_exp <= 120, "score_exp %d out of range", score_exp);
     LVS_REQUIRE(make_plan(nq, nb, d, xb_pack, xq_pack, 1, p, true) == LVS_OK, "bad shape");
     LVS_REQUIRE(metric == LVS_METRIC_IP || metric == LVS_METRIC_L2, "bad metric %d", metric);
     LVS_REQUIRE(capacity >= 0 && out_count, "bad output buffers");
@@ -1542,7 +1584,8 @@ extern "C" int32_t lvs_range_join(const void* xb, int32_t xb_pack, int64_t nb, c
     a.pair_count = (unsigned long long*)out_count;
     a.pair_capacity = capacity;
     a.q_row0 = q_row0;
-    a.threshold = threshold;
+    a.threshold = threshold * ldexpf(1.0f, score_exp);  // the device scores are 2^score_exp x the caller's (exact)
+    a.out_scale = ldexpf(1.0f, -score_exp);
     a.qt_stride = qt_stride;
     a.qt_phase = qt_phase;
     {

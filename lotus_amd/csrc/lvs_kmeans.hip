@@ -246,7 +246,7 @@ __global__ __launch_bounds__(256) void km_update_kernel(const float* __restrict_
 // dst[i][0..d) = float32 value of packed row ids[i] (row i when ids == NULL): hi (+ lo)
 __global__ __launch_bounds__(256) void unpack_rows_kernel(const _Float16* __restrict__ src, long long ld, int d, int dpad,
                                                           int split, const long long* __restrict__ ids, long long n,
-                                                          float* __restrict__ dst) {
+                                                          float unscale, float* __restrict__ dst) {
     const int lane = threadIdx.x & 63;
     const long long i = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (i >= n) return;
@@ -255,7 +255,7 @@ __global__ __launch_bounds__(256) void unpack_rows_kernel(const _Float16* __rest
     for (int j = lane; j < d; j += 64) {
         float v = (float)row[j];
         if (split) v += (float)row[dpad + j];
-        o[j] = v;
+        o[j] = v * unscale;
     }
 }
 
@@ -475,8 +475,9 @@ extern "C" int32_t lvs_kmeans_update_centroids(const float* sums, float* counts,
 }
 
 extern "C" int32_t lvs_unpack_rows(const void* src, int32_t d, int32_t pack_mode, const int64_t* ids, int64_t n,
-                                   float* dst, void* stream) {
+                                   int32_t scale_exp, float* dst, void* stream) {
     LVS_REQUIRE(d > 0 && n >= 0, "bad shape n=%lld d=%d", (long long)n, d);
+    LVS_REQUIRE(scale_exp >= -100 && scale_exp <= 100, "scale_exp %d out of range", scale_exp);
     LVS_REQUIRE(pack_mode == LVS_PACK_F16 || pack_mode == LVS_PACK_SPLIT, "bad pack_mode %d", pack_mode);
     if (n == 0) return LVS_OK;
     LVS_REQUIRE(src && dst, "NULL buffer");
@@ -485,7 +486,7 @@ extern "C" int32_t lvs_unpack_rows(const void* src, int32_t d, int32_t pack_mode
     const int split = pack_mode == LVS_PACK_SPLIT;
     hipLaunchKernelGGL(unpack_rows_kernel, dim3((unsigned)lvs_ceil_div(n, 4)), dim3(256), 0, (hipStream_t)stream,
                        (const _Float16*)src, (long long)(split ? 2 * dpad : dpad), d, dpad, split,
-                       (const long long*)ids, (long long)n, dst);
+                       (const long long*)ids, (long long)n, ldexpf(1.0f, -scale_exp), dst);
     LVS_HIP_CHECK(hipGetLastError());
     return LVS_OK;
 }

@@ -38,6 +38,7 @@ struct LvsTileArgs {
     long long pair_capacity;
     long long q_row0;         // >= 0: self-join, query r is corpus row q_row0 + r and only pairs j > i are kept
     float threshold;
+    float out_scale;          // SCORES / RANGE: factor applied to a score on its way out (2^-e of operands packed with a scale)
     int qt_stride, qt_phase;  // only query tiles with qt % qt_stride == qt_phase are processed (multi-GPU deal)
     long long ld_scores;
     long long nb, nq;

@@ -440,7 +440,7 @@ __global__ __launch_bounds__(512, 2) void lvs_tile_kernel(const LvsTileArgs a) {
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
                             const long long row = trow0 + lrow_base + mi * 32 + (r & 3) + 8 * (r >> 2);
-                            if (row < a.nb) orow[row] = acc[mi][ni][r];
+                            if (row < a.nb) orow[row] = acc[mi][ni][r] * a.out_scale;
                         }
                     } else {
                         const bool th = qvalid[ni] && (max16(acc[mi][ni]) > a.threshold);
@@ -458,7 +458,7 @@ __global__ __launch_bounds__(512, 2) void lvs_tile_kernel(const LvsTileArgs a) {
                             if ((long long)pos < a.pair_capacity) {
                                 a.pair_q[pos] = qg;
                                 a.pair_j[pos] = jg;
-                                a.pair_s[pos] = s;
+                                a.pair_s[pos] = s * a.out_scale;
                             }
                         }
                     }

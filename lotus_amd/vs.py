@@ -205,7 +205,20 @@ class HipVS(VS):
         lo, hi = min(n, rank * per), min(n, (rank + 1) * per)
         is_dev = self._is_device_tensor(vecs)
         dtype = np.float16 if (is_dev and str(vecs.dtype) == "torch.float16") else (np.float32 if is_dev else vecs.dtype)
-        packed = self.backend.pack(vecs[lo:hi], self._pack_mode(dtype))
+        mode = self._pack_mode(dtype)
+        exp = "auto"  # fp32-accurate rows are stored as x * 2^e with e chosen from the data (backend.pack); fp16 rows as given
+        if world > 1 and mode == _capi.PACK_SPLIT:
+            # one exponent for every shard (per-shard lists are merged by score): agreed from each rank's first rows.  Every
+            # rank of the corpus group enters the exchange, also one whose shard is empty.
+            from . import _dist
+            import torch
+
+            head = vecs[lo:min(hi, lo + 65536)]
+            head = head.float().cpu().numpy() if is_dev else np.asarray(head, dtype=np.float32)
+            amax = float(max(head.max(initial=0.0), -head.min(initial=0.0)))
+            t = torch.tensor([amax if np.isfinite(amax) else 0.0], dtype=torch.float64)
+            exp = self.backend.exp_for(float(_dist.all_gather_rows(t, self._pg_corpus()).max().item()))
+        packed = self.backend.pack(vecs[lo:hi], mode, exp=exp, check=True)
         ent = _Resident(vecs=stored, packed=packed, n=n, d=d, lo=lo, hi=hi, sig=sig)
         self._resident[index_dir] = ent
         self._resident.move_to_end(index_dir)
@@ -314,13 +327,18 @@ class HipVS(VS):
             q = q[min(nq, qrank * per):min(nq, (qrank + 1) * per)]
             nq = int(q.shape[0])
 
-        queries = be.pack(q, ent.packed.mode)
+        # queries share the index's power-of-two scale (required for L2; for inner products it keeps one exponent per
+        # index); they are validated while they are packed, the flag word comes back together with the results
+        qexp = kwargs.get("_query_exp", ent.packed.exp)
+        queries = be.pack(q, ent.packed.mode, exp=qexp, check="lazy")
+        score_exp = be.score_exp_of(ent.packed, queries)
         id_map = None
         if rank_all:
             # score rows of this rank's shard, exchanged so that every rank ranks the complete rows (column-sharded
             # score matrix, one all-gather); the device sort goes through the queries in chunks of < 2^32 scores
             sc, order = self._score_rows(ent, queries, sub, world)
             keys = be.rank_scores(sc)[:, :k_eff].contiguous()
+            score_exp = 0  # score rows come back in the caller's units already
             if order is not None:
                 id_map = be.to_device(order)
             world = 1  # already complete on every rank: nothing left to merge
@@ -345,11 +363,20 @@ class HipVS(VS):
             pad[:nq] = keys
             keys = _dist.all_gather_rows(pad, pg_query).reshape(qworld * per, k_eff)[:q_all].contiguous()
             nq = q_all
-        Dd, Id = be.keys_to_result(keys, self.metric, id_map)
+        Dd, Id = be.keys_to_result(keys, self.metric, id_map, score_exp=score_exp)
+        flags = getattr(queries, "flags", None)
         if return_device and k_eff == K:  # results stay in HBM (torch tensors) for a GPU-side consumer
+            if flags is not None:
+                self._check_queries(int(flags.item()), query_vectors, K, ids, kwargs)
             return RMOutput(distances=Dd, indices=Id)
-        if hasattr(be, "to_host"):  # both copies in flight together, one synchronisation, pinned-backed result arrays
-            Dh, Ih = be.to_host(Dd, Id)
+        if hasattr(be, "to_host"):  # all copies in flight together, one synchronisation, pinned-backed result arrays
+            if flags is not None:
+                Dh, Ih, fh = be.to_host(Dd, Id, flags)
+                redo = self._check_queries(int(fh[0]), query_vectors, K, ids, kwargs)
+                if redo is not None:
+                    return redo
+            else:
+                Dh, Ih = be.to_host(Dd, Id)
         else:
             Dh, Ih = Dd.cpu().numpy(), Id.cpu().numpy()
         if k_eff == K:
@@ -359,6 +386,20 @@ class HipVS(VS):
         D[:, :k_eff] = Dh
         I[:, :k_eff] = Ih
         return RMOutput(distances=D, indices=I)
+
+    def _check_queries(self, f: int, query_vectors, K, ids, kwargs):
+        """Validation flags of the packed queries (``lvs_pack_rows_checked``).  inf / NaN raise.  Magnitudes that leave
+        fp16's range under the INDEX's scale are searched again with an exponent of their own when the metric allows it
+        (inner products; squared L2 needs one scale on both sides) - returns that result, else None."""
+        if not f:
+            return None
+        if f & _capi.PACK_FLAG_RANGE and not f & _capi.PACK_FLAG_NONFINITE and self.metric == METRIC_INNER_PRODUCT \
+                and "_query_exp" not in kwargs:
+            kw = dict(kwargs)
+            kw["_query_exp"] = "auto"
+            return self.__call__(query_vectors, K, ids, **kw)
+        self.backend.raise_for_flags(f, "query vectors")
+        return None
 
     def scores(self, query_vectors, ids: list[int] | None = None):
         """Similarity of every query to every indexed row (or to rows ``ids``, in that order) as one float32 matrix
@@ -379,7 +420,7 @@ class HipVS(VS):
             if sub.size == ent.n and np.array_equal(sub, np.arange(ent.n)):
                 sub = None
         _, world = self._dist()
-        queries = be.pack(q, ent.packed.mode)
+        queries = be.pack(q, ent.packed.mode, exp=ent.packed.exp, check=True)
         sc, order = self._score_rows(ent, queries, sub, world, want_ids=False)
         out = sc.cpu().numpy()
         if order is not None:  # columns arrived shard by shard: put them back into the order of `ids`

@@ -36,7 +36,7 @@ class OracleBackend:
     def to_device(self, arr):
         return torch.from_numpy(np.ascontiguousarray(arr))
 
-    def pack(self, x, mode, normalize=False, check=False):
+    def pack(self, x, mode, normalize=False, check=False, exp=0):
         x = x.numpy() if torch.is_tensor(x) else np.asarray(x)
         x = x.astype(np.float32)
         if check:
@@ -88,7 +88,11 @@ class OracleBackend:
         self.calls.append(("merge", P, nq, k))
         return torch.from_numpy(np.array(out, dtype=np.uint64, order="C", copy=True).view(np.int64))
 
-    def keys_to_result(self, keys, metric, id_map=None):
+    @staticmethod
+    def score_exp_of(corpus, queries):
+        return 0
+
+    def keys_to_result(self, keys, metric, id_map=None, score_exp=0):
         k = keys.numpy().view(np.uint64)
         D, I = _finish(k, metric, None if id_map is None else id_map.numpy())
         return torch.from_numpy(D), torch.from_numpy(I)
@@ -110,7 +114,7 @@ class OracleBackend:
         keys = np.sort(oracle.pack_keys(s, ids), axis=1)[:, ::-1]
         return torch.from_numpy(np.array(keys, dtype=np.uint64, order="C", copy=True).view(np.int64))
 
-    def unpack(self, src, ids_dev=None):
+    def unpack(self, src, ids_dev=None, raw=False):
         rows = src.rows if ids_dev is None else src.rows[ids_dev.numpy().astype(np.int64)]
         return rows.clone().to(torch.float32)
 
@@ -159,11 +163,11 @@ class OracleBackend:
         o = x2.numpy()[0] - 2.0 * (c * sums.numpy().astype(np.float64)).sum() + (counts.numpy().astype(np.float64) * (c * c).sum(1)).sum()
         out[0] = float(o)
 
-    def kmeans_pack_centroids(self, centroids, mode):
+    def kmeans_pack_centroids(self, centroids, mode, exp=0):
         pk = self.pack(centroids, mode)
         return pk, torch.zeros(2)
 
-    def kmeans_finish(self, sums, counts, centroids, n_train, mode, nsplit_out=None):
+    def kmeans_finish(self, sums, counts, centroids, n_train, mode, nsplit_out=None, exp=0):
         self.kmeans_update_centroids(sums, counts, centroids)
         hs = counts.numpy()
         ns = 0

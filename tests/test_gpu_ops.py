@@ -219,3 +219,85 @@ def test_partial_load_from_the_row_store(hip_backend, tmp_path, monkeypatch):
     D, I = hip_backend.keys_to_result(keys, 0)
     err, hard, recall = synth.compare_topk(Dr, Ir, D.cpu().numpy(), I.cpu().numpy())
     assert err <= 1e-5 and hard == 0 and recall == 1.0
+
+
+@pytest.mark.parametrize("scale", [1e-2, 1.0, 1e2])
+@pytest.mark.parametrize("metric", [0, 1])
+def test_fp32_embeddings_of_any_magnitude_keep_fp32_accuracy(hip_backend, tmp_path, scale, metric):
+    """faiss takes any float32 (faiss_vs.py:24).  HipVS stores fp32 embeddings as fp16 hi|lo pairs of x * 2^e with e chosen
+    from the data, so rows of norm 1e-2 are scored as accurately as rows of norm 1e+2: error <= 1e-6 |q| |y| against a
+    float64 reference (unscaled, the lo half of small values would live in fp16's subnormals)."""
+    xb = (synth.corpus(30_000, 256, seed=41) * scale).astype(np.float32)
+    xq = (synth.queries(xb / scale, 400, seed=42)[0] * scale).astype(np.float32)
+    vs = HipVS(backend=hip_backend, metric=metric)
+    vs.index(None, xb, str(tmp_path / "i"), persist=False)
+    assert vs._resident[vs.index_dir].packed.exp == 6 - int(np.floor(np.log2(np.abs(xb[:262144]).max())))
+    out = vs(xq, 10)
+    S = xq.astype(np.float64) @ xb.astype(np.float64).T
+    if metric == 1:
+        S = -((xq.astype(np.float64) ** 2).sum(1)[:, None] + (xb.astype(np.float64) ** 2).sum(1)[None, :] - 2 * S)
+    order = np.argsort(-S, axis=1, kind="stable")[:, :10]
+    ref = np.take_along_axis(S, order, 1) * (1 if metric == 0 else -1)
+    bar = 1e-6 * scale * scale * (1 if metric == 0 else 4)  # |q| |y| = scale^2; a squared distance is a sum of three such terms
+    assert np.abs(out.distances - ref).max() <= bar, (np.abs(out.distances - ref).max(), bar)
+    assert (out.indices == order).mean() >= 0.995
+    got = vs.get_vectors_from_index(vs.index_dir, [5, 17])  # served from the device image: scale undone
+    assert np.abs(got - xb[[5, 17]]).max() <= 2.0 ** -21 * np.abs(xb).max()
+    sc = vs.scores(xq[:3])
+    assert np.abs(sc - S[:3]).max() <= bar
+
+
+def test_non_finite_and_out_of_range_inputs_are_refused_or_rescaled(hip_backend, tmp_path):
+    xb = synth.corpus(5_000, 64, seed=43)
+    bad = xb.copy()
+    bad[77, 3] = np.inf
+    vs = HipVS(backend=hip_backend)
+    with pytest.raises(ValueError, match="inf or NaN"):
+        vs.index(None, bad, str(tmp_path / "bad"), persist=False)
+    vs.index(None, xb, str(tmp_path / "ok"), persist=False)
+    q = synth.queries(xb, 8, seed=44)[0]
+    qn = q.copy()
+    qn[2, 5] = np.nan
+    with pytest.raises(ValueError, match="inf or NaN"):
+        vs(qn, 3)
+    # queries a million times larger than the index's rows leave fp16's range under the index's scale: inner products are
+    # searched again with an exponent of their own, same neighbours, scores scaled accordingly
+    big = vs(q * 1e6, 3)
+    ref = vs(q, 3)
+    assert np.array_equal(big.indices, ref.indices)
+    assert np.allclose(big.distances, ref.distances * 1e6, rtol=1e-5)
+    vl2 = HipVS(backend=hip_backend, metric=1)
+    vl2.index(None, xb, str(tmp_path / "l2"), persist=False)
+    with pytest.raises(ValueError, match="range"):
+        vl2(q * 1e6, 3)
+    # storage="fp16" keeps values as given: fp32 inputs beyond fp16's range are refused, not turned into inf
+    v16 = HipVS(backend=hip_backend, storage="fp16")
+    with pytest.raises(ValueError, match="range"):
+        v16.index(None, xb * 1e6, str(tmp_path / "f16"), persist=False)
+
+
+def test_kmeans_and_dedup_on_scaled_rows(hip_backend, tmp_path):
+    """The pack scale is invisible to the operators: k-means centroids / objective and the threshold join come back in the
+    caller's units."""
+    from lotus_amd.cluster import kmeans
+
+    rng = np.random.default_rng(45)
+    c = rng.standard_normal((12, 64)).astype(np.float32)
+    x = ((c[rng.integers(0, 12, 20_000)] + 0.3 * rng.standard_normal((20_000, 64))) * 1e-3).astype(np.float32)
+    vs = HipVS(backend=hip_backend)
+    vs.index(None, x, str(tmp_path / "km"), persist=False)
+    assert vs._resident[vs.index_dir].packed.exp > 6
+    r = vs.kmeans(None, 12, niter=5, return_result=True)
+    hi = x.astype(np.float16)  # the oracle sees the values the device holds: hi|lo of the scaled rows, scaled back
+    e = vs._resident[vs.index_dir].packed.exp
+    xs = (x * np.float32(2.0 ** e)).astype(np.float32)
+    stored = (xs.astype(np.float16).astype(np.float32) + (xs - xs.astype(np.float16).astype(np.float32)).astype(np.float16).astype(np.float32)) * np.float32(2.0 ** -e)
+    ref = oracle.kmeans_faiss(stored, 12, niter=5)
+    assert (r.assign == ref.assign).mean() >= 1 - 1e-4
+    assert np.allclose(r.obj, ref.obj, rtol=1e-5) and np.allclose(r.centroids, ref.centroids, rtol=1e-4, atol=1e-9)
+    xd = (synth.corpus(3_000, 64, seed=46) * 50.0).astype(np.float32)
+    xd[1500:1600] = xd[:100] * (1 + 1e-3)
+    vd = HipVS(backend=hip_backend)
+    vd.index(None, xd, str(tmp_path / "dd"), persist=False)
+    i, j, s = threshold_pairs(hip_backend, vd.packed_rows(), 0.95 * 2500.0)
+    assert len(i) == 100 and np.array_equal(j - i, np.full(100, 1500)) and np.allclose(s, 2500.0 * (1 + 1e-3), rtol=1e-4)
