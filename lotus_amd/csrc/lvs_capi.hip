@@ -344,15 +344,15 @@ __global__ __launch_bounds__(256) void merge_keys_kernel(const u64* __restrict__
     if (lane < k) out[q * out_ld + lane] = best;
 }
 
-// the same merge with ONE WORKGROUP per query: its four waves each merge a quarter of the parts, wave 0 merges the four
-// results.  For the small-batch kernel's 64 .. 256 partial lists of a few dozen queries, where one wave per query left the
-// merge longer than the scan it follows.
-__global__ __launch_bounds__(256) void merge_keys_wide_kernel(const u64* __restrict__ parts, int nparts, long long nq, int k,
-                                                              u64* __restrict__ out, long long out_ld) {
-    __shared__ u64 sm[4][64];
+// the same merge with ONE WORKGROUP of 16 waves per query: every wave merges a sixteenth of the parts (its loads in flight
+// next to the other waves'), wave 0 merges the sixteen results.  For the small-batch kernel's 64 .. 256 partial lists of a
+// few dozen queries, where one wave per query left the merge (a chain of dependent loads) as long as a tenth of the scan.
+__global__ __launch_bounds__(1024) void merge_keys_wide_kernel(const u64* __restrict__ parts, int nparts, long long nq, int k,
+                                                               u64* __restrict__ out, long long out_ld) {
+    __shared__ u64 sm[16][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long long q = blockIdx.x;
-    const int per = (nparts + 3) / 4;
+    const int per = (nparts + 15) / 16;
     const int p0 = wave * per, p1 = p0 + per < nparts ? p0 + per : nparts;
     const long long total = p1 > p0 ? (long long)(p1 - p0) * k : 0;
     u64 best = 0;
@@ -372,9 +372,10 @@ __global__ __launch_bounds__(256) void merge_keys_wide_kernel(const u64* __restr
     sm[wave][lane] = best;
     __syncthreads();
     if (wave != 0) return;
-#pragma unroll
-    for (int o = 1; o < 4; ++o) {
+#pragma unroll 1
+    for (int o = 1; o < 16; ++o) {
         const u64 w = sm[o][63 - lane];
+        if (__builtin_amdgcn_ballot_w64(w != 0) == 0ull) continue;
         best = best > w ? best : w;
         best = lvs_wave_bitonic_merge_desc(best, lane);
     }
@@ -788,10 +789,10 @@ int make_plan(int64_t nq, int64_t nb, int32_t d, int32_t xb_pack, int32_t xq_pac
     off += lvs_round_up((int64_t)p.nslab * nq * p.kpass * 8, 256);
     p.off_pass = off;  // [nq][kpass] merged keys of one pass (multi-pass only)
     off += p.npass > 1 ? lvs_round_up(nq * p.kpass * 8, 256) : 0;
-    // the small-batch kernel: one k-list per (corpus range, query) written from off_partial onwards, then the score rows of
-    // the sample that seeds its thresholds
+    // the small-batch kernel: one k-list per (corpus range, query) written from off_partial onwards, then the per-range best
+    // scores of the sample that seeds its thresholds
     if (nq <= LVS_STREAM_MAXQ && k <= LVS_KPASS)
-        off += lvs_stream_parts_bytes(nq, k) + lvs_round_up((int64_t)(nq > 0 ? nq : 1) * LVS_STREAM_SEED_MAX * 4, 256);
+        off += lvs_stream_parts_bytes(nq, k) + lvs_round_up((int64_t)(nq > 0 ? nq : 1) * (LVS_STREAM_MAXWG + 8) * 4, 256);
     p.total = off;
     return LVS_OK;
 }
@@ -958,46 +959,35 @@ bool make_two_phase_plan(int64_t nq, int64_t nb, int32_t d, int32_t xb_pack, int
     return true;
 }
 
-// Seed of the small-batch kernel's shared thresholds: gtau[q] = order key of the k-th largest of scores[q][0 .. S) (0 when
-// S < k).  One workgroup per query: radix select over the order keys, four 8-bit digits, histogram in LDS.  Any real row's
-// score is a valid lower bound of the query's final k-th best score, so the seeded search stays exact.
-__global__ __launch_bounds__(256) void seed_select_kernel(const float* __restrict__ scores, long long ld, int S, int k,
-                                                          uint32_t* __restrict__ gtau) {
-    __shared__ uint32_t hist[256];
-    __shared__ uint32_t s_prefix, s_k;
-    const int tid = threadIdx.x;
-    const float* row = scores + (long long)blockIdx.x * ld;
-    uint32_t prefix = 0, mask = 0, kk = (uint32_t)k;  // the kk-th largest among the keys with (key & mask) == prefix
-    for (int shift = 24; shift >= 0; shift -= 8) {
-        hist[tid] = 0;
-        __syncthreads();
-        for (int i = tid; i < S; i += 256) {
-            const uint32_t key = lvs_ord32(row[i]);
-            if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
+// Seed of the small-batch kernel's shared thresholds: gtau[q] = order key of the k-th largest of the nparts values
+// seeds[p][q] (the best score of query q over the sample rows of corpus range p; lvs_stream_kernel<.., SEED>), 0 when fewer
+// than k ranges saw a row.  One wave per query: 64 values at a time are sorted across the lanes and folded into the running
+// top 64 (k <= 56).  Every value is a real row's score, and the k-th largest of a subset never exceeds the k-th largest of
+// all rows: a valid lower bound of the final k-th best score, so the seeded search stays exact.
+__global__ __launch_bounds__(256) void seed_kth_kernel(const float* __restrict__ seeds, int nparts, long long nq, int k,
+                                                       uint32_t* __restrict__ gtau) {
+    const int lane = threadIdx.x & 63;
+    const long long q = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (q >= nq) return;
+    u64 best = 0;
+    for (int p0 = 0; p0 < nparts; p0 += 64) {
+        const int p = p0 + lane;
+        u64 v = 0;
+        if (p < nparts) {
+            const float sc = seeds[(long long)p * nq + q];
+            if (sc > -INFINITY) v = (u64)lvs_ord32(sc) << 32;  // -inf: that range saw no row
         }
-        __syncthreads();
-        if (tid == 0) {
-            uint32_t seen = 0;
-            int b = 255;
-            for (; b >= 0; --b) {
-                if (seen + hist[b] >= kk) break;
-                seen += hist[b];
-            }
-            if (b < 0) {  // fewer than k candidates: no threshold
-                s_prefix = 0;
-                s_k = 0;
-            } else {
-                s_prefix = prefix | ((uint32_t)b << shift);
-                s_k = kk - seen;
-            }
+        v = lvs_wave_sort_desc(v, lane);
+        if (p0 == 0) {
+            best = v;
+        } else {
+            const u64 w = lvs_shfl_u64(v, 63 - lane);
+            best = best > w ? best : w;
+            best = lvs_wave_bitonic_merge_desc(best, lane);
         }
-        __syncthreads();
-        prefix = s_prefix;
-        kk = s_k;
-        mask |= 0xFFu << shift;
-        if (kk == 0) break;
     }
-    if (tid == 0) gtau[blockIdx.x] = kk == 0 ? 0u : prefix;
+    const uint32_t kth = (uint32_t)(lvs_shfl_u64(best, k - 1) >> 32);
+    if (lane == 0) gtau[q] = kth;
 }
 
 __global__ void copy_pass_kernel(const u64* __restrict__ src, long long nq, int kp, u64* __restrict__ dst, int k,
@@ -1193,28 +1183,23 @@ extern "C" int32_t lvs_flat_search_keys(const void* xb, int32_t xb_pack, int64_t
             // Every workgroup scans its own contiguous range, all at the same time: without help each of them starts with
             // empty lists and pays its own cold start (~k (1 + ln(range / k)) insertions per query and workgroup - with
             // dozens of queries that, not HBM, set the time in round 2).  So with several queries the thresholds are
-            // SEEDED: the scores of the first `sample` rows go into a small matrix (the tile kernel's SCORES epilogue, a
-            // ~20 us GEMM), a radix select takes every query's k-th largest, and the scan starts from there: a workgroup
-            // then only inserts rows that beat it (~k * nb / sample per query over the WHOLE launch).  Exact: a threshold
-            // taken from real rows never excludes a top-k row; the sample rows themselves are scanned again with the rest.
-            int64_t sample = lvs_round_up(nb / 64 > 8192 ? nb / 64 : 8192, 256);
-            if (sample > LVS_STREAM_SEED_MAX) sample = LVS_STREAM_SEED_MAX;
-            if (nq >= lvs_tune("LVS_STREAM_SEED_MINQ", 2) && nb >= 8 * sample && k <= sample && lvs_tune("LVS_STREAM_SEED", 1) != 0) {
-                float* sc = (float*)((char*)partial + lvs_stream_parts_bytes(nq, k));  // [nq][sample]
-                Plan ps;
-                LVS_REQUIRE(make_plan(nq, sample, d, xb_pack, xq_pack, 1, ps, true) == LVS_OK, "bad sample plan");
-                LvsTileArgs ta;
-                fill_args(ta, ps, nullptr, nullptr);
-                ta.nb = sample;
-                ta.row_ids = nullptr;
-                ta.id_offset = 0;
-                ta.k = 1;
-                ta.scores = sc;
-                ta.ld_scores = sample;
-                ta.out_scale = 1.0f;
-                LVS_HIP_CHECK(lvs_tile_launch(LVS_MODE_SCORES, ta, st));
-                hipLaunchKernelGGL(seed_select_kernel, dim3((unsigned)nq), dim3(256), 0, st, sc, (long long)sample,
-                                   (int)sample, k, gtau);  // writes every gtau[q]
+            // SEEDED: the same kernel first scans a sample (the first nb / 8 rows, at most 32 768) in SEED mode - no lists,
+            // every workgroup just keeps the best score per query over its 4 row blocks - and one wave per query takes the
+            // k-th largest of those per-range maxima as the starting threshold (~15 + 5 us; round 3's first version scored the
+            // sample into a matrix with the tile kernel and radix-selected it: 130-180 us).  A workgroup of the main scan then
+            // only inserts rows that beat it (~k * nb / sample per query over the WHOLE launch).  Exact: every value is a
+            // real row's score and the k-th largest of a subset never exceeds the k-th largest of all rows; the sample
+            // rows themselves are scanned again with the rest.
+            int64_t sample = nb / 8 / 1024 * 1024;
+            if (sample > LVS_STREAM_SEED_ROWS) sample = LVS_STREAM_SEED_ROWS;
+            if (nq >= lvs_tune("LVS_STREAM_SEED_MINQ", 2) && sample >= 4096 && lvs_tune("LVS_STREAM_SEED", 1) != 0) {
+                float* seeds = (float*)((char*)partial + lvs_stream_parts_bytes(nq, k));  // [ranges][nq]
+                LvsStreamArgs ss = sa;
+                ss.nb = sample;
+                ss.seed_out = seeds;
+                LVS_HIP_CHECK(lvs_stream_launch(ss, st));
+                hipLaunchKernelGGL(seed_kth_kernel, dim3((unsigned)lvs_ceil_div(nq, 4)), dim3(256), 0, st, (const float*)seeds,
+                                   ss.nparts, (long long)nq, k, gtau);  // writes every gtau[q]
                 LVS_HIP_CHECK(hipGetLastError());
             } else {
                 LVS_HIP_CHECK(hipMemsetAsync(gtau, 0, (size_t)nq * 4, st));
@@ -1224,7 +1209,7 @@ extern "C" int32_t lvs_flat_search_keys(const void* xb, int32_t xb_pack, int64_t
                 LVS_HIP_CHECK(lvs_stream_launch(sa, st));
             }
             if (sa.nparts >= 16 && k <= 64)
-                hipLaunchKernelGGL(merge_keys_wide_kernel, dim3((unsigned)nq), dim3(256), 0, st, partial, sa.nparts,
+                hipLaunchKernelGGL(merge_keys_wide_kernel, dim3((unsigned)nq), dim3(1024), 0, st, partial, sa.nparts,
                                    (long long)nq, k, (u64*)out_keys, (long long)k);
             else
                 hipLaunchKernelGGL(merge_keys_kernel, dim3((unsigned)lvs_ceil_div(nq, 4)), dim3(256), 0, st, partial,

@@ -53,7 +53,11 @@ __device__ inline float max16(const f32x16& v) {
 
 }  // namespace
 
-template <int UNROLL, int NQB, int WAVES>
+// SEED = true: the same scan over a SAMPLE of the rows with a trivial epilogue - every lane keeps the best score it saw, the
+// workgroup writes one value per query (a.seed_out[range][q]) and no lists exist.  lvs_flat_search_keys takes the k-th
+// largest of a query's values as its starting threshold (a valid lower bound of the k-th best score: each value is the
+// score of a real row, and the k-th largest of a subset never exceeds the k-th largest of the whole).
+template <int UNROLL, int NQB, int WAVES, bool SEED>
 __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void lvs_stream_kernel(const LvsStreamArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -85,9 +89,14 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void lvs_stream_ker
         if (qrow > a.nq - 1) qrow = a.nq - 1;
         bfrag[idx] = *(const half8*)(xq + (long long)qrow * a.ldq + part * a.jper * 16 + jj * 16 + (l >> 5) * 8);
     }
-    for (int i = tid; i < NQ * KCAP; i += WAVES * 64) lists[i] = 0;
-    for (int i = tid; i < NQ; i += WAVES * 64) locks[i] = 0;
+    if (!SEED) {
+        for (int i = tid; i < NQ * KCAP; i += WAVES * 64) lists[i] = 0;
+        for (int i = tid; i < NQ; i += WAVES * 64) locks[i] = 0;
+    }
     __syncthreads();
+    float seedbest[NQB];
+#pragma unroll
+    for (int qb = 0; qb < NQB; ++qb) seedbest[qb] = -INFINITY;
 
     // per query block: this lane's query, its validity, running threshold, shared threshold, |q|^2
     int qi[NQB];   // list index inside this workgroup; the query is qbase + qi
@@ -100,7 +109,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void lvs_stream_ker
         qvalid[qb] = qbase + qi[qb] < a.nq;
         tauf[qb] = -INFINITY;
         // start from the shared threshold: zero on a fresh call, the k-th best score of the sample on a seeded one
-        gord[qb] = qvalid[qb] ? a.gtau[qbase + qi[qb]] : 0u;
+        gord[qb] = (!SEED && qvalid[qb]) ? a.gtau[qbase + qi[qb]] : 0u;
         tauf[qb] = tau_float(gord[qb]);
         qnv[qb] = (a.metric == LVS_METRIC_L2 && qvalid[qb]) ? a.qn[qbase + qi[qb]] : 0.f;
     }
@@ -243,6 +252,10 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void lvs_stream_ker
                     acc[qb][r] = -fmaxf((qnv[qb] + bnv) - 2.0f * acc[qb][r], 0.f);
                 }
             }
+            if constexpr (SEED) {
+                seedbest[qb] = fmaxf(seedbest[qb], max16(acc[qb]));  // the sample holds whole 32-row blocks only: every row is real
+                continue;
+            }
             {
                 const uint32_t lo = (uint32_t)(lists[q * KCAP + k - 1] >> 32);
                 tauf[qb] = fmaxf(tauf[qb], tau_float(lo));
@@ -298,9 +311,9 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void lvs_stream_ker
         }
         // exchange thresholds with the other workgroups every 32 blocks of this wave (the global load drains the
         // in-flight fragment loads - vmcnt is in-order - so this must stay rare)
-        const bool exch = (((blk - b0) / WAVES) & 31) == 31;
+        const bool exch = !SEED && (((blk - b0) / WAVES) & 31) == 31;
 #pragma unroll
-        for (int qb = 0; qb < NQB; ++qb) {
+        for (int qb = 0; qb < NQB && !SEED; ++qb) {
             if (exch && qvalid[qb] && lane < 32) {
                 const uint32_t lo = (uint32_t)(lists[qi[qb] * KCAP + k - 1] >> 32);
                 if (lo > gord[qb]) atomicMax(&a.gtau[qbase + qi[qb]], lo);
@@ -311,6 +324,19 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void lvs_stream_ker
             gord[qb] = gl > gord[qb] ? gl : gord[qb];
             tauf[qb] = fmaxf(tauf[qb], tau_float(gord[qb]));
         }
+    }
+    if constexpr (SEED) {
+        float* red = (float*)lists;  // [WAVES * 2][NQ] (the list area is unused in this mode)
+        __syncthreads();
+#pragma unroll
+        for (int qb = 0; qb < NQB; ++qb) red[(wave * 2 + (lane >> 5)) * NQ + qi[qb]] = seedbest[qb];
+        __syncthreads();
+        for (int qq = tid; qq < NQ; qq += WAVES * 64) {
+            float m = -INFINITY;
+            for (int w = 0; w < WAVES * 2; ++w) m = fmaxf(m, red[w * NQ + qq]);
+            if (qbase + qq < a.nq) a.seed_out[(long long)range * a.nq + qbase + qq] = m;
+        }
+        return;
     }
     __syncthreads();
     for (int i = tid; i < NQ * k; i += WAVES * 64) {
@@ -370,32 +396,39 @@ int lvs_stream_plan(int64_t nq, int k, int nbfrag, int* out_kcap, int* out_nqb, 
     return 0;
 }
 
-template <int U, int NQB, int WAVES>
+template <int U, int NQB, int WAVES, bool SEED>
 static hipError_t stream_launch_one(const LvsStreamArgs& a, int grid, size_t lds, hipStream_t stream) {
     static LvsPerDeviceOnce attr;  // the attribute is a per-device property (one per instantiation)
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
     if (!attr.done(dev, lds)) {
-        e = hipFuncSetAttribute((const void*)lvs_stream_kernel<U, NQB, WAVES>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)lds);
+        e = hipFuncSetAttribute((const void*)lvs_stream_kernel<U, NQB, WAVES, SEED>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         attr.set(dev, lds);
     }
-    hipLaunchKernelGGL((lvs_stream_kernel<U, NQB, WAVES>), dim3(grid), dim3(WAVES * 64), lds, stream, a);
+    hipLaunchKernelGGL((lvs_stream_kernel<U, NQB, WAVES, SEED>), dim3(grid), dim3(WAVES * 64), lds, stream, a);
     return hipGetLastError();
 }
 
-template <int NQB, int WAVES>
+template <int NQB, int WAVES, bool SEED>
 static hipError_t stream_launch_nqb(const LvsStreamArgs& a, int grid, size_t lds, hipStream_t stream) {
     // fragments in flight: the largest of 16 / 24 / 8 that divides the fragments per K segment gives the branch-free
     // inner loop; anything else runs the general state machine with 16
-    if (a.jper % 16 == 0) return stream_launch_one<16, NQB, WAVES>(a, grid, lds, stream);
-    if constexpr (NQB == 1) {  // 24 fragment registers + 2 accumulator sets: one query block only
-        if (a.jper % 24 == 0) return stream_launch_one<24, NQB, WAVES>(a, grid, lds, stream);
+    if (a.jper % 16 == 0) return stream_launch_one<16, NQB, WAVES, SEED>(a, grid, lds, stream);
+    if constexpr (NQB == 1 && !SEED) {  // 24 fragment registers + 2 accumulator sets: one query block only
+        if (a.jper % 24 == 0) return stream_launch_one<24, NQB, WAVES, SEED>(a, grid, lds, stream);
     }
-    if (a.jper % 8 == 0) return stream_launch_one<8, NQB, WAVES>(a, grid, lds, stream);
-    return stream_launch_one<16, NQB, WAVES>(a, grid, lds, stream);
+    if (a.jper % 8 == 0) return stream_launch_one<8, NQB, WAVES, SEED>(a, grid, lds, stream);
+    return stream_launch_one<16, NQB, WAVES, SEED>(a, grid, lds, stream);
+}
+
+template <bool SEED>
+static hipError_t stream_launch_mode(const LvsStreamArgs& a, int grid, size_t lds, hipStream_t stream) {
+    if (a.nqb == 1) return stream_launch_nqb<1, 4, SEED>(a, grid, lds, stream);
+    if (a.nqb == 2) return stream_launch_nqb<2, 8, SEED>(a, grid, lds, stream);
+    return stream_launch_nqb<3, 8, SEED>(a, grid, lds, stream);
 }
 
 // a.nqb / a.groups / a.kcap come from lvs_stream_plan.  On return a.nparts = candidate lists per query in a.out
@@ -416,7 +449,6 @@ hipError_t lvs_stream_launch(LvsStreamArgs& a, hipStream_t stream) {
     a.nparts = ranges;
     const int grid = ranges * a.groups;
     const size_t lds = lvs_stream_lds_bytes(a.nbfrag, a.nqb, a.kcap);
-    if (a.nqb == 1) return stream_launch_nqb<1, 4>(a, grid, lds, stream);
-    if (a.nqb == 2) return stream_launch_nqb<2, 8>(a, grid, lds, stream);
-    return stream_launch_nqb<3, 8>(a, grid, lds, stream);
+    if (a.seed_out) return stream_launch_mode<true>(a, grid, lds, stream);
+    return stream_launch_mode<false>(a, grid, lds, stream);
 }

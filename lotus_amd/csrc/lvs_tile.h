@@ -152,7 +152,7 @@ hipError_t lvs_tile_launch(int mode, const LvsTileArgs& a, hipStream_t stream);
 // workgroup; beyond 64 queries 2 or 4 sibling workgroups share a corpus range through their XCD's L2. ----
 #define LVS_STREAM_MAXQ 256
 #define LVS_STREAM_MAXWG 768   // most corpus ranges (= partial candidate lists per query) a launch may use
-#define LVS_STREAM_SEED_MAX 16384  // most sample rows whose scores seed the thresholds of a multi-query call
+#define LVS_STREAM_SEED_ROWS 32768  // sample rows (the first of the shard) whose scores seed the thresholds of a multi-query call
 struct LvsStreamArgs {
     const void* xb;
     const void* xq;
@@ -161,6 +161,7 @@ struct LvsStreamArgs {
     const uint32_t* row_ids;
     uint32_t* gtau;  // [nq] zero-initialised, or seeded with a valid lower bound of every query's k-th best score
     u64* out;        // [nparts][nq][k]
+    float* seed_out; // non-NULL: SEED mode - [nparts][nq] best score of every (corpus range, query) instead of lists
     long long nb, ldb, ldq, id_offset;
     int nq, k, metric;
     int nj;                  // MFMAs per 32-row block = nseg * dpad / 16
