@@ -236,6 +236,23 @@ int32_t lvs_kmeans_pack_centroids(const float* centroids, int32_t k, int32_t d, 
 int32_t lvs_kmeans_update_centroids(const float* sums, float* counts, int32_t k, int32_t d, int64_t n_train, float* centroids,
                                     int32_t* out_nsplit, int32_t pack_mode, void* packed_out, float* norms_out,
                                     float* stats_out, void* stream);
+/* ---- exact distance bounds across k-means iterations (Hamerly): rows whose nearest centroid provably has not changed are
+ * not searched again - same assignments as faiss's exhaustive iteration (lotus/utils.py:62), less work once the centroids
+ * settle.  Per training row: assign (int32, -1 = unknown), ub >= its distance to the assigned centroid, lb <= its distance
+ * to every other centroid (Euclidean, in the rows' stored domain). ---- */
+/* out_delta [k] = |c_new_j - c_old_j| (rounded up), out_top2 [3] = {largest delta, its centroid (int bits), second largest} */
+int32_t lvs_kmeans_centroid_shift(const float* c_old, const float* c_new, int32_t k, int32_t d, float* out_delta,
+                                  float* out_top2, void* stream);
+/* Bounds of rows positions[i] (NULL: rows 0..m) from an L2 search result: keys [m][key_stride] (winner first; with
+ * second == NULL the runner-up is keys[i][1], an exact k = 2 search), second [m] the runner-up score of lvs_nearest_hi.
+ * The search's own error bound (coef5 / corpus_stats as in lvs_margin_select_stats) widens both bounds. */
+int32_t lvs_kmeans_bounds_set(const uint64_t* keys, int32_t key_stride, const float* second, const float* q_norms_sq,
+                              const int64_t* positions, int64_t m, const float* corpus_stats, const float* coef5,
+                              int64_t id_offset, int32_t* assign, float* ub, float* lb, void* stream);
+/* After a centroid update: ub += delta[assign], lb -= largest delta among the other centroids; rows with ub (1 + 1e-5) >= lb
+ * (or no assignment yet) are appended to out_idx (order unspecified), *out_count (device uint64, zeroed by the caller) += n. */
+int32_t lvs_kmeans_bounds_step(const int32_t* assign, float* ub, float* lb, const float* delta, const float* top2, int64_t n,
+                               int64_t* out_idx, uint64_t* out_count, void* stream);
 /* HOST helpers (plain host pointers), bit-exact with faiss: rand_perm(n, seed) = Fisher-Yates on std::mt19937
  * (training subsample and initial centroids), and split_clusters (empty-cluster re-seeding, RNG seed 1234). */
 int32_t lvs_rand_perm_host(int64_t n, int64_t seed, int64_t* out_perm);

@@ -339,7 +339,7 @@ class HipBackend:
         return keys
 
     def nearest(self, corpus: PackedRows, queries: PackedRows, metric: int, id_offset: int = 0, stats: dict | None = None,
-                exact_scores: bool = True, corpus_stats=None):
+                exact_scores: bool = True, corpus_stats=None, bounds=None):
         """Nearest corpus row of every query (k = 1) -> int64 key tensor [nq, 1], same winner as ``search_keys(.., 1, ..)``.
 
         fp32-accurate operands (fp16 hi|lo rows) cost two or three MFMA passes in the exact search.  Here ONE pass over
@@ -350,9 +350,15 @@ class HipBackend:
         fp32-accurate centroids at the cost of fp16 ones.  ``exact_scores=False`` leaves the one-pass scores inside the
         keys of certified queries (the ids are exact either way) and saves one pass over the queries.  ``corpus_stats``:
         device float32 [2] = (largest |row|^2, largest |lo part of a row|^2) of the corpus as ``kmeans_pack_centroids`` /
-        ``kmeans_finish`` leave it - the certificate's bound is then evaluated on the device (no host round trip for it)."""
+        ``kmeans_finish`` leave it - the certificate's bound is then evaluated on the device (no host round trip for it).
+        ``bounds``: ``(assign int32, ub float32, lb float32, positions int64 or None)`` device tensors - squared-L2 searches
+        only, needs ``corpus_stats``: the rows ``positions`` (None: rows 0..nq) also get their Hamerly bounds from this
+        search (``lvs_kmeans_bounds_set``): the winner, an upper bound of its distance and a lower bound of the distance to
+        every other corpus row, the search's own error bound included."""
         torch = self.torch
-        if corpus.mode == _capi.PACK_F16 and queries.mode == _capi.PACK_F16:
+        if bounds is not None and (corpus_stats is None or metric != _capi.METRIC_L2):
+            raise ValueError("bounds need the squared-L2 metric and the corpus statistics")
+        if corpus.mode == _capi.PACK_F16 and queries.mode == _capi.PACK_F16 and bounds is None:
             return self.search_keys(corpus, queries, 1, metric, id_offset=id_offset)  # nothing to certify: already exact
         plain = dict(id_offset=id_offset, one_pass=False)
         if corpus.d != queries.d:
@@ -397,6 +403,12 @@ class HipBackend:
             coef5 = (ctypes.c_float * 5)(*coef)
             self._c("lvs_margin_select_stats", _ptr(keys), _ptr(sec), _ptr(queries.norms), nq, _ptr(corpus_stats),
                     ctypes.addressof(coef5), _ptr(idx), _ptr(cnt), self._stream())
+        if bounds is not None:  # every row's bounds from the one-pass result first; the uncertified rows are redone below
+            b_assign, b_ub, b_lb, b_pos = bounds
+            coef5 = (ctypes.c_float * 5)(*coef)
+            self._c("lvs_kmeans_bounds_set", _ptr(keys), 1, _ptr(sec), _ptr(queries.norms), _ptr(b_pos), nq,
+                    _ptr(corpus_stats), ctypes.addressof(coef5), int(id_offset), _ptr(b_assign), _ptr(b_ub), _ptr(b_lb),
+                    self._stream())
         n_open = int(cnt.item())  # the call's one host round trip: the exact search below is sized by it
         # the winners are certified, their scores are still the one-pass approximations: put the exact scores in
         # (one HBM-bound pass over the queries; the k-means objective sums them)
@@ -405,11 +417,43 @@ class HipBackend:
                     metric, _ptr(corpus.norms), _ptr(queries.norms), int(id_offset), 1, _ptr(keys), self._stream())
         if n_open:
             sel = idx[:n_open]
-            keys[sel] = self.search_keys(corpus, self.gather(queries, sel), 1, metric, **plain)
+            sub = self.gather(queries, sel)
+            if bounds is None or corpus.n < 2:
+                keys[sel] = self.search_keys(corpus, sub, 1, metric, **plain)
+            else:  # exact best AND second best: the uncertified rows get bounds from exact (float32) distances
+                k2 = self.search_keys(corpus, sub, 2, metric, **plain)
+                keys[sel] = k2[:, :1]
+                # float32 rounding of |x|^2 + |c|^2 - 2 x.c (cancellation when the row sits on a centroid): a few ulps of
+                # the largest term - 8e-6 R |x| + 4e-6 R^2; errors proportional to the distance itself are covered by the
+                # relative margin of lvs_kmeans_bounds_step
+                exact = (ctypes.c_float * 5)(0.0, 8e-6, 0.0, 0.0, 4e-6)
+                qn_err = sub.norms
+                pos = sel if b_pos is None else b_pos[sel]
+                self._c("lvs_kmeans_bounds_set", _ptr(k2), 2, None, _ptr(qn_err), _ptr(pos), n_open, _ptr(corpus_stats),
+                        ctypes.addressof(exact), int(id_offset), _ptr(b_assign), _ptr(b_ub), _ptr(b_lb), self._stream())
         if stats is not None:
             stats["uncertified"] = stats.get("uncertified", 0) + n_open
             stats["queries"] = stats.get("queries", 0) + nq
         return keys
+
+    def kmeans_centroid_shift(self, c_old, c_new):
+        """-> (delta float32 [k], top2 float32 [3]): how far every centroid moved, the largest and second largest shift."""
+        torch = self.torch
+        k, d = int(c_new.shape[0]), int(c_new.shape[1])
+        delta = torch.empty((k,), dtype=torch.float32, device=self.device)
+        top2 = torch.empty((3,), dtype=torch.float32, device=self.device)
+        self._c("lvs_kmeans_centroid_shift", _ptr(c_old), _ptr(c_new), k, d, _ptr(delta), _ptr(top2), self._stream())
+        return delta, top2
+
+    def kmeans_bounds_step(self, assign, ub, lb, delta, top2):
+        """Move the bounds by the centroid shifts; -> int64 device tensor of the rows that need a new search."""
+        torch = self.torch
+        n = int(assign.numel())
+        idx = torch.empty((n,), dtype=torch.int64, device=self.device)
+        cnt = torch.zeros((1,), dtype=torch.int64, device=self.device)
+        self._c("lvs_kmeans_bounds_step", _ptr(assign), _ptr(ub), _ptr(lb), _ptr(delta), _ptr(top2), n, _ptr(idx), _ptr(cnt),
+                self._stream())
+        return idx[:int(cnt.item())]
 
     def merge_keys(self, parts):
         """parts int64 [P, nq, k] -> [nq, k]."""

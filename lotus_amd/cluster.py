@@ -33,7 +33,7 @@ class KMeansResult:
 def kmeans(x, k: int, niter: int = 20, seed: int = 1234, max_points_per_centroid: int | None = 256, backend=None,
            pack_mode: int | None = None, packed=None, shard: bool = False, process_group=None,
            final_assign: bool = True, centroid_precision: str = "fp32", n_total: int | None = None,
-           local_pos=None, stats: dict | None = None) -> KMeansResult:
+           local_pos=None, stats: dict | None = None, bounds: bool | None = None) -> KMeansResult:
     """faiss-parity k-means (``faiss.Kmeans(d, k, niter).train(x)`` + ``index.search(x, 1)``, ``lotus/utils.py:61-65``).
 
     ``x``: host matrix [n,d] (float16/32/64) and/or ``packed``: its device image.  Everything after the packing runs
@@ -42,7 +42,13 @@ def kmeans(x, k: int, niter: int = 20, seed: int = 1234, max_points_per_centroid
     the centroid division, faiss's empty-cluster split (its ``std::mt19937`` replayed by a device thread) and the
     repacking of the centroids happen on the device too: an iteration is a chain of launches whose only host round trip
     is the count of uncertified rows inside ``nearest``; objectives and split counts are read once, after the loop.
-    ``stats`` (dict) collects ``uncertified`` / ``queries`` of the certified assignments.
+    ``stats`` (dict) collects ``uncertified`` / ``queries`` of the certified assignments (and ``searched_rows`` per iteration).
+
+    ``bounds`` (default: on from 2^20 training rows with fp32-accurate centroids): exact distance bounds across iterations
+    (Hamerly 2010) - a row whose upper bound to its centroid stays below its lower bound to every other centroid after the
+    centroids moved keeps its assignment without a search (``lvs_kmeans_bounds_step``); all other rows are searched and get
+    fresh bounds.  Same assignments, sums, centroids and objectives as the exhaustive iteration - the sums still run over
+    all rows in row order - but once the centroids settle an iteration costs little more than that one pass over the rows.
 
     Multi-GPU (``shard=True`` with ``torch.distributed`` initialised):
       * rows replicated (``packed`` holds all ``n`` rows on every rank): the training rows are dealt to the ranks in
@@ -142,8 +148,34 @@ def kmeans(x, k: int, niter: int = 20, seed: int = 1234, max_points_per_centroid
         obj_dev = torch.zeros((max(niter, 1),), dtype=torch.float64, device=dev)
         nsplit_dev = torch.zeros((max(niter, 1),), dtype=torch.int32, device=dev)
         cpk, cstats = be.kmeans_pack_centroids(centroids, cmode, exp=pexp)
+        use_bounds = bounds if bounds is not None else (train.n >= (1 << 20))
+        use_bounds = bool(use_bounds) and cmode == _capi.PACK_SPLIT and hasattr(be, "kmeans_bounds_step") and k >= 2
+        if use_bounds:
+            b_assign = torch.full((train.n,), -1, dtype=torch.int32, device=dev)
+            b_ub = torch.zeros((train.n,), dtype=torch.float32, device=dev)
+            b_lb = torch.zeros((train.n,), dtype=torch.float32, device=dev)
+            keys = None
         for it in range(niter):
-            keys = be.nearest(cpk, train, _capi.METRIC_L2, exact_scores=False, corpus_stats=cstats, stats=stats)  # ids only ...
+            if not use_bounds:
+                keys = be.nearest(cpk, train, _capi.METRIC_L2, exact_scores=False, corpus_stats=cstats, stats=stats)  # ids only ...
+            else:
+                act = None
+                if keys is not None:  # bounds moved by the last update: which rows may have changed their centroid?
+                    act = be.kmeans_bounds_step(b_assign, b_ub, b_lb, shift, top2)
+                if keys is None or int(act.numel()) > train.n // 2:  # (almost) everything moved: search all rows in place
+                    keys = be.nearest(cpk, train, _capi.METRIC_L2, exact_scores=False, corpus_stats=cstats, stats=stats,
+                                      bounds=(b_assign, b_ub, b_lb, None))
+                    searched = train.n
+                elif int(act.numel()):
+                    sub = be.gather(train, act)
+                    keys[act] = be.nearest(cpk, sub, _capi.METRIC_L2, exact_scores=False, corpus_stats=cstats, stats=stats,
+                                           bounds=(b_assign, b_ub, b_lb, act))
+                    searched = int(act.numel())
+                else:
+                    searched = 0
+                if stats is not None:
+                    stats.setdefault("searched_rows", []).append(searched)
+                c_old = centroids.clone()
             sums, counts = be.kmeans_accumulate_keys(train, keys, k)
             # ... because the objective (faiss: sum of the assignment distances) follows from the sums the update needs
             # anyway:  sum_i |x_i - c_a(i)|^2 = sum_i |x_i|^2 - 2 sum_j c_j . S_j + sum_j n_j |c_j|^2   (float64, [k,d])
@@ -152,6 +184,8 @@ def kmeans(x, k: int, niter: int = 20, seed: int = 1234, max_points_per_centroid
                 _dist.all_reduce_sum_([sums, counts, obj_dev[it:it + 1]], process_group)
             # centroid division + faiss split_clusters (same RNG stream on every rank) + repack, nothing read back
             cpk, cstats = be.kmeans_finish(sums, counts, centroids, nt, cmode, nsplit_dev[it:it + 1], exp=pexp)
+            if use_bounds:
+                shift, top2 = be.kmeans_centroid_shift(c_old, centroids)
         obj[:] = (obj_dev[:niter].cpu().numpy() * 2.0 ** (-2 * pexp)).astype(np.float32)
         nsplit[:] = nsplit_dev[:niter].cpu().numpy()
     assign = np.zeros(0, np.int64)

@@ -428,6 +428,169 @@ int32_t km_pack_and_stats(const float* centroids, int32_t k, int32_t d, int32_t 
 }
 }  // namespace
 
+// ---- exact distance bounds across iterations (Hamerly 2010): which rows need no new search -------------------------------
+// Per row i: assign[i], ub[i] >= |x_i - c_assign| and lb[i] <= min over the OTHER centroids of |x_i - c_j| (Euclidean, in
+// the rows' scaled domain).  When the centroids move by delta_j, ub grows by delta_assign and lb shrinks by the largest
+// delta among the others; while ub < lb (with a margin above float32 noise) the row's nearest centroid provably has not
+// changed - faiss's exhaustive search would return the same id - and the row is skipped.  Every other row goes through the
+// full search again, which also renews its bounds.  Results are identical to the exhaustive iteration; only work is saved.
+namespace {
+// delta[j] = |c_new_j - c_old_j| (one wave per centroid)
+__global__ __launch_bounds__(256) void km_shift_kernel(const float* __restrict__ c_old, const float* __restrict__ c_new, int k,
+                                                       int d, float* __restrict__ delta) {
+    const int lane = threadIdx.x & 63;
+    const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (j >= k) return;
+    float acc = 0.f;
+    for (int t = lane; t < d; t += 64) {
+        const float v = c_new[(long long)j * d + t] - c_old[(long long)j * d + t];
+        acc += v * v;
+    }
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) acc += __shfl_xor(acc, m, 64);
+    if (lane == 0) delta[j] = sqrtf(acc) * (1.0f + 1e-6f);  // rounded up
+}
+// top2[0] = largest delta, top2[1] = its centroid (as float bits of an int), top2[2] = second largest (one workgroup)
+__global__ __launch_bounds__(256) void km_shift_top2_kernel(const float* __restrict__ delta, int k, float* __restrict__ top2) {
+    __shared__ float m1[256], m2[256];
+    __shared__ int a1[256];
+    float b1 = 0.f, b2 = 0.f;
+    int i1 = -1;
+    for (int j = threadIdx.x; j < k; j += 256) {
+        const float v = delta[j];
+        if (v > b1 || i1 < 0) {
+            b2 = i1 < 0 ? 0.f : b1;
+            b1 = v;
+            i1 = j;
+        } else if (v > b2) {
+            b2 = v;
+        }
+    }
+    m1[threadIdx.x] = b1;
+    m2[threadIdx.x] = b2;
+    a1[threadIdx.x] = i1;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float g1 = 0.f, g2 = 0.f;
+        int gi = -1;
+        for (int t = 0; t < 256; ++t) {
+            if (a1[t] < 0) continue;
+            if (m1[t] > g1 || gi < 0) {
+                g2 = gi < 0 ? m2[t] : fmaxf(g1, m2[t]);
+                g1 = m1[t];
+                gi = a1[t];
+            } else {
+                g2 = fmaxf(g2, m1[t]);
+            }
+        }
+        top2[0] = g1;
+        top2[1] = __int_as_float(gi);
+        top2[2] = g2;
+    }
+}
+// bounds of the rows pos[i] (NULL: rows 0 .. m) from a search result: keys[i] = winner key (score = -dist^2), second[i] =
+// runner-up score; err_i = (coef[0] E + coef[1] R) |x| + coef[2] + coef[3] R + coef[4] R^2 is added to the winner's squared
+// distance and subtracted from the runner-up's before the roots (the search's own error bound)
+__global__ __launch_bounds__(256) void km_bounds_set_kernel(const u64* __restrict__ keys, long long key_stride,
+                                                            const float* __restrict__ second, const float* __restrict__ qn,
+                                                            const long long* __restrict__ pos, long long m,
+                                                            const float* __restrict__ stats, float c0, float c1, float c2,
+                                                            float c3, float c4, long long id_offset, int* __restrict__ assign,
+                                                            float* __restrict__ ub, float* __restrict__ lb) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    const float R = sqrtf(stats[0]), E = sqrtf(stats[1]);
+    const long long row = pos ? pos[i] : i;
+    const u64 kq = keys[i * key_stride];
+    const float err = (c0 * E + c1 * R) * sqrtf(qn[i]) + c2 + c3 * R + c4 * R * R;
+    const float d1 = kq ? fmaxf(-lvs_unord32((uint32_t)(kq >> 32)), 0.f) : 3.0e38f;
+    const float s2 = second ? second[i] : lvs_unord32((uint32_t)(keys[i * key_stride + 1] >> 32));
+    const float d2 = fmaxf(-s2, 0.f);  // -inf runner-up (a single centroid) -> +inf
+    assign[row] = kq ? (int)((long long)(0xFFFFFFFFu - (uint32_t)(kq & 0xFFFFFFFFull)) - id_offset) : -1;
+    ub[row] = sqrtf(d1 + err) * (1.0f + 1e-6f);
+    lb[row] = sqrtf(fmaxf(d2 - err, 0.f)) * (1.0f - 1e-6f);
+}
+// one iteration later: move the bounds by the centroid shifts and list the rows whose nearest centroid may have changed
+__global__ __launch_bounds__(256) void km_bounds_step_kernel(const int* __restrict__ assign, float* __restrict__ ub,
+                                                             float* __restrict__ lb, const float* __restrict__ delta,
+                                                             const float* __restrict__ top2, long long n, long long per_block,
+                                                             long long* __restrict__ out_idx,
+                                                             unsigned long long* __restrict__ out_count) {
+    __shared__ unsigned long long s_base;
+    __shared__ unsigned s_count;
+    const float g1 = top2[0], g2 = top2[2];
+    const int gi = __float_as_int(top2[1]);
+    const long long q_begin = (long long)blockIdx.x * per_block;
+    const long long q_end = q_begin + per_block < n ? q_begin + per_block : n;
+    if (threadIdx.x == 0) s_count = 0;
+    __syncthreads();
+    unsigned mine = 0;
+    for (long long q = q_begin + threadIdx.x; q < q_end; q += blockDim.x) {
+        const int a = assign[q];
+        float u = ub[q], l = lb[q];
+        if (a >= 0) {
+            u += delta[a];
+            l -= a == gi ? g2 : g1;
+        }
+        ub[q] = u;
+        lb[q] = l;
+        mine += (a < 0 || !(u * (1.0f + 1e-5f) < l)) ? 1u : 0u;
+    }
+    if (mine) atomicAdd(&s_count, mine);
+    __syncthreads();
+    if (s_count == 0) return;
+    if (threadIdx.x == 0) {
+        s_base = atomicAdd(out_count, (unsigned long long)s_count);
+        s_count = 0;
+    }
+    __syncthreads();
+    for (long long q = q_begin + threadIdx.x; q < q_end; q += blockDim.x) {
+        const int a = assign[q];
+        if (a < 0 || !(ub[q] * (1.0f + 1e-5f) < lb[q])) out_idx[s_base + atomicAdd(&s_count, 1u)] = q;
+    }
+}
+}  // namespace
+
+extern "C" int32_t lvs_kmeans_centroid_shift(const float* c_old, const float* c_new, int32_t k, int32_t d, float* out_delta,
+                                             float* out_top2, void* stream) {
+    LVS_REQUIRE(k > 0 && d > 0 && c_old && c_new && out_delta && out_top2, "bad arguments");
+    LVS_DEVICE_GUARD(stream);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(km_shift_kernel, dim3((unsigned)lvs_ceil_div(k, 4)), dim3(256), 0, st, c_old, c_new, k, d, out_delta);
+    hipLaunchKernelGGL(km_shift_top2_kernel, dim3(1), dim3(256), 0, st, (const float*)out_delta, k, out_top2);
+    LVS_HIP_CHECK(hipGetLastError());
+    return LVS_OK;
+}
+
+extern "C" int32_t lvs_kmeans_bounds_set(const uint64_t* keys, int32_t key_stride, const float* second, const float* q_norms_sq,
+                                         const int64_t* positions, int64_t m, const float* corpus_stats, const float* coef5,
+                                         int64_t id_offset, int32_t* assign, float* ub, float* lb, void* stream) {
+    LVS_REQUIRE(m >= 0 && key_stride >= 1 && (second || key_stride >= 2), "bad arguments");
+    if (m == 0) return LVS_OK;
+    LVS_REQUIRE(keys && q_norms_sq && corpus_stats && coef5 && assign && ub && lb, "NULL buffer");
+    LVS_DEVICE_GUARD(stream);
+    hipLaunchKernelGGL(km_bounds_set_kernel, dim3((unsigned)lvs_ceil_div(m, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const u64*)keys, (long long)key_stride, second, q_norms_sq, (const long long*)positions, (long long)m,
+                       corpus_stats, coef5[0], coef5[1], coef5[2], coef5[3], coef5[4], (long long)id_offset, assign, ub, lb);
+    LVS_HIP_CHECK(hipGetLastError());
+    return LVS_OK;
+}
+
+extern "C" int32_t lvs_kmeans_bounds_step(const int32_t* assign, float* ub, float* lb, const float* delta, const float* top2,
+                                          int64_t n, int64_t* out_idx, uint64_t* out_count, void* stream) {
+    LVS_REQUIRE(n >= 0, "bad arguments");
+    if (n == 0) return LVS_OK;
+    LVS_REQUIRE(assign && ub && lb && delta && top2 && out_idx && out_count, "NULL buffer");
+    LVS_DEVICE_GUARD(stream);
+    long long per_block = lvs_ceil_div(n, 2048);
+    per_block = lvs_round_up(per_block < 1024 ? 1024 : per_block, 256);
+    hipLaunchKernelGGL(km_bounds_step_kernel, dim3((unsigned)lvs_ceil_div(n, per_block)), dim3(256), 0, (hipStream_t)stream,
+                       assign, ub, lb, delta, top2, (long long)n, per_block, (long long*)out_idx,
+                       (unsigned long long*)out_count);
+    LVS_HIP_CHECK(hipGetLastError());
+    return LVS_OK;
+}
+
 extern "C" int64_t lvs_kmeans_objective_workspace_bytes(int32_t k) { return k > 0 ? lvs_round_up((int64_t)k * 8, 256) : LVS_EINVAL; }
 
 extern "C" int32_t lvs_kmeans_objective(const float* centroids, const float* sums, const float* counts, int32_t k, int32_t d,

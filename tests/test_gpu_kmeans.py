@@ -361,3 +361,31 @@ def test_counting_sort_two_digit_path_and_ignored_rows(hip_backend):
         r2 = np.zeros((k2, 8), np.float32)
         np.add.at(r2, a2, x2.astype(np.float32))
         assert np.array_equal(s2.cpu().numpy(), r2) and np.array_equal(c2.cpu().numpy(), np.bincount(a2, minlength=k2))
+
+
+@pytest.mark.parametrize("mode", [F16, SPLIT])
+def test_distance_bounds_skip_rows_without_changing_any_result(hip_backend, mode):
+    """Hamerly bounds (lvs_kmeans_bounds_step): rows whose nearest centroid provably did not change are not searched again.
+    Same assignments => bit-identical sums, centroids, objectives, split counts as the exhaustive iteration - and on
+    clustered rows almost nothing is searched once the centroids settle."""
+    import benchdata
+    from lotus_amd.cluster import kmeans
+
+    K, n, d = 96, 150_000, 64
+    x16, _ = benchdata.blobs(benchdata.CFG_KMEANS, n, d, K)
+    x = x16 if mode == F16 else (x16.astype(np.float32) * np.float32(1.0 + 2.0 ** -13))  # values that need the lo half
+    kw = dict(niter=12, backend=hip_backend, max_points_per_centroid=None)
+    plain = kmeans(x, K, bounds=False, **kw)
+    st = {}
+    fast = kmeans(x, K, bounds=True, stats=st, **kw)
+    assert np.array_equal(fast.nsplit, plain.nsplit)
+    assert np.array_equal(fast.obj, plain.obj) and np.array_equal(fast.centroids, plain.centroids)
+    assert np.array_equal(fast.assign, plain.assign)
+    searched = st["searched_rows"]
+    assert searched[0] == n and len(searched) == 12
+    assert sum(searched[6:]) <= 0.2 * 6 * n, searched  # the tail of the run searches a small fraction of the rows
+    # rows without structure: the bounds rarely certify anything, the result must not change either
+    xu = benchdata.corpus(benchdata.CFG_KMEANS, 60_000, d)
+    a = kmeans(xu, 40, niter=5, backend=hip_backend, max_points_per_centroid=None, bounds=False)
+    b = kmeans(xu, 40, niter=5, backend=hip_backend, max_points_per_centroid=None, bounds=True)
+    assert np.array_equal(a.centroids, b.centroids) and np.array_equal(a.obj, b.obj) and np.array_equal(a.assign, b.assign)
