@@ -59,23 +59,22 @@ def scenario(name, kernel, fn, reps, warm=2, bound="hbm", bytes_per_call=None, f
 
 def ld(p): return int(p.rows.shape[1])
 # ---- HBM-bound: the small-batch streaming kernel (the literal sem_search) ----
-scenario("stream_1q_x_1M_d768", "lvs_stream_kernel", lambda: be.search_keys(p1m, be.slice_rows(q100k, 0, 1), 10, IP), 10,
+MAIN = ", false>(LvsStreamArgs)"  # the scan itself (the SEED-mode launch over the sample carries ", true>")
+scenario("stream_1q_x_1M_d768", MAIN, lambda: be.search_keys(p1m, be.slice_rows(q100k, 0, 1), 10, IP), 10,
          bytes_per_call=1_000_000 * ld(p1m) * 2)
-scenario("stream_64q_x_1M_d768", "lvs_stream_kernel", lambda: be.search_keys(p1m, be.slice_rows(q100k, 0, 64), 10, IP), 10,
-         bytes_per_call=1_000_000 * ld(p1m) * 2, launches_per_call=2, note="two 32-query blocks per corpus pass; sample + seeded main pass")
-scenario("tile_96q_x_1M_d768", "lvs_tile_kernel<0, 2>", lambda: be.search_keys(p1m, be.slice_rows(q100k, 0, 96), 10, IP), 10,
-         bound="mfma", flops_per_call=2.0 * 96 * 1_000_000 * D, note="past LVS_STREAM_MAXQ = 64: 128-query tile geometry")
-scenario("stream_32q_x_1M_d768", "lvs_stream_kernel", lambda: be.search_keys(p1m, be.slice_rows(q100k, 0, 32), 10, IP), 10,
-         bytes_per_call=1_000_000 * ld(p1m) * 2)
-scenario("tile_128q_x_1M_d768", "lvs_tile_kernel<0, 2>", lambda: be.search_keys(p1m, be.slice_rows(q100k, 0, 128), 10, IP), 10,
-         bound="mfma", flops_per_call=2.0 * 128 * 1_000_000 * D, note="just past the streaming kernel: 128-query tile geometry")
-scenario("stream_1q_x_4M_d768", "lvs_stream_kernel", lambda: be.search_keys(p4m, be.slice_rows(q100k, 0, 1), 10, IP), 10,
+for nq_s, note_s in ((32, "one 32-query block per workgroup, thresholds seeded from 32 768 sample rows"),
+                     (64, "two blocks per workgroup (8 waves)"), (96, "three blocks per workgroup"),
+                     (128, "two sibling workgroups per corpus range x 2 blocks: the corpus crosses the fabric twice"),
+                     (192, "two sibling workgroups x 3 blocks"), (256, "three sibling workgroups x 3 blocks")):
+    scenario(f"stream_{nq_s}q_x_1M_d768", MAIN, lambda n_=nq_s: be.search_keys(p1m, be.slice_rows(q100k, 0, n_), 10, IP), 10,
+             bytes_per_call=1_000_000 * ld(p1m) * 2, note=note_s)
+scenario("stream_1q_x_4M_d768", MAIN, lambda: be.search_keys(p4m, be.slice_rows(q100k, 0, 1), 10, IP), 10,
          bytes_per_call=N4 * ld(p4m) * 2)
-scenario("stream_32q_x_4M_d768", "lvs_stream_kernel", lambda: be.search_keys(p4m, be.slice_rows(q100k, 0, 32), 10, IP), 10,
+scenario("stream_32q_x_4M_d768", MAIN, lambda: be.search_keys(p4m, be.slice_rows(q100k, 0, 32), 10, IP), 10,
          bytes_per_call=N4 * ld(p4m) * 2)
-scenario("stream_1q_x_2M_d384", "lvs_stream_kernel", lambda: be.search_keys(p384, be.slice_rows(q384, 0, 1), 10, IP), 10,
+scenario("stream_1q_x_2M_d384", MAIN, lambda: be.search_keys(p384, be.slice_rows(q384, 0, 1), 10, IP), 10,
          bytes_per_call=2_000_000 * ld(p384) * 2, note="d = 384 = BASELINE configs[0]'s dimension")
-scenario("stream_32q_x_2M_d384", "lvs_stream_kernel", lambda: be.search_keys(p384, q384, 10, IP), 10,
+scenario("stream_32q_x_2M_d384", MAIN, lambda: be.search_keys(p384, q384, 10, IP), 10,
          bytes_per_call=2_000_000 * ld(p384) * 2)
 # ---- MFMA-bound: the tile kernel in its modes ----
 shard = be.slice_rows(p4m, 0, 125_000)
