@@ -171,7 +171,9 @@ class HipBackend:
         auto = isinstance(exp, str)
         if auto and exp != "auto":
             raise ValueError("exp must be an int or 'auto'")
-        if auto and (mode != _capi.PACK_SPLIT or n == 0 or normalize):
+        if auto and normalize and mode == _capi.PACK_SPLIT:
+            auto, exp = False, self.SCALE_TARGET_EXP + 2  # unit rows: components <= 1, typically ~3 / sqrt(d)
+        if auto and (mode != _capi.PACK_SPLIT or n == 0):
             auto, exp = False, 0
         rows = torch.empty((n, ld), dtype=torch.float16, device=self.device)
         norms = torch.empty((n,), dtype=torch.float32, device=self.device)

@@ -33,6 +33,7 @@ METRIC_INNER_PRODUCT = _capi.METRIC_IP  # == faiss.METRIC_INNER_PRODUCT (0)
 METRIC_L2 = _capi.METRIC_L2  # == faiss.METRIC_L2 (1)
 
 FLT_MAX = np.float32(3.4028234663852886e38)
+_RANK_BLOCK_SCORES = 1 << 28  # K = N ranking: scores (float32) materialised at a time
 
 
 @dataclass
@@ -66,18 +67,23 @@ class HipVS(VS):
             concatenated across the query groups.  ``"auto"`` - ``lotus_amd.plan.pick_split`` chooses (gq, gc) from the
             per-GPU shapes' measured rates (8 GPUs: 2 x 4 - 50 k x 250 k per GPU at configs[2] - where the fused top-k runs
             closer to its long-stream rate than on the 100 k x 125 k shards of the pure row split).
+        normalize: L2-normalise every row and every query on the device while packing (``lvs_pack_rows(normalize=1)``):
+            with the inner-product metric this IS cosine similarity whatever the embedder returns.  ``FaissVS`` has no
+            such switch - it relies on the RM normalising (``sentence_transformers_rm.py:30,71``) - so the default is off.
         max_resident: how many indexes stay on the GPU.
         backend: injected device backend (tests); default ``HipBackend``.
     """
 
     def __init__(self, metric: int = METRIC_INNER_PRODUCT, storage: str = "auto", device: str | None = None,
-                 shard: bool | str = False, max_resident: int = 4, backend=None, process_group=None) -> None:
+                 shard: bool | str = False, max_resident: int = 4, backend=None, process_group=None,
+                 normalize: bool = False) -> None:
         super().__init__()
         if metric not in (METRIC_INNER_PRODUCT, METRIC_L2):
             raise ValueError("metric must be METRIC_INNER_PRODUCT or METRIC_L2")
         if storage not in ("auto", "fp16", "fp32"):
             raise ValueError("storage must be 'auto', 'fp16' or 'fp32'")
         self.metric = metric
+        self.normalize = bool(normalize)
         self.storage = storage
         self.index_dir: str | None = None
         self._device = device
@@ -207,7 +213,7 @@ class HipVS(VS):
         dtype = np.float16 if (is_dev and str(vecs.dtype) == "torch.float16") else (np.float32 if is_dev else vecs.dtype)
         mode = self._pack_mode(dtype)
         exp = "auto"  # fp32-accurate rows are stored as x * 2^e with e chosen from the data (backend.pack); fp16 rows as given
-        if world > 1 and mode == _capi.PACK_SPLIT:
+        if world > 1 and mode == _capi.PACK_SPLIT and not self.normalize:
             # one exponent for every shard (per-shard lists are merged by score): agreed from each rank's first rows.  Every
             # rank of the corpus group enters the exchange, also one whose shard is empty.
             from . import _dist
@@ -218,7 +224,7 @@ class HipVS(VS):
             amax = float(max(head.max(initial=0.0), -head.min(initial=0.0)))
             t = torch.tensor([amax if np.isfinite(amax) else 0.0], dtype=torch.float64)
             exp = self.backend.exp_for(float(_dist.all_gather_rows(t, self._pg_corpus()).max().item()))
-        packed = self.backend.pack(vecs[lo:hi], mode, exp=exp, check=True)
+        packed = self.backend.pack(vecs[lo:hi], mode, normalize=self.normalize, exp=exp, check=True)
         ent = _Resident(vecs=stored, packed=packed, n=n, d=d, lo=lo, hi=hi, sig=sig)
         self._resident[index_dir] = ent
         self._resident.move_to_end(index_dir)
@@ -330,14 +336,27 @@ class HipVS(VS):
         # queries share the index's power-of-two scale (required for L2; for inner products it keeps one exponent per
         # index); they are validated while they are packed, the flag word comes back together with the results
         qexp = kwargs.get("_query_exp", ent.packed.exp)
-        queries = be.pack(q, ent.packed.mode, exp=qexp, check="lazy")
+        queries = be.pack(q, ent.packed.mode, normalize=self.normalize, exp=qexp, check="lazy")
         score_exp = be.score_exp_of(ent.packed, queries)
         id_map = None
         if rank_all:
             # score rows of this rank's shard, exchanged so that every rank ranks the complete rows (column-sharded
             # score matrix, one all-gather); the device sort goes through the queries in chunks of < 2^32 scores
-            sc, order = self._score_rows(ent, queries, sub, world)
-            keys = be.rank_scores(sc)[:, :k_eff].contiguous()
+            # ... and in blocks of at most 2^28 scores (1 GB of float32), so that a K = N call never holds the whole Q x N
+            # matrix next to its Q x N keys (sem_dedup's reference path asks for N x N)
+            n_cols = ent.n if sub is None else int(sub.size)
+            qstep = max(1, min(nq, _RANK_BLOCK_SCORES // max(1, n_cols)))
+            parts, order = [], None
+            for q0 in range(0, nq, qstep):
+                sc, order = self._score_rows(ent, be.slice_rows(queries, q0, min(nq, q0 + qstep)), sub, world)
+                parts.append(be.rank_scores(sc)[:, :k_eff].contiguous())
+                del sc
+            if len(parts) == 1:
+                keys = parts[0]
+            else:
+                import torch
+
+                keys = torch.cat(parts)
             score_exp = 0  # score rows come back in the caller's units already
             if order is not None:
                 id_map = be.to_device(order)
@@ -420,7 +439,7 @@ class HipVS(VS):
             if sub.size == ent.n and np.array_equal(sub, np.arange(ent.n)):
                 sub = None
         _, world = self._dist()
-        queries = be.pack(q, ent.packed.mode, exp=ent.packed.exp, check=True)
+        queries = be.pack(q, ent.packed.mode, normalize=self.normalize, exp=ent.packed.exp, check=True)
         sc, order = self._score_rows(ent, queries, sub, world, want_ids=False)
         out = sc.cpu().numpy()
         if order is not None:  # columns arrived shard by shard: put them back into the order of `ids`

@@ -185,3 +185,43 @@ def test_scores_matrix_for_cascade_callers(indexed):
     assert S.shape == (5, 400) and S.dtype == np.float32 and np.allclose(S, ref, atol=1e-6)
     sub = [3, 7, 399]
     assert np.allclose(vs.scores(xq, ids=sub), ref[:, sub], atol=1e-6)
+
+
+def test_normalize_option_is_cosine_similarity(tmp_path):
+    """HipVS(normalize=True): rows and queries are L2-normalised while they are packed - inner product == cosine."""
+    import synth
+    from lotus_amd import HipVS
+    from oracle_backend import OracleBackend
+
+    xb = synth.corpus(300, 16, seed=3) * np.linspace(0.1, 9.0, 300, dtype=np.float32)[:, None]
+    xq = synth.queries(synth.corpus(300, 16, seed=3), 7, seed=4)[0] * 5.0
+    vs = HipVS(backend=OracleBackend(), normalize=True)
+    vs.index(None, xb, str(tmp_path / "i"), persist=False)
+    out = vs(xq, 4)
+    cos = (xq / np.linalg.norm(xq, axis=1, keepdims=True)) @ (xb / np.linalg.norm(xb, axis=1, keepdims=True)).T
+    ref = np.argsort(-cos, axis=1)[:, :4]
+    assert np.array_equal(out.indices, ref) and np.allclose(out.distances, np.take_along_axis(cos, ref, 1), atol=1e-5)
+
+
+def test_k_equals_n_ranking_goes_through_in_query_blocks(tmp_path, monkeypatch):
+    """K = N callers beyond LVS_MAX_K: the score matrix is produced and ranked in blocks of <= 2^28 scores."""
+    import synth
+    from lotus_amd import HipVS, vs as vs_mod
+    from oracle_backend import OracleBackend
+
+    xb = synth.corpus(2100, 8, seed=5)
+    vs = HipVS(backend=OracleBackend())
+    vs.index(None, xb, str(tmp_path / "i"), persist=False)
+    calls = []
+    orig = vs._score_rows
+    monkeypatch.setattr(vs, "_score_rows", lambda ent, q, sub, world, **kw: (calls.append(q.n), orig(ent, q, sub, world, **kw))[1])
+    out = vs(xb[:50], 2100)
+    assert calls == [50]
+    monkeypatch.setattr(vs_mod, "_RANK_BLOCK_SCORES", 2100 * 16)  # 16 queries per block
+    calls.clear()
+    out2 = vs(xb[:50], 2100)
+    assert calls == [16, 16, 16, 2] and np.array_equal(out2.indices, out.indices) and np.array_equal(out2.distances, out.distances)
+    import oracle
+    Dr, Ir = oracle.flat_search(xb, xb[:50], 2100)
+    err, hard, recall = synth.compare_topk(Dr, Ir, out.distances, out.indices)
+    assert err <= 1e-5 and hard == 0 and recall == 1.0
