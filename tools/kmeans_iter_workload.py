@@ -11,11 +11,24 @@ from lotus_amd.cluster import kmeans
 
 be = HipBackend("cuda:0")
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000
-g = torch.Generator(device=be.device); g.manual_seed(7)
-x = torch.nn.functional.normalize(torch.randn((n, 768), generator=g, device=be.device), dim=1).to(torch.float16)
-pk = be.pack(x, _capi.PACK_F16)
-del x
-kw = dict(backend=be, packed=pk, max_points_per_centroid=None, final_assign=False)
+if "blobs" in sys.argv[1:]:  # the bench's configs[4] rows (host-generated numpy streams)
+    import benchdata
+    xh, _ = benchdata.blobs(benchdata.CFG_KMEANS, n, 768, 1024)
+    pk = be.pack(xh, _capi.PACK_F16)
+    del xh
+else:
+    g = torch.Generator(device=be.device); g.manual_seed(7)
+    x = torch.nn.functional.normalize(torch.randn((n, 768), generator=g, device=be.device), dim=1).to(torch.float16)
+    pk = be.pack(x, _capi.PACK_F16)
+    del x
+kw = dict(backend=be, packed=pk, max_points_per_centroid=None, final_assign=False, bounds=False)
 kmeans(None, 1024, niter=1, **kw); be.synchronize()
 t0 = time.perf_counter(); kmeans(None, 1024, niter=5, **kw); be.synchronize()
-print(f"5 iterations: {(time.perf_counter() - t0) * 1e3:.1f} ms", flush=True)
+print(f"5 iterations (exhaustive): {(time.perf_counter() - t0) * 1e3:.1f} ms", flush=True)
+if "both" in sys.argv[1:]:
+    for b in (False, True):
+        for niter in (2, 6, 2, 6, 12):
+            st = {}
+            be.synchronize(); t0 = time.perf_counter()
+            kmeans(None, 1024, niter=niter, **dict(kw, bounds=b, stats=st)); be.synchronize()
+            print(f"bounds={b} niter={niter}: {(time.perf_counter() - t0) * 1e3:.1f} ms searched {[round(v / n, 3) for v in st.get('searched_rows', [])]}", flush=True)

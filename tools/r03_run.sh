@@ -15,6 +15,8 @@ for w in $what; do
     kmprof) timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kmprof -o km -- python tools/kmeans_iter_workload.py > $out/kmprof.log 2>&1; tail -5 $out/kmprof.log ;;
     sweep) make -C lotus_amd/csrc tuning -j8 > $out/tuning_build.log 2>&1; timeout -k 10 600 python tools/small_batch_sweep.py > $out/small_batch_sweep.log 2>&1; cat $out/small_batch_sweep.log ;;
     sbtrace) timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/sbtrace -o sb -- python tools/small_batch_sweep.py trace > $out/sbtrace.log 2>&1; tail -3 $out/sbtrace.log ;;
+    kmdebug) timeout -k 10 600 python tools/kmeans_bounds_debug.py > $out/kmdebug.log 2>&1; tail -60 $out/kmdebug.log ;;
+    kmtime) timeout -k 10 600 python tools/kmeans_iter_workload.py 10000000 both blobs > $out/kmtime.log 2>&1; tail -20 $out/kmtime.log ;;
     smoke) timeout -k 10 300 python -c 'import __graft_entry__ as g; g.smoke()' > $out/smoke.log 2>&1; tail -3 $out/smoke.log ;;
     *) echo "unknown step $w" ;;
   esac
