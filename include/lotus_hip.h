@@ -249,6 +249,13 @@ int32_t lvs_kmeans_centroid_shift(const float* c_old, const float* c_new, int32_
 int32_t lvs_kmeans_bounds_set(const uint64_t* keys, int32_t key_stride, const float* second, const float* q_norms_sq,
                               const int64_t* positions, int64_t m, const float* corpus_stats, const float* coef5,
                               int64_t id_offset, int32_t* assign, float* ub, float* lb, void* stream);
+/* Rows whose one-pass winner was not certified and that the exact k = 1 search decided: approx_keys [m] = their one-pass keys
+ * (whose bounds lvs_kmeans_bounds_set wrote), exact_keys [m] = the exact search's.  ub is renewed from the exact distance
+ * (+ exact_coef2[0] R |x| + exact_coef2[1] R^2 of float32 rounding); lb is kept when the winner is the same centroid and
+ * otherwise lowered below the distance to the one-pass winner. */
+int32_t lvs_kmeans_bounds_fix(const uint64_t* approx_keys, const uint64_t* exact_keys, const float* q_norms_sq,
+                              const int64_t* positions, int64_t m, const float* corpus_stats, const float* coef5,
+                              const float* exact_coef2, int64_t id_offset, int32_t* assign, float* ub, float* lb, void* stream);
 /* After a centroid update: ub += delta[assign], lb -= largest delta among the other centroids; rows with ub (1 + 1e-5) >= lb
  * (or no assignment yet) are appended to out_idx (order unspecified), *out_count (device uint64, zeroed by the caller) += n. */
 int32_t lvs_kmeans_bounds_step(const int32_t* assign, float* ub, float* lb, const float* delta, const float* top2, int64_t n,

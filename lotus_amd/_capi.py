@@ -65,6 +65,7 @@ SIGNATURES = {
     "lvs_kmeans_update_centroids": (_i32, [_vp, _vp, _i32, _i32, _i64, _vp, _vp, _i32, _vp, _vp, _vp, _vp]),
     "lvs_kmeans_centroid_shift": (_i32, [_vp, _vp, _i32, _i32, _vp, _vp, _vp]),
     "lvs_kmeans_bounds_set": (_i32, [_vp, _i32, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
+    "lvs_kmeans_bounds_fix": (_i32, [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
     "lvs_kmeans_bounds_step": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp]),
     "lvs_rand_perm_host": (_i32, [_i64, _i64, _vp]),
     "lvs_rand_perm_prefix_host": (_i32, [_i64, _i64, _i64, _vp]),

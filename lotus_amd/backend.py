@@ -420,19 +420,17 @@ class HipBackend:
         if n_open:
             sel = idx[:n_open]
             sub = self.gather(queries, sel)
-            if bounds is None or corpus.n < 2:
-                keys[sel] = self.search_keys(corpus, sub, 1, metric, **plain)
-            else:  # exact best AND second best: the uncertified rows get bounds from exact (float32) distances
-                k2 = self.search_keys(corpus, sub, 2, metric, **plain)
-                keys[sel] = k2[:, :1]
+            exact_keys = self.search_keys(corpus, sub, 1, metric, **plain)  # the same exact search with or without bounds
+            if bounds is not None:
                 # float32 rounding of |x|^2 + |c|^2 - 2 x.c (cancellation when the row sits on a centroid): a few ulps of
                 # the largest term - 8e-6 R |x| + 4e-6 R^2; errors proportional to the distance itself are covered by the
                 # relative margin of lvs_kmeans_bounds_step
-                exact = (ctypes.c_float * 5)(0.0, 8e-6, 0.0, 0.0, 4e-6)
-                qn_err = sub.norms
+                exact2 = (ctypes.c_float * 2)(8e-6, 4e-6)
                 pos = sel if b_pos is None else b_pos[sel]
-                self._c("lvs_kmeans_bounds_set", _ptr(k2), 2, None, _ptr(qn_err), _ptr(pos), n_open, _ptr(corpus_stats),
-                        ctypes.addressof(exact), int(id_offset), _ptr(b_assign), _ptr(b_ub), _ptr(b_lb), self._stream())
+                self._c("lvs_kmeans_bounds_fix", _ptr(keys[sel].contiguous()), _ptr(exact_keys), _ptr(sub.norms), _ptr(pos),
+                        n_open, _ptr(corpus_stats), ctypes.addressof(coef5), ctypes.addressof(exact2), int(id_offset),
+                        _ptr(b_assign), _ptr(b_ub), _ptr(b_lb), self._stream())
+            keys[sel] = exact_keys
         if stats is not None:
             stats["uncertified"] = stats.get("uncertified", 0) + n_open
             stats["queries"] = stats.get("queries", 0) + nq

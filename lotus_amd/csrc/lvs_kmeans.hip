@@ -304,26 +304,56 @@ __global__ __launch_bounds__(256) void km_obj_sum_kernel(const double* __restric
     if (threadIdx.x == 0) out[0] = (x2 ? x2[0] : 0.0) + sm[0];
 }
 
-// faiss split_clusters on the device: ONE wave; lane 0 replays std::mt19937(1234) and takes every decision exactly as the
-// host twin (lvs_kmeans_split_clusters_host), all lanes copy / perturb the centroid rows.  hassign (= the counts) is
-// modified in place as faiss does.  Nothing happens - not even the generator's set-up - unless some cluster is empty.
-struct KmMt {
-    uint32_t* mt;
-    int idx;
-    __device__ void seed(uint32_t s) {
-        mt[0] = s;
-        for (int i = 1; i < 624; ++i) mt[i] = 1812433253u * (mt[i - 1] ^ (mt[i - 1] >> 30)) + (uint32_t)i;
-        idx = 624;
-    }
-    __device__ uint32_t next() {
-        if (idx >= 624) {
-            for (int i = 0; i < 624; ++i) {
-                const uint32_t y = (mt[i] & 0x80000000u) | (mt[(i + 1) % 624] & 0x7FFFFFFFu);
-                mt[i] = mt[(i + 397) % 624] ^ (y >> 1) ^ ((y & 1u) ? 0x9908B0DFu : 0u);
-            }
-            idx = 0;
+// faiss split_clusters on the device: ONE wave replays std::mt19937(1234) and takes every decision exactly as the host twin
+// (lvs_kmeans_split_clusters_host); all lanes copy / perturb the centroid rows.  hassign (= the counts) is modified in
+// place as faiss does.  Nothing happens - not even the generator's set-up - unless some cluster is empty.
+//
+// A split walks the clusters cyclically and accepts cluster cj with probability (hassign[cj] - 1) / (n - k): ~k draws per
+// split, 135 000 for the 132 empty clusters of configs[4]'s first iteration.  One thread doing that against global memory
+// took 67 ms; here the 64 lanes test 64 consecutive (draw, cluster) pairs at once - the draws are consumed in faiss's order,
+// the first accepting lane wins and the stream position advances by exactly the draws faiss would have used - with the
+// sizes in LDS and the generator's 624-word state regenerated by all lanes (three dependency-free segments).
+struct KmMtWave {
+    uint32_t* mt;  // [624] in LDS
+    __device__ void seed(uint32_t s, int lane) {
+        if (lane == 0) {
+            mt[0] = s;
+            for (int i = 1; i < 624; ++i) mt[i] = 1812433253u * (mt[i - 1] ^ (mt[i - 1] >> 30)) + (uint32_t)i;
         }
-        uint32_t y = mt[idx++];
+        __builtin_amdgcn_wave_barrier();
+    }
+    __device__ static uint32_t mix(uint32_t a, uint32_t b, uint32_t c) {  // next state word from mt[i], mt[i+1], mt[i+397]
+        const uint32_t y = (a & 0x80000000u) | (b & 0x7FFFFFFFu);
+        return c ^ (y >> 1) ^ ((y & 1u) ? 0x9908B0DFu : 0u);
+    }
+    // the standard in-place twist; word i needs OLD mt[i], mt[i+1] and mt[i+397 mod 624], which is old for i < 227 and already
+    // NEW for i >= 227: segments [0,227), [227,454), [454,623) are each free of internal dependencies, word 623 comes last
+    __device__ void twist(int lane) {
+        for (int base = 0; base < 227; base += 64) {
+            const int i = base + lane;
+            uint32_t v = 0;
+            if (i < 227) v = mix(mt[i], mt[i + 1], mt[i + 397]);
+            __builtin_amdgcn_wave_barrier();
+            if (i < 227) mt[i] = v;
+            __builtin_amdgcn_wave_barrier();
+        }
+        // mt[i + 1] read by word i = 226 was still old when it was computed (all reads of a round precede its writes; rounds
+        // run upwards, and word i only ever reads indices > i or, for i >= 227, the finished new words below i - 226)
+        for (int seg = 227; seg < 623; seg += 227) {
+            const int hi = seg + 227 < 623 ? seg + 227 : 623;
+            for (int base = seg; base < hi; base += 64) {
+                const int i = base + lane;
+                uint32_t v = 0;
+                if (i < hi) v = mix(mt[i], mt[i + 1], mt[i - 227]);
+                __builtin_amdgcn_wave_barrier();
+                if (i < hi) mt[i] = v;
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        if (lane == 0) mt[623] = mix(mt[623], mt[0], mt[396]);
+        __builtin_amdgcn_wave_barrier();
+    }
+    __device__ static uint32_t temper(uint32_t y) {
         y ^= y >> 11;
         y ^= (y << 7) & 0x9D2C5680u;
         y ^= (y << 15) & 0xEFC60000u;
@@ -331,49 +361,82 @@ struct KmMt {
         return y;
     }
 };
+constexpr int KM_SPLIT_LDS_K = 15360;  // cluster sizes kept in LDS up to this k (with the generator's state: < 64 KB); beyond, global memory
 __global__ __launch_bounds__(64) void km_split_kernel(int d, int k, long long n, float* hassign_, float* __restrict__ centroids,
                                                       int* __restrict__ out_nsplit) {
-    __shared__ uint32_t state[624];
+    extern __shared__ uint32_t km_split_smem[];
+    uint32_t* state = km_split_smem;                 // [624] (+ 16 pad)
+    float* hl = (float*)(km_split_smem + 640);       // [k] when k <= KM_SPLIT_LDS_K
     const int lane = threadIdx.x;
-    volatile float* hassign = hassign_;
+    volatile float* hg = hassign_;
+    const bool in_lds = k <= KM_SPLIT_LDS_K;
     bool any = false;
-    for (int c = lane; c < k; c += 64) any |= hassign[c] == 0.f;
+    for (int c = lane; c < k; c += 64) {
+        const float h = hg[c];
+        if (in_lds) hl[c] = h;
+        any |= h == 0.f;
+    }
+    __builtin_amdgcn_wave_barrier();
     if (__builtin_amdgcn_ballot_w64(any) == 0ull || n <= k) {
         if (lane == 0 && out_nsplit) *out_nsplit = 0;
         return;
     }
-    KmMt rng{state, 624};
-    if (lane == 0) rng.seed(1234u);
+    auto H = [&](int c) -> float { return in_lds ? hl[c] : hg[c]; };
+    auto setH = [&](int c, float v) {
+        if (in_lds) hl[c] = v;
+        hg[c] = v;
+    };
+    KmMtWave rng{state};
+    rng.seed(1234u, lane);
+    int idx = 624;  // next unused word of the current state block (624: regenerate first), wave-uniform
     const float EPS = 1.0f / 1024.0f;
+    const float denom = (float)(n - k);
     int nsplit = 0;
     for (int ci = 0; ci < k; ++ci) {
-        int cj = -1;
-        if (lane == 0 && hassign[ci] == 0.f) {
-            // the acceptance probabilities of one round over the clusters sum to 1, so a split takes ~k draws; the cap only
-            // guards the device against counts that do not describe n points (faiss itself would spin forever)
-            long long draws = 0;
-            const long long cap = 4096ll * k + (1ll << 20);
-            for (cj = 0;; cj = (cj + 1) % k) {
-                const float p = (hassign[cj] - 1.0f) / (float)(n - k);
-                const float r = (float)rng.next() / 4294967295.0f;  // faiss rand_float(): mt() / float(mt.max())
-                if (r < p) break;
-                if (++draws > cap) {
-                    cj = -2;
-                    break;
-                }
+        if (H(ci) != 0.f) continue;  // wave-uniform (every lane reads the same word)
+        // walk cj = 0, 1, 2, ... (cyclically) consuming one draw per step until r < p(cj)
+        int cj0 = 0, found = -1;
+        long long draws = 0;
+        // the acceptance probabilities of one round over the clusters sum to 1, so a split takes ~k draws; the cap only
+        // guards the device against counts that do not describe n points (faiss itself would spin forever)
+        const long long cap = 4096ll * k + (1ll << 20);
+        while (found < 0 && draws <= cap) {
+            if (idx >= 624) {
+                rng.twist(lane);
+                idx = 0;
             }
-            if (cj >= 0) {
-                const float half = hassign[cj] / 2;
-                hassign[ci] = half;
-                hassign[cj] = hassign[cj] - half;
+            const int avail = 624 - idx < 64 ? 624 - idx : 64;  // draws this round (one per lane), wave-uniform
+            bool acc = false;
+            if (lane < avail) {
+                const int cj = (cj0 + lane) % k;
+                const float p = (H(cj) - 1.0f) / denom;
+                const float r = (float)KmMtWave::temper(state[idx + lane]) / 4294967295.0f;  // faiss rand_float(): mt() / float(mt.max())
+                acc = r < p;
+            }
+            const u64 m = __builtin_amdgcn_ballot_w64(acc);
+            if (m) {
+                const int w = __ffsll((long long)m) - 1;  // the first accepting step: later draws of this round stay unused
+                found = (cj0 + w) % k;
+                idx += w + 1;
+                draws += w + 1;
+            } else {
+                idx += avail;
+                draws += avail;
+                cj0 = (cj0 + avail) % k;
             }
         }
-        cj = __shfl(cj, 0, 64);
-        if (cj == -2) {  // inconsistent counts: report and stop
+        if (found < 0) {  // inconsistent counts: report and stop
             if (lane == 0 && out_nsplit) *out_nsplit = -1;
             return;
         }
-        if (cj < 0) continue;
+        const int cj = found;
+        if (lane == 0) {
+            const float hj = H(cj);
+            const float half = hj / 2;
+            setH(ci, half);
+            setH(cj, hj - half);
+        }
+        __builtin_amdgcn_wave_barrier();
         float* a = centroids + (long long)ci * d;
         float* b = centroids + (long long)cj * d;
         for (int j = lane; j < d; j += 64) {  // a lane only ever touches its own columns: later splits see these writes
@@ -510,6 +573,33 @@ __global__ __launch_bounds__(256) void km_bounds_set_kernel(const u64* __restric
     ub[row] = sqrtf(d1 + err) * (1.0f + 1e-6f);
     lb[row] = sqrtf(fmaxf(d2 - err, 0.f)) * (1.0f - 1e-6f);
 }
+// rows whose one-pass winner was NOT certified: the exact (k = 1) search decided them.  exact[i] = its key; approx[i] = the
+// one-pass key whose bounds km_bounds_set_kernel has just written for row pos[i].  The upper bound is renewed from the exact
+// distance; the lower bound stays valid as it is when the winner is the same centroid (every other centroid's one-pass score
+// was <= the runner-up's), and otherwise must also stay below the distance to the one-pass winner, now one of "the others".
+__global__ __launch_bounds__(256) void km_bounds_fix_kernel(const u64* __restrict__ approx, const u64* __restrict__ exact,
+                                                            const float* __restrict__ qn, const long long* __restrict__ pos,
+                                                            long long m, const float* __restrict__ stats, float c0, float c1,
+                                                            float c2, float c3, float c4, float e1, float e4, long long id_offset,
+                                                            int* __restrict__ assign, float* __restrict__ ub,
+                                                            float* __restrict__ lb) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    const float R = sqrtf(stats[0]), E = sqrtf(stats[1]);
+    const long long row = pos ? pos[i] : i;
+    const u64 ka = approx[i], ke = exact[i];
+    if (!ke) return;
+    const float qnorm = sqrtf(qn[i]);
+    const float err1 = (c0 * E + c1 * R) * qnorm + c2 + c3 * R + c4 * R * R;  // the one-pass search's error bound
+    const float err2 = e1 * R * qnorm + e4 * R * R;                           // float32 rounding of the exact distance
+    const float d1e = fmaxf(-lvs_unord32((uint32_t)(ke >> 32)), 0.f);
+    assign[row] = (int)((long long)(0xFFFFFFFFu - (uint32_t)(ke & 0xFFFFFFFFull)) - id_offset);
+    ub[row] = sqrtf(d1e + err2) * (1.0f + 1e-6f);
+    if ((uint32_t)ka != (uint32_t)ke) {  // another centroid than the one-pass winner
+        const float d1a = ka ? fmaxf(-lvs_unord32((uint32_t)(ka >> 32)), 0.f) : 0.f;
+        lb[row] = fminf(lb[row], sqrtf(fmaxf(d1a - err1, 0.f)) * (1.0f - 1e-6f));
+    }
+}
 // one iteration later: move the bounds by the centroid shifts and list the rows whose nearest centroid may have changed
 __global__ __launch_bounds__(256) void km_bounds_step_kernel(const int* __restrict__ assign, float* __restrict__ ub,
                                                              float* __restrict__ lb, const float* __restrict__ delta,
@@ -576,6 +666,22 @@ extern "C" int32_t lvs_kmeans_bounds_set(const uint64_t* keys, int32_t key_strid
     return LVS_OK;
 }
 
+extern "C" int32_t lvs_kmeans_bounds_fix(const uint64_t* approx_keys, const uint64_t* exact_keys, const float* q_norms_sq,
+                                         const int64_t* positions, int64_t m, const float* corpus_stats, const float* coef5,
+                                         const float* exact_coef2, int64_t id_offset, int32_t* assign, float* ub, float* lb,
+                                         void* stream) {
+    LVS_REQUIRE(m >= 0, "bad arguments");
+    if (m == 0) return LVS_OK;
+    LVS_REQUIRE(approx_keys && exact_keys && q_norms_sq && corpus_stats && coef5 && exact_coef2 && assign && ub && lb, "NULL buffer");
+    LVS_DEVICE_GUARD(stream);
+    hipLaunchKernelGGL(km_bounds_fix_kernel, dim3((unsigned)lvs_ceil_div(m, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const u64*)approx_keys, (const u64*)exact_keys, q_norms_sq, (const long long*)positions, (long long)m,
+                       corpus_stats, coef5[0], coef5[1], coef5[2], coef5[3], coef5[4], exact_coef2[0], exact_coef2[1],
+                       (long long)id_offset, assign, ub, lb);
+    LVS_HIP_CHECK(hipGetLastError());
+    return LVS_OK;
+}
+
 extern "C" int32_t lvs_kmeans_bounds_step(const int32_t* assign, float* ub, float* lb, const float* delta, const float* top2,
                                           int64_t n, int64_t* out_idx, uint64_t* out_count, void* stream) {
     LVS_REQUIRE(n >= 0, "bad arguments");
@@ -628,7 +734,10 @@ extern "C" int32_t lvs_kmeans_update_centroids(const float* sums, float* counts,
     hipLaunchKernelGGL(km_update_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, st, sums,
                        (const float*)counts, total, d, centroids);
     if (n_train > 0)  // faiss: split_clusters right after compute_centroids; n_train <= 0 skips it (caller splits on the host)
-        hipLaunchKernelGGL(km_split_kernel, dim3(1), dim3(64), 0, st, d, k, (long long)n_train, counts, centroids, out_nsplit);
+    {
+        const size_t lds = (640 + (size_t)(k <= KM_SPLIT_LDS_K ? k : 0)) * 4;
+        hipLaunchKernelGGL(km_split_kernel, dim3(1), dim3(64), lds, st, d, k, (long long)n_train, counts, centroids, out_nsplit);
+    }
     LVS_HIP_CHECK(hipGetLastError());
     if (packed_out) {
         LVS_REQUIRE(norms_out, "norms_out is NULL");

@@ -293,7 +293,8 @@ def test_device_split_replays_faiss_rng(hip_backend):
     be = hip_backend
     rng = np.random.default_rng(4)
     for k, d, n, empties in ((9, 11, 90, [0, 2, 5]), (300, 96, 40_000, list(range(0, 300, 7))), (64, 768, 5000, [63]),
-                             (16, 8, 1000, [])):
+                             (16, 8, 1000, []), (1024, 32, 262_144, list(range(3, 1024, 8))),  # ~130 k draws: many state blocks
+                             (20_000, 4, 2_000_000, [5, 19_999])):                                # sizes beyond the LDS copy
         counts = rng.integers(1, 50, k).astype(np.float32)
         counts[empties] = 0
         sums = rng.standard_normal((k, d)).astype(np.float32) * counts[:, None]

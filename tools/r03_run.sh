@@ -17,6 +17,7 @@ for w in $what; do
     sbtrace) timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/sbtrace -o sb -- python tools/small_batch_sweep.py trace > $out/sbtrace.log 2>&1; tail -3 $out/sbtrace.log ;;
     kmdebug) timeout -k 10 600 python tools/kmeans_bounds_debug.py > $out/kmdebug.log 2>&1; tail -60 $out/kmdebug.log ;;
     kmtime) timeout -k 10 600 python tools/kmeans_iter_workload.py 10000000 both blobs > $out/kmtime.log 2>&1; tail -20 $out/kmtime.log ;;
+    kmtrace) timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kmtrace -o km -- python tools/kmeans_iter_workload.py 10000000 bounds blobs > $out/kmtrace.log 2>&1; grep iterations $out/kmtrace.log ;;
     smoke) timeout -k 10 300 python -c 'import __graft_entry__ as g; g.smoke()' > $out/smoke.log 2>&1; tail -3 $out/smoke.log ;;
     *) echo "unknown step $w" ;;
   esac
