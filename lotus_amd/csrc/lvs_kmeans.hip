@@ -203,19 +203,40 @@ __global__ __launch_bounds__(64) void km_reduce_kernel(const _Float16* __restric
 #pragma unroll
     for (int t = 0; t < 8; ++t) acc[t] = 0.f;
     const _Float16* xc = x + j0;
+    // Batches of U rows, double-buffered: the loads of batch b + 1 (row indices, then the rows) are in flight while batch b
+    // is added - a bucket is one dependent chain of additions, so its time is (batches) x (what a batch cannot overlap).
+    // Without the overlap a batch cost two memory latencies; on configs[4]'s blob rows, where bucket sizes differ by 4 x in
+    // the first iterations, the longest bucket set the kernel's time (4.6 ms instead of the 2.6 ms HBM needs).
+    const uint32_t nfull = (e - b) / U;
     uint32_t p = b;
-    for (; p + U <= e; p += U) {
-        km_half8 hi[U], lo[U];
+    if (nfull) {
+        km_half8 chi[U], clo[U];
+        auto load = [&](km_half8 (&hi)[U], km_half8 (&lo)[U], uint32_t at) {
 #pragma unroll
-        for (int i = 0; i < U; ++i) {
-            const _Float16* row = xc + (long long)rows[p + i] * ld;
-            hi[i] = *(const km_half8*)row;
-            if (SPLIT) lo[i] = *(const km_half8*)(row + dpad);
+            for (int i = 0; i < U; ++i) {
+                const _Float16* row = xc + (long long)rows[at + i] * ld;
+                hi[i] = *(const km_half8*)row;
+                if (SPLIT) lo[i] = *(const km_half8*)(row + dpad);
+            }
+        };
+        load(chi, clo, p);
+        for (uint32_t kb = 1; kb <= nfull; ++kb) {
+            km_half8 nhi[U], nlo[U];
+            const bool more = kb < nfull;
+            if (more) load(nhi, nlo, p + U);
+#pragma unroll
+            for (int i = 0; i < U; ++i)
+#pragma unroll
+                for (int t = 0; t < 8; ++t) acc[t] += SPLIT ? (float)chi[i][t] + (float)clo[i][t] : (float)chi[i][t];
+            if (more) {
+#pragma unroll
+                for (int i = 0; i < U; ++i) {
+                    chi[i] = nhi[i];
+                    if (SPLIT) clo[i] = nlo[i];
+                }
+            }
+            p += U;
         }
-#pragma unroll
-        for (int i = 0; i < U; ++i)
-#pragma unroll
-            for (int t = 0; t < 8; ++t) acc[t] += SPLIT ? (float)hi[i][t] + (float)lo[i][t] : (float)hi[i][t];
     }
     for (; p < e; ++p) {
         const _Float16* row = xc + (long long)rows[p] * ld;
