@@ -342,7 +342,7 @@ def search_legs(ctx, legs):
     # the HBM-bound regime: the literal sem_search issues ONE query per call (sem_search.py:121-122); small sim-joins and the
     # K-doubling loop send a few dozen to a few hundred.  Every corpus byte exactly once = the algorithmic bytes.
     by = corpus.n * int(corpus.rows.shape[1]) * 2.0
-    for nq_small in (1, 32, 64, 128, 256):
+    for nq_small in (1, 32, 64, 96, 128, 192, 256):
         if nq_small > queries.n:
             continue
         qs = be.slice_rows(queries, 0, nq_small)

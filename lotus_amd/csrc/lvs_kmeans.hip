@@ -198,43 +198,37 @@ __global__ __launch_bounds__(64) void km_reduce_kernel(const _Float16* __restric
     const uint32_t b = offsets[c], e = offsets[c + 1];
     if (blockIdx.y == 0 && lane == 0) cnt_out[c] += (float)(e - b);
     if (j0 >= dpad) return;
-    constexpr int U = SPLIT ? 8 : 16;
+    constexpr int U = SPLIT ? 16 : 32;
     float acc[8];
 #pragma unroll
     for (int t = 0; t < 8; ++t) acc[t] = 0.f;
     const _Float16* xc = x + j0;
-    // Batches of U rows, double-buffered: the loads of batch b + 1 (row indices, then the rows) are in flight while batch b
-    // is added - a bucket is one dependent chain of additions, so its time is (batches) x (what a batch cannot overlap).
-    // Without the overlap a batch cost two memory latencies; on configs[4]'s blob rows, where bucket sizes differ by 4 x in
-    // the first iterations, the longest bucket set the kernel's time (4.6 ms instead of the 2.6 ms HBM needs).
+    // A bucket is one dependent chain of additions, and a batch of U rows costs what it cannot overlap: a memory latency.
+    // So: many rows per batch (U x 16 B in flight per lane), and the row NUMBERS of the next batch are fetched while this
+    // batch is added (they are wave-uniform: scalar loads), so that a batch waits for one latency, not two.  On configs[4]'s
+    // blob rows, where bucket sizes differ by 4 x in the first iterations, the longest bucket sets the kernel's time.
     const uint32_t nfull = (e - b) / U;
     uint32_t p = b;
     if (nfull) {
-        km_half8 chi[U], clo[U];
-        auto load = [&](km_half8 (&hi)[U], km_half8 (&lo)[U], uint32_t at) {
+        uint32_t idx[U];
+#pragma unroll
+        for (int i = 0; i < U; ++i) idx[i] = rows[p + i];
+        for (uint32_t kb = 0; kb < nfull; ++kb) {
+            km_half8 hi[U], lo[U];
 #pragma unroll
             for (int i = 0; i < U; ++i) {
-                const _Float16* row = xc + (long long)rows[at + i] * ld;
+                const _Float16* row = xc + (long long)idx[i] * ld;
                 hi[i] = *(const km_half8*)row;
                 if (SPLIT) lo[i] = *(const km_half8*)(row + dpad);
             }
-        };
-        load(chi, clo, p);
-        for (uint32_t kb = 1; kb <= nfull; ++kb) {
-            km_half8 nhi[U], nlo[U];
-            const bool more = kb < nfull;
-            if (more) load(nhi, nlo, p + U);
+            if (kb + 1 < nfull) {
+#pragma unroll
+                for (int i = 0; i < U; ++i) idx[i] = rows[p + U + i];
+            }
 #pragma unroll
             for (int i = 0; i < U; ++i)
 #pragma unroll
-                for (int t = 0; t < 8; ++t) acc[t] += SPLIT ? (float)chi[i][t] + (float)clo[i][t] : (float)chi[i][t];
-            if (more) {
-#pragma unroll
-                for (int i = 0; i < U; ++i) {
-                    chi[i] = nhi[i];
-                    if (SPLIT) clo[i] = nlo[i];
-                }
-            }
+                for (int t = 0; t < 8; ++t) acc[t] += SPLIT ? (float)hi[i][t] + (float)lo[i][t] : (float)hi[i][t];
             p += U;
         }
     }

@@ -21,7 +21,8 @@
 //     in the tile kernels (corpus = A, queries = B) so that a lane owns one query column and its threshold is a register;
 //   * hits go through the same wave-cooperative sorted insertion into per-query lists (LDS, a.kcap slots per query, one
 //     lock per query because the waves of a workgroup share the queries).  With several queries the thresholds are SEEDED
-//     (lvs_flat_search_keys): the k-th best score of the first ~nb/64 rows, taken from a small score matrix, so that a
+//     (lvs_flat_search_keys): the kernel first runs in SEED mode over a sample of the rows - no lists, every workgroup keeps
+//     the best score per query - and the k-th largest of those per-range maxima is the starting threshold, so that a
 //     workgroup only inserts rows that beat it (~k nb / sample per query over the whole launch) instead of building its
 //     lists from cold (~k (1 + ln(rows / k)) insertions per query AND workgroup - with dozens of queries that, not HBM, set
 //     the time in round 2).  Exact: a threshold taken from real rows never excludes a top-k row.  Thresholds are also
