@@ -7,45 +7,48 @@ merged inside a corpus group (one all-gather of 8-byte keys + ``lvs_merge_keys``
 groups (one all-gather, no merge).  ``gc == world`` is BASELINE's row split, ``gq == world`` the query split.
 
 The total MFMA work is the same for every split; what differs is how far the fused top-k kernel runs below its
-long-stream rate on the per-GPU shape.  Measured on one MI355X (bench.py legs ``node_plan_8gpu`` / ``shard_*``;
-fraction of the dense fp16 MFMA roof, profiles/r03a_bench.json, a box whose 100 k x 1 M launch runs at 44.0 %):
+long-stream rate on the per-GPU shape.  Measured on one MI355X (bench.py legs ``node_plan_8gpu`` / ``shard_*``; fraction
+of the dense fp16 MFMA roof on two boxes of the pool, profiles/r03a_bench.json / profiles/r03j_bench.json, whose
+100 k x 1 M launches run at 44.0 / 44.6 %):
 
-    per-GPU shape at 8 GPUs     1 x 8: 100 k x 125 k  35.8 %      2 x 4: 50 k x 250 k  37.0 %
-                                4 x 2: 25 k x 500 k   36.8 %      8 x 1: 12.5 k x 1 M  36.8 %
-    row split at 4 / 2 GPUs     100 k x 250 k  39.6 %             100 k x 500 k  42.3 %
+    per-GPU shape at 8 GPUs     1 x 8: 100 k x 125 k  35.8 / 37.5 %      2 x 4: 50 k x 250 k  37.0 / 37.4 %
+                                4 x 2: 25 k x 500 k   36.8 / 37.1 %      8 x 1: 12.5 k x 1 M  36.8 / 36.4 %
+    row split at 4 / 2 GPUs     100 k x 250 k  39.6 / 40.1 %             100 k x 500 k  42.3 / 43.0 %
 
-Halving the corpus stream costs threshold events per flop (the top-k slow path: ~ln(N) / N), halving the query count
-costs L2 sharing of a corpus stream and fuller tail rounds; the two penalties are about equal per halving and mildly
-convex, so the balanced splits come out ~3 % ahead of the pure row split (4.81 M vs 4.66 M q/s kernel-side at 8 GPUs) - a
-small but free gain, as long as the larger corpus shard still fits.  The corpus side has to fit: a shard must leave
-room in HBM for the queries and workspaces.
+Halving the corpus stream costs threshold events per flop (the top-k slow path: ~ln(N) / N, mildly convex: 1.6, 4.4, 7.6
+points after 1, 2, 3 halvings); halving the query count costs L2 sharing of a corpus stream and fuller tail rounds (2.7,
+5.7, 7.7 points, mildly concave).  The sums come out within a point of each other - inside the box-to-box spread - so the
+kernel gives no reason to prefer a split, and the tie goes to the one with the most corpus shards: least HBM per GPU, and
+the only split that scales the corpus past one GPU (BASELINE's configuration).  The planner still ranks by the projected
+fraction, so a per-GPU shape that falls off a cliff (a few hundred queries per GPU, a corpus shard of a few tiles) loses.
 """
 from __future__ import annotations
 
 import math
 
-# fraction of the MFMA roof lost after h halvings of the per-GPU corpus stream / query count relative to 100 k x 1 M
+# points of the MFMA roof lost after h halvings of the per-GPU corpus stream / query count relative to 100 k x 1 M
 # (measured, see above; linear interpolation between the points, extrapolated with the last slope)
-_LOSS_PER_HALVING = (0.0, 0.017, 0.044, 0.078, 0.12)
-_BASE_FRAC = 0.44
+_LOSS_ROWS = (0.0, 0.016, 0.044, 0.076, 0.115)
+_LOSS_QUERIES = (0.0, 0.027, 0.057, 0.077, 0.10)
+_BASE_FRAC = 0.443
 _REF_QUERIES, _REF_ROWS = 100_000, 1_000_000
+_TIE = 0.01  # projected fractions closer than this are a tie (box-to-box spread of the measurements)
 HBM_BYTES = 288e9
 
 
-def _loss(halvings: float) -> float:
+def _loss(table, halvings: float) -> float:
     h = max(0.0, halvings)
     i = int(h)
-    t = _LOSS_PER_HALVING
-    if i + 1 < len(t):
-        return t[i] + (h - i) * (t[i + 1] - t[i])
-    return t[-1] + (h - (len(t) - 1)) * (t[-1] - t[-2])
+    if i + 1 < len(table):
+        return table[i] + (h - i) * (table[i + 1] - table[i])
+    return table[-1] + (h - (len(table) - 1)) * (table[-1] - table[-2])
 
 
 def projected_fraction(queries_per_gpu: float, rows_per_gpu: float) -> float:
     """Projected fraction of the MFMA roof of the fused top-k kernel on one GPU's share of a join."""
     hq = math.log2(_REF_QUERIES / max(1.0, queries_per_gpu))
     hn = math.log2(_REF_ROWS / max(1.0, rows_per_gpu))
-    return max(0.05, _BASE_FRAC - _loss(hq) - _loss(hn))
+    return max(0.05, _BASE_FRAC - _loss(_LOSS_QUERIES, hq) - _loss(_LOSS_ROWS, hn))
 
 
 def splits(world: int):
@@ -54,13 +57,16 @@ def splits(world: int):
 
 def pick_split(world: int, nq: int = _REF_QUERIES, nb: int = _REF_ROWS, d: int = 768, bytes_per_value: int = 2,
                hbm_bytes: float = HBM_BYTES):
-    """-> (gq, gc) with the best projected node throughput among the splits whose corpus shard fits one GPU's HBM
-    (a shard may take at most 60 % of it).  Ties go to the split with more corpus shards (less HBM per GPU)."""
-    best, best_f = (1, world), -1.0
+    """-> (gq, gc): the split with the best projected node throughput among those whose corpus shard fits one GPU's HBM
+    (a shard may take at most 60 % of it); projections within a point of the best are a tie, which goes to the split
+    with the most corpus shards (least HBM per GPU)."""
+    cands = []
     for gq, gc in splits(world):
         if (nb / gc) * d * bytes_per_value > 0.6 * hbm_bytes:
             continue
-        f = projected_fraction(nq / gq, nb / gc)
-        if f > best_f + 1e-9 or (abs(f - best_f) <= 1e-9 and gc > best[1]):
-            best, best_f = (gq, gc), f
-    return best
+        cands.append((projected_fraction(nq / gq, nb / gc), gq, gc))
+    if not cands:
+        return (1, world)
+    best = max(f for f, _, _ in cands)
+    _, gq, gc = max((c for c in cands if c[0] >= best - _TIE), key=lambda c: c[2])
+    return (gq, gc)

@@ -64,9 +64,9 @@ class HipVS(VS):
             queries; the finished lists are all-gathered, nothing is merged.  ``(gq, gc)`` - the 2-D split: ``gq`` query
             groups x ``gc`` corpus shards (``gq * gc`` = ranks; rank r is in query group r // gc and holds corpus shard
             r % gc): every GPU searches Q / gq queries against N / gc rows, the lists are merged inside a corpus group and
-            concatenated across the query groups.  ``"auto"`` - ``lotus_amd.plan.pick_split`` chooses (gq, gc) from the
-            per-GPU shapes' measured rates (8 GPUs: 2 x 4 - 50 k x 250 k per GPU at configs[2] - where the fused top-k runs
-            closer to its long-stream rate than on the 100 k x 125 k shards of the pure row split).
+            concatenated across the query groups.  ``"auto"`` - ``lotus_amd.plan.pick_split`` ranks the splits by the
+            per-GPU shapes' measured rates (at configs[2] on 8 GPUs all four splits run within a point of 37 % of the
+            MFMA roof, so the tie goes to the row split: least HBM per GPU).
         normalize: L2-normalise every row and every query on the device while packing (``lvs_pack_rows(normalize=1)``):
             with the inner-product metric this IS cosine similarity whatever the embedder returns.  ``FaissVS`` has no
             such switch - it relies on the RM normalising (``sentence_transformers_rm.py:30,71``) - so the default is off.

@@ -10,7 +10,7 @@
 tag=${1:-prof}
 cd "${GRAFT_REPO_ROOT:-.}"; export TMPDIR=/tmp
 out=gpurun_out/$tag; mkdir -p $out
-python bench.py > $out/bench.json 2> $out/bench.err; tail -c 600 $out/bench.json; echo
+if [ -z "$SKIP_BENCH" ]; then python bench.py > $out/bench.json 2> $out/bench.err; tail -c 600 $out/bench.json; echo; fi
 B="python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-legs --check-sample 0"
 timeout -k 5 200 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_stats -o b -- $B > $out/prof_stats.log 2>&1
 for c in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" \
