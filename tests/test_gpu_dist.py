@@ -20,3 +20,51 @@ def test_2d_split_on_the_hip_backend(tmp_path):
     concatenation across the query groups, k-means and score rows through the corpus sub-group."""
     res = dist_cases.run_2d(tmp_path, "hip")
     dist_cases.check_2d(res, exact=False)
+
+
+def _rccl_worker(port, out_q):
+    import os
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch
+    import torch.distributed as dist
+
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        from lotus_amd import _dist
+
+        dev = torch.device("cuda", 0)
+        keys = torch.arange(12, dtype=torch.int64, device=dev).reshape(4, 3) * (1 << 40)
+        g = _dist.all_gather_rows(keys)  # device tensor straight into RCCL (no host staging under nccl)
+        sums = torch.ones((5, 7), dtype=torch.float32, device=dev)
+        counts = torch.full((5,), 2.0, dtype=torch.float32, device=dev)
+        obj = torch.tensor([3.5], dtype=torch.float64, device=dev)
+        _dist.all_reduce_sum_([sums, counts, obj])
+        _dist.barrier()
+        staged = _dist._staging_device(keys, None)
+        out_q.put((tuple(g.shape), bool(torch.equal(g[0], keys)), g.is_cuda, float(sums.sum()), float(counts.sum()), float(obj.item()),
+                   staged is None))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_transport_branch_runs_on_device_tensors():
+    """The `nccl` (= RCCL) branch of lotus_amd/_dist.py - device tensors handed to the collectives as they are - executed on
+    the one GPU of this box (world size 1: RCCL has no second device here; the 8-GPU run is the driver's).  Covers the API
+    shapes the path uses: all_gather_into_tensor of int64 keys, all-reduce of float32 sums / counts and the float64 objective."""
+    import os
+
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_worker, args=(30500 + os.getpid() % 2000, q))
+    p.start()
+    shape, same, on_gpu, s, c, o, direct = q.get(timeout=300)
+    p.join(60)
+    assert p.exitcode == 0
+    assert shape == (1, 4, 3) and same and on_gpu and direct
+    assert s == 35.0 and c == 10.0 and o == 3.5
