@@ -792,8 +792,7 @@ int make_plan(int64_t nq, int64_t nb, int32_t d, int32_t xb_pack, int32_t xq_pac
     // the small-batch kernel: one k-list per (corpus range, query) written from off_partial onwards, then the per-range best
     // scores of the sample that seeds its thresholds
     if (nq <= LVS_STREAM_MAXQ && k <= LVS_KPASS)
-        off += lvs_stream_parts_bytes(nq, k) + lvs_round_up((int64_t)(nq > 0 ? nq : 1) * (LVS_STREAM_MAXWG + 8) * 4, 256) +
-               lvs_round_up((int64_t)(LVS_STREAM_MAXWG + 8) * 32 * 4, 256);
+        off += lvs_stream_parts_bytes(nq, k) + lvs_round_up((int64_t)(nq > 0 ? nq : 1) * (LVS_STREAM_MAXWG + 8) * 4, 256);
     p.total = off;
     return LVS_OK;
 }
@@ -1204,11 +1203,6 @@ extern "C" int32_t lvs_flat_search_keys(const void* xb, int32_t xb_pack, int64_t
                 LVS_HIP_CHECK(hipGetLastError());
             } else {
                 LVS_HIP_CHECK(hipMemsetAsync(gtau, 0, (size_t)nq * 4, st));
-            }
-            if (groups > 1 && lvs_tune("LVS_STREAM_PACE", 1) != 0) {  // sibling pacing words, behind the seeds: [ranges][4][8]
-                sa.progress = (uint32_t*)((char*)partial + lvs_stream_parts_bytes(nq, k) +
-                                          lvs_round_up((int64_t)nq * (LVS_STREAM_MAXWG + 8) * 4, 256));
-                LVS_HIP_CHECK(hipMemsetAsync(sa.progress, 0, (size_t)(LVS_STREAM_MAXWG + 8) * 32 * 4, st));
             }
             {
                 ScopedKernelTimer timer(st);

@@ -54,20 +54,6 @@ __device__ inline float max16(const f32x16& v) {
 
 }  // namespace
 
-// Pacing of sibling workgroups (G > 1): wave w of every sibling walks the same row blocks.  After each block a wave publishes
-// how many it has finished (one global store) and, if it is ahead of the slowest sibling's same wave by more than
-// LVS_PACE_LAG blocks, sleeps until that sibling has caught up - so that the siblings' reads of a line fall within the time
-// it stays in their XCD's L2 (~4 us of stream) instead of going back to the fabric.  The poll is a SCALAR load (glc: from
-// the L2, not the scalar cache): it waits on lgkmcnt, so the wave's vector loads - the fragment pipeline - stay in flight.
-// Best effort and hang-proof: the wait is bounded; a wave that times out once stops pacing for the rest of the launch.
-__device__ inline uint32_t lvs_sload_glc(const uint32_t* p) {
-    uint32_t v;
-    asm volatile("s_load_dword %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p) : "memory");
-    return v;
-}
-constexpr uint32_t LVS_PACE_LAG = 1;
-constexpr int LVS_PACE_MAX_SPINS = 4000;  // x s_sleep 32 (~2 k cycles): ~4 ms, far beyond any launch of this kernel
-
 // SEED = true: the same scan over a SAMPLE of the rows with a trivial epilogue - every lane keeps the best score it saw, the
 // workgroup writes one value per query (a.seed_out[range][q]) and no lists exist.  lvs_flat_search_keys takes the k-th
 // largest of a query's values as its starting threshold (a valid lower bound of the k-th best score: each value is the
@@ -194,13 +180,6 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void lvs_stream_ker
         }
     }
 
-    bool pace = !SEED && G > 1 && a.progress != nullptr;
-    uint32_t* pace_mine = nullptr;
-    const uint32_t* pace_base = nullptr;
-    if (pace) {
-        pace_base = a.progress + ((size_t)range * 4) * 8 + wave;  // [range][group 0..3][wave 0..7]
-        pace_mine = a.progress + ((size_t)range * 4 + grp) * 8 + wave;
-    }
     for (long long blk = b0 + wave; blk < b1; blk += WAVES) {
         const long long row0 = blk * 32;
         f32x16 acc[NQB];
@@ -346,27 +325,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void lvs_stream_ker
             gord[qb] = gl > gord[qb] ? gl : gord[qb];
             tauf[qb] = fmaxf(tauf[qb], tau_float(gord[qb]));
         }
-        if (pace) {
-            const uint32_t done = (uint32_t)((blk - b0) / WAVES) + 1u;
-            if (lane == 0) __hip_atomic_store(pace_mine, done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            int spins = 0;
-            for (;;) {
-                uint32_t slowest = done;
-                for (int g = 0; g < G; ++g) {
-                    const uint32_t v = lvs_sload_glc(pace_base + g * 8);
-                    slowest = v < slowest ? v : slowest;
-                }
-                if (slowest + LVS_PACE_LAG >= done) break;
-                if (++spins > LVS_PACE_MAX_SPINS) {
-                    pace = false;
-                    break;
-                }
-                __builtin_amdgcn_s_sleep(32);
-            }
-        }
     }
-    if (pace_mine && lane == 0)  // finished (also after a time-out): nobody waits for this wave any more
-        __hip_atomic_store(pace_mine, 0xFFFFFFFFu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if constexpr (SEED) {
         float* red = (float*)lists;  // [WAVES * 2][NQ] (the list area is unused in this mode)
         __syncthreads();

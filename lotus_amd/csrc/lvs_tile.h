@@ -161,7 +161,6 @@ struct LvsStreamArgs {
     const uint32_t* row_ids;
     uint32_t* gtau;  // [nq] zero-initialised, or seeded with a valid lower bound of every query's k-th best score
     u64* out;        // [nparts][nq][k]
-    uint32_t* progress; // nullable: [ranges][4][8] zero-initialised words through which sibling workgroups pace each other
     float* seed_out; // non-NULL: SEED mode - [nparts][nq] best score of every (corpus range, query) instead of lists
     long long nb, ldb, ldq, id_offset;
     int nq, k, metric;

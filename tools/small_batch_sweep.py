@@ -41,11 +41,8 @@ if trace:
 for nq in (1, 2, 8, 32, 64, 96, 128, 160, 192, 256):
     q = be.slice_rows(cq, 0, nq)
     out = []
-    for tag, env in (("stream", {}), ("stream-nopace", {"LVS_STREAM_PACE": "0"}), ("stream-unseeded", {"LVS_STREAM_SEED": "0"}),
-                     ("tile", {"LVS_STREAM_MAXQ_RT": "1"})):
-        if tag == "stream-nopace" and nq <= 96:
-            continue
-        for kk in ("LVS_STREAM_SEED", "LVS_STREAM_MAXQ_RT", "LVS_STREAM_PACE"):
+    for tag, env in (("stream", {}), ("stream-unseeded", {"LVS_STREAM_SEED": "0"}), ("tile", {"LVS_STREAM_MAXQ_RT": "1"})):
+        for kk in ("LVS_STREAM_SEED", "LVS_STREAM_MAXQ_RT"):
             os.environ.pop(kk, None)
         os.environ.update(env)
         kus, wus = run(q)
