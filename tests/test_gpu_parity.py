@@ -543,3 +543,21 @@ def test_pack_validation_flags_non_finite_and_out_of_range_values(hip_backend):
         for mode in (F16, SPLIT):
             with pytest.raises(ValueError, match=what):
                 be.pack(y, mode, check=True)
+
+
+@pytest.mark.parametrize("nq,nb", [(7, 10_001), (1, 4096), (3, 4097), (300, 2049), (2, 300_000), (5, 1)])
+def test_row_ranking_is_a_stable_descending_sort(hip_backend, nq, nb):
+    """lvs_sort_rows_desc (hand-written segmented radix sort): every row ranked best-first, equal scores by ascending id -
+    the total order of the result keys - incl. signed zeros, infinities and heavy ties."""
+    import torch
+
+    be = hip_backend
+    rng = np.random.default_rng(nq * 1000 + nb)
+    sc = rng.standard_normal((nq, nb)).astype(np.float32)
+    sc[:, ::7] = np.round(sc[:, ::7], 1)            # many exact ties
+    if nb > 10:
+        sc[0, 3], sc[0, 4], sc[-1, 5], sc[-1, 6] = 0.0, -0.0, np.inf, -np.inf
+    keys = be.rank_scores(torch.from_numpy(sc).to(be.device), id_offset=11).cpu().numpy().view(np.uint64)
+    ids = np.broadcast_to(np.arange(nb, dtype=np.int64) + 11, sc.shape)
+    ref = np.sort(oracle.pack_keys(sc, ids), axis=1)[:, ::-1]
+    assert np.array_equal(keys, ref)
