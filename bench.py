@@ -284,8 +284,23 @@ def cpu_baseline(np, xb_h, xq_h, sample, k):
                       blas_twin.flat_search_c))
     impls.append((f"oracle/blas_twin.py (torch-CPU: {blas_twin.QUERY_BLOCK} x {blas_twin.DB_BLOCK} MKL sgemm blocks + topk)",
                   blas_twin.flat_search_blas))
+    # the C twin does not scale to every hardware thread of a big host (on 2 x EPYC 9575F: 256 threads 1.0, 128 1.6, 64 2.5
+    # TFLOP/s - two threads of a core evict each other's packed block from the L2): calibrate the thread count on a short
+    # sample and time the best one
+    twin_threads = os.cpu_count() or 1
+    if blas_twin.c_available():
+        blas_twin.flat_search_c(xb32[:65536], xq32[:256], k)
+        best_rate = 0.0
+        for th in sorted({max(1, (os.cpu_count() or 1) // dv) for dv in (1, 2, 4, 8)}):
+            t0 = time.perf_counter()
+            blas_twin.flat_search_c(xb32[:262144], xq32[:1024], k, threads=th)
+            rate = 1.0 / (time.perf_counter() - t0)
+            if rate > best_rate:
+                best_rate, twin_threads = rate, th
     runs = []
     for impl, fn in impls:
+        if fn is blas_twin.flat_search_c:
+            fn = (lambda f, th: (lambda a, b, kk: f(a, b, kk, threads=th)))(fn, twin_threads)
         fn(xb32[:65536], xq32[:256], k)  # thread pool / page warm-up, not timed
         # a slower comparator gets a smaller sample (its rate is what is compared): keep the leg within ~30 s
         ns = sample if not runs else max(256, sample // 8)
