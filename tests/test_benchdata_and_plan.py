@@ -1,0 +1,55 @@
+"""Host-side pieces added in round 3: the regenerable bench inputs (SURVEY.md 8(d) recipe) and the split planner."""
+import numpy as np
+
+import benchdata
+from lotus_amd import plan
+
+
+def test_inputs_are_a_function_of_config_and_block_only(monkeypatch):
+    monkeypatch.setattr(benchdata, "BLOCK_ROWS", 3000)
+    a = benchdata.corpus(3, 7001, 24, threads=1)
+    monkeypatch.setattr(benchdata, "CHUNK_ROWS", 333)      # how a block's draws are split does not change the values
+    b = benchdata.corpus(3, 7001, 24, threads=4)
+    assert a.dtype == np.float16 and np.array_equal(a, b)
+    assert np.array_equal(benchdata.corpus(3, 7001, 24, rows=(2500, 6100)), a[2500:6100])  # a rank's slice: whole blocks drawn
+    assert not np.array_equal(benchdata.corpus(4, 7001, 24)[:100], a[:100])                # another config: another stream
+    assert np.abs(np.linalg.norm(a.astype(np.float32), axis=1) - 1).max() < 2e-3
+    rng = np.random.default_rng(np.random.SeedSequence([benchdata.SEED, 3, 1]))            # block 1 = rows 3000..5999
+    x = rng.standard_normal((3000, 24), dtype=np.float32)
+    x /= np.sqrt(np.einsum("ij,ij->i", x, x))[:, None]
+    assert np.array_equal(a[3000:6000], x.astype(np.float16))
+    q, j = benchdata.queries(3, a, 50)
+    cos = (q.astype(np.float32) * a[j].astype(np.float32)).sum(1)
+    assert cos.min() > 0.5 and np.array_equal(benchdata.queries(3, a, 50)[0], q)
+
+
+def test_planted_duplicates_are_exactly_the_pairs_above_the_threshold():
+    x, plants = benchdata.dedup_rows(4, 6000, 96)
+    n_base, n_dup, n_chain, n_neg = benchdata.dedup_layout(6000)
+    assert n_base + n_dup + n_chain + n_neg == 6000 and len(plants["row"]) == n_dup + n_chain + n_neg
+    assert (plants["src"] < plants["row"]).all()
+    sure, maybe = benchdata.dedup_expected_pairs(x, plants, 0.95)
+    x32 = x.astype(np.float32)
+    S = x32 @ x32.T
+    iu = np.triu_indices(6000, 1)
+    got = set(zip(iu[0][S[iu] > 0.95 + 2e-5].tolist(), iu[1][S[iu] > 0.95 + 2e-5].tolist()))
+    assert got <= (sure | maybe) and sure <= set(zip(iu[0][S[iu] > 0.95 - 2e-5].tolist(), iu[1][S[iu] > 0.95 - 2e-5].tolist()))
+    assert len(sure) >= n_dup + n_chain  # every direct duplicate and every chain link
+
+
+def test_blobs_carry_their_labels():
+    x, lab = benchdata.blobs(5, 5000, 64, 20)
+    c = benchdata.blob_centres(5, 20, 64)
+    assert ((x.astype(np.float32) @ c.T).argmax(1) == lab).mean() > 0.999
+
+
+def test_split_planner():
+    assert plan.splits(8) == [(1, 8), (2, 4), (4, 2), (8, 1)]
+    for w in (1, 2, 4, 8):
+        gq, gc = plan.pick_split(w)
+        assert gq * gc == w
+    assert plan.pick_split(8) == (1, 8)                       # configs[2]: a tie between the splits -> most corpus shards
+    assert plan.pick_split(8, nq=100_000, nb=400_000_000) == (1, 8)   # 614 GB of corpus: only the row split fits
+    assert plan.pick_split(8, nq=1_000_000, nb=8_000)[0] > 1  # a corpus of a few tiles: split the queries instead
+    f = plan.projected_fraction
+    assert f(100_000, 1_000_000) > f(100_000, 125_000) > f(1_000, 125_000)
