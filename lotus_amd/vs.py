@@ -212,25 +212,54 @@ class HipVS(VS):
         is_dev = self._is_device_tensor(vecs)
         dtype = np.float16 if (is_dev and str(vecs.dtype) == "torch.float16") else (np.float32 if is_dev else vecs.dtype)
         mode = self._pack_mode(dtype)
-        exp = "auto"  # fp32-accurate rows are stored as x * 2^e with e chosen from the data (backend.pack); fp16 rows as given
         if world > 1 and mode == _capi.PACK_SPLIT and not self.normalize:
-            # one exponent for every shard (per-shard lists are merged by score): agreed from each rank's first rows.  Every
-            # rank of the corpus group enters the exchange, also one whose shard is empty.
-            from . import _dist
-            import torch
-
-            head = vecs[lo:min(hi, lo + 65536)]
-            head = head.float().cpu().numpy() if is_dev else np.asarray(head, dtype=np.float32)
-            amax = float(max(head.max(initial=0.0), -head.min(initial=0.0)))
-            t = torch.tensor([amax if np.isfinite(amax) else 0.0], dtype=torch.float64)
-            exp = self.backend.exp_for(float(_dist.all_gather_rows(t, self._pg_corpus()).max().item()))
-        packed = self.backend.pack(vecs[lo:hi], mode, normalize=self.normalize, exp=exp, check=True)
+            packed = self._pack_shard_agreed(vecs, lo, hi, mode, is_dev)
+        else:  # fp32-accurate rows are stored as x * 2^e with e chosen from the data (backend.pack); fp16 rows as given
+            packed = self.backend.pack(vecs[lo:hi], mode, normalize=self.normalize, exp="auto", check=True)
         ent = _Resident(vecs=stored, packed=packed, n=n, d=d, lo=lo, hi=hi, sig=sig)
         self._resident[index_dir] = ent
         self._resident.move_to_end(index_dir)
         while len(self._resident) > self._max_resident:
             self._resident.popitem(last=False)
         return ent
+
+    _EXP_HEAD_ROWS = 65536  # rows per shard the agreed exponent is sampled from
+
+    def _pack_shard_agreed(self, vecs, lo: int, hi: int, mode: int, is_dev: bool):
+        """Pack rows [lo, hi) of a row-sharded fp32-accurate index with ONE power-of-two scale for every shard (per-shard
+        lists are merged by score).  The exponent is agreed from each rank's first rows (one tiny all-gather) and has 500x
+        headroom; should some later row of some shard still leave fp16's range under it, every rank packs with the
+        exponent of its own true maximum and the smallest of them is adopted.  Every rank of the corpus group enters every
+        exchange, also one whose shard is empty - the decisions are taken from gathered values only."""
+        import torch
+        from . import _dist
+
+        be, pg = self.backend, self._pg_corpus()
+
+        def gathered(values):
+            t = torch.tensor([float(v) for v in values], dtype=torch.float64)
+            return _dist.all_gather_rows(t, pg).numpy()
+
+        head = vecs[lo:min(hi, lo + self._EXP_HEAD_ROWS)]
+        head = head.float().cpu().numpy() if is_dev else np.asarray(head, dtype=np.float32)
+        amax = float(max(head.max(initial=0.0), -head.min(initial=0.0)))
+        exp = be.exp_for(float(gathered([amax if np.isfinite(amax) else 0.0]).max()))
+        packed = be.pack(vecs[lo:hi], mode, exp=exp, check="lazy")
+        flags = gathered([int(packed.flags.item())]).astype(np.int64).reshape(-1)
+        f = int(np.bitwise_or.reduce(flags))
+        if f & _capi.PACK_FLAG_RANGE and not f & _capi.PACK_FLAG_NONFINITE:
+            packed = be.pack(vecs[lo:hi], mode, exp="auto", check="lazy")
+            mine = gathered([packed.exp, hi - lo, int(packed.flags.item())]).reshape(-1, 3)
+            f = int(np.bitwise_or.reduce(mine[:, 2].astype(np.int64)))
+            held = mine[mine[:, 1] > 0]
+            exp = int(held[:, 0].min()) if len(held) else 0
+            if not f and len(held) and (held[:, 0] != exp).any():  # decided from gathered values: same on every rank
+                if packed.exp != exp:
+                    packed = be.pack(vecs[lo:hi], mode, exp=exp, check="lazy")
+                f = int(np.bitwise_or.reduce(gathered([int(packed.flags.item())]).astype(np.int64).reshape(-1)))
+        be.raise_for_flags(f)
+        packed.flags = None
+        return packed
 
     def _current(self) -> _Resident:
         if self.index_dir is None or self.index_dir not in self._resident:
@@ -336,8 +365,24 @@ class HipVS(VS):
         # queries share the index's power-of-two scale (required for L2; for inner products it keeps one exponent per
         # index); they are validated while they are packed, the flag word comes back together with the results
         qexp = kwargs.get("_query_exp", ent.packed.exp)
+        if qexp == "auto" and qworld > 1:
+            # the finished lists of all query groups are decoded with ONE score exponent: agree it from the largest magnitude
+            import torch
+            from . import _dist
+
+            amax = be.absmax(q) if (nq and self._is_device_tensor(q)) else float(np.abs(q).max(initial=0.0)) if nq else 0.0
+            t = torch.tensor([amax if np.isfinite(amax) else 0.0], dtype=torch.float64)
+            qexp = be.exp_for(float(_dist.all_gather_rows(t, pg_query).max())) if ent.packed.mode == _capi.PACK_SPLIT else 0
         queries = be.pack(q, ent.packed.mode, normalize=self.normalize, exp=qexp, check="lazy")
         score_exp = be.score_exp_of(ent.packed, queries)
+        flags = getattr(queries, "flags", None)
+        if qworld > 1 and flags is not None:
+            # every query group validates its own slice; the verdict (raise / search again with another exponent - both
+            # collective decisions) must be the same everywhere: OR of the flag words, one tiny all-gather
+            from . import _dist
+
+            g = _dist.all_gather_rows(flags, pg_query)
+            flags = ((g & 1).amax(0) | (g & 2).amax(0)).to(flags.dtype)
         id_map = None
         if rank_all:
             # score rows of this rank's shard, exchanged so that every rank ranks the complete rows (column-sharded
@@ -383,21 +428,18 @@ class HipVS(VS):
             keys = _dist.all_gather_rows(pad, pg_query).reshape(qworld * per, k_eff)[:q_all].contiguous()
             nq = q_all
         Dd, Id = be.keys_to_result(keys, self.metric, id_map, score_exp=score_exp)
-        flags = getattr(queries, "flags", None)
         if return_device and k_eff == K:  # results stay in HBM (torch tensors) for a GPU-side consumer
             if flags is not None:
                 self._check_queries(int(flags.item()), query_vectors, K, ids, kwargs)
             return RMOutput(distances=Dd, indices=Id)
         if hasattr(be, "to_host"):  # all copies in flight together, one synchronisation, pinned-backed result arrays
-            if flags is not None:
-                Dh, Ih, fh = be.to_host(Dd, Id, flags)
-                redo = self._check_queries(int(fh[0]), query_vectors, K, ids, kwargs)
-                if redo is not None:
-                    return redo
-            else:
-                Dh, Ih = be.to_host(Dd, Id)
+            Dh, Ih, *fh = be.to_host(Dd, Id, *([flags] if flags is not None else []))
         else:
-            Dh, Ih = Dd.cpu().numpy(), Id.cpu().numpy()
+            Dh, Ih, *fh = [t.cpu().numpy() for t in ((Dd, Id) + ((flags,) if flags is not None else ()))]
+        if fh:
+            redo = self._check_queries(int(fh[0][0]), query_vectors, K, ids, kwargs)
+            if redo is not None:
+                return redo
         if k_eff == K:
             return RMOutput(distances=Dh, indices=Ih)
         D = np.full((nq, K), pad_d, np.float32)  # fewer than K rows exist: faiss pads with -1 / -+FLT_MAX (Appendix A.2)
@@ -409,18 +451,52 @@ class HipVS(VS):
     def _check_queries(self, f: int, query_vectors, K, ids, kwargs):
         """Validation flags of the packed queries (``lvs_pack_rows_checked``).  inf / NaN raise.  Magnitudes that leave
         fp16's range under the INDEX's scale are searched again with an exponent of their own when the metric allows it
-        (inner products; squared L2 needs one scale on both sides) - returns that result, else None."""
+        (inner products; squared L2 needs one scale on both sides): the offending queries on their own, so that the rest
+        of the batch keeps the index's exponent and its full precision - returns that result, else None.  The split is
+        taken from the complete (replicated) query matrix, so every rank of a sharded store makes the same calls."""
         if not f:
             return None
-        if f & _capi.PACK_FLAG_RANGE and not f & _capi.PACK_FLAG_NONFINITE and self.metric == METRIC_INNER_PRODUCT \
-                and "_query_exp" not in kwargs:
-            kw = dict(kwargs)
-            kw["_query_exp"] = "auto"
-            return self.__call__(query_vectors, K, ids, **kw)
-        self.backend.raise_for_flags(f, "query vectors")
-        return None
+        ent = self._current()
+        if not (f & _capi.PACK_FLAG_RANGE and not f & _capi.PACK_FLAG_NONFINITE and self.metric == METRIC_INNER_PRODUCT
+                and "_query_exp" not in kwargs and ent.packed.mode == _capi.PACK_SPLIT):
+            self.backend.raise_for_flags(f, "query vectors")
+            return None
+        q = self._as_matrix(query_vectors, "query_vectors")
+        on_device = self._is_device_tensor(q)
+        big = self._out_of_range_rows(q, ent)
+        kw = dict(kwargs)
+        kw["_query_exp"] = "auto"
+        if big.all() or not big.any():
+            return self.__call__(q, K, ids, **kw)
+        sel_big, sel_rest = np.flatnonzero(big), np.flatnonzero(~big)
+        if on_device:
+            import torch
 
-    def scores(self, query_vectors, ids: list[int] | None = None):
+            pick = lambda sel: q[torch.from_numpy(sel).to(q.device)]
+        else:
+            pick = lambda sel: q[sel]
+        rest = self.__call__(pick(sel_rest), K, ids, **kwargs)
+        own = self.__call__(pick(sel_big), K, ids, **kw)
+        if self._is_device_tensor(rest.distances) or hasattr(rest.distances, "index_copy_"):  # return_device=True
+            import torch
+
+            D = torch.empty((len(big), K), dtype=rest.distances.dtype, device=rest.distances.device)
+            I = torch.empty((len(big), K), dtype=rest.indices.dtype, device=rest.indices.device)
+            for sel, part in ((sel_rest, rest), (sel_big, own)):
+                at = torch.from_numpy(sel).to(D.device)
+                D[at], I[at] = part.distances, part.indices
+            return RMOutput(distances=D, indices=I)
+        D, I = np.empty((len(big), K), np.float32), np.empty((len(big), K), np.int64)
+        D[sel_rest], I[sel_rest] = rest.distances, rest.indices
+        D[sel_big], I[sel_big] = own.distances, own.indices
+        return RMOutput(distances=D, indices=I)
+
+    def _out_of_range_rows(self, q, ent) -> np.ndarray:
+        """bool [nq]: queries with a component beyond fp16's range under the index's power-of-two scale."""
+        rowmax = q.abs().amax(dim=1).float().cpu().numpy() if self._is_device_tensor(q) else np.abs(q).max(axis=1, initial=0.0)
+        return np.asarray(rowmax, dtype=np.float64) * 2.0 ** ent.packed.exp > 65504.0
+
+    def scores(self, query_vectors, ids: list[int] | None = None, _query_exp=None):
         """Similarity of every query to every indexed row (or to rows ``ids``, in that order) as one float32 matrix
         [Q, N] - what the K = N callers actually want (``sem_filter.py:491-497`` takes ``vec_scores`` of ALL rows,
         ``sem_join.py:343-373`` clips them to [0, 1]) without ranking anything.  Inner product:
@@ -439,7 +515,28 @@ class HipVS(VS):
             if sub.size == ent.n and np.array_equal(sub, np.arange(ent.n)):
                 sub = None
         _, world = self._dist()
-        queries = be.pack(q, ent.packed.mode, normalize=self.normalize, exp=ent.packed.exp, check=True)
+        queries = be.pack(q, ent.packed.mode, normalize=self.normalize,
+                          exp=ent.packed.exp if _query_exp is None else _query_exp, check="lazy")
+        f = int(queries.flags.item()) if getattr(queries, "flags", None) is not None else 0
+        if (f & _capi.PACK_FLAG_RANGE and not f & _capi.PACK_FLAG_NONFINITE and self.metric == METRIC_INNER_PRODUCT
+                and _query_exp is None and ent.packed.mode == _capi.PACK_SPLIT):
+            # magnitudes outside fp16's range under the index's scale: inner products allow those queries an exponent of
+            # their own (the rest of the batch keeps the index's, as in __call__)
+            big = self._out_of_range_rows(q, ent)
+            if big.all() or not big.any():
+                return self.scores(q, ids, _query_exp="auto")
+            if self._is_device_tensor(q):
+                import torch
+
+                pick = lambda sel: q[torch.from_numpy(np.flatnonzero(sel)).to(q.device)]
+            else:
+                pick = lambda sel: q[sel]
+            rest, own = self.scores(pick(~big), ids), self.scores(pick(big), ids, _query_exp="auto")
+            out = np.empty((len(big), rest.shape[1]), np.float32)
+            out[~big], out[big] = rest, own
+            return out
+        if f:
+            be.raise_for_flags(f, "query vectors")
         sc, order = self._score_rows(ent, queries, sub, world, want_ids=False)
         out = sc.cpu().numpy()
         if order is not None:  # columns arrived shard by shard: put them back into the order of `ids`

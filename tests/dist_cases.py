@@ -338,3 +338,122 @@ def check_2d(res, exact: bool):
     for r in res:  # k-means runs inside a corpus group (2 shards); the two query groups repeat it
         c, a, o = r["km"]
         assert np.allclose(c, one.centroids, atol=2e-5) and (a == one.assign).mean() >= 0.999 and np.allclose(o, one.obj, rtol=1e-5)
+
+
+# ---- fp32 rows whose magnitudes differ per shard; query validation under the query split (2 ranks) ---------------------
+SC_N, SC_D = 2000, 48
+
+
+def scale_data():
+    rng = np.random.default_rng(31)
+    xb = rng.standard_normal((SC_N, SC_D)).astype(np.float32)
+    xb[:1000] *= 0.05   # shard 0
+    xb[1000:] *= 40.0   # shard 1
+    xb[1900] *= 3000.0  # far beyond the headroom of the exponent agreed from the shards' first rows (4 in this scenario)
+    xq = rng.standard_normal((10, SC_D)).astype(np.float32)
+    xq[7] *= 1.0e7      # leaves fp16's range under the index's scale: searched again with an exponent of its own
+    return xb, xq
+
+
+def _backend(backend_kind):
+    if backend_kind == "hip":
+        import torch
+        from lotus_amd.backend import HipBackend
+
+        torch.cuda.set_device(0)
+        return HipBackend("cuda:0")
+    from oracle_backend import OracleBackend
+
+    return OracleBackend()
+
+
+def worker_scale(rank, world, port, tmp, out_q, backend_kind):
+    sys.path.insert(0, os.path.dirname(HERE))
+    sys.path.insert(0, HERE)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch.distributed as dist
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from lotus_amd import HipVS
+
+        be = _backend(backend_kind)
+        xb, xq = scale_data()
+        res = {"rank": rank}
+        HipVS._EXP_HEAD_ROWS = 4
+        vs = HipVS(backend=be, shard=True)
+        vs.index(None, xb, os.path.join(tmp, "sc"), persist=False)
+        res["exp"] = vs._resident[vs.index_dir].packed.exp
+        out = vs(xq[:6], 5)
+        res["rows"] = (np.asarray(out.distances), np.asarray(out.indices))
+        vq = HipVS(backend=be, shard="queries")
+        vq.index(None, xb[:1000], os.path.join(tmp, "scq"), persist=False)
+        out = vq(xq, 5)  # the out-of-range query sits in rank 1's slice; both ranks must take the retry
+        res["queries"] = (np.asarray(out.distances), np.asarray(out.indices))
+        bad = xq.copy()
+        bad[2, 3] = np.nan  # rank 0's slice
+        try:
+            vq(bad, 5)
+            res["nan"] = "no error"
+        except ValueError as e:
+            res["nan"] = str(e)
+        bad = xb.copy()
+        bad[1500, 0] = np.inf  # rank 1's shard
+        try:
+            HipVS(backend=be, shard=True).index(None, bad, os.path.join(tmp, "scbad"), persist=False)
+            res["inf"] = "no error"
+        except ValueError as e:
+            res["inf"] = str(e)
+        out_q.put(res)
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def run_scale(tmp, backend_kind):
+    import torch.multiprocessing as mp
+
+    world = 2
+    port = 33500 + (os.getpid() % 2000) + (7 if backend_kind == "hip" else 0)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=worker_scale, args=(r, world, port, str(tmp), q, backend_kind)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=600) for _ in range(world)], key=lambda t: t["rank"])
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    return res
+
+
+def check_scale(res, exact: bool):
+    import synth
+    from lotus_amd import HipVS
+    from oracle_backend import OracleBackend
+
+    xb, xq = scale_data()
+    one = HipVS(backend=OracleBackend())  # the same rows on one rank: the exponent of the true maximum
+    one.index(None, xb, "unused", persist=False)
+    want_exp = one._resident[one.index_dir].packed.exp
+    ref_rows = one(xq[:6], 5)
+    one.index(None, xb[:1000], "unused2", persist=False)
+    ref_q = one(xq, 5)
+
+    def same(got, ref):
+        D, I = got
+        Dr, Ir = np.asarray(ref.distances), np.asarray(ref.indices)
+        if exact:
+            assert np.array_equal(I, Ir) and np.array_equal(D, Dr)
+        else:
+            scale = np.abs(Dr).max(axis=1, keepdims=True)
+            err, hard, recall = synth.compare_topk(Dr / scale, Ir, D / scale, I, atol=1e-5)
+            assert err <= 1e-5 and hard == 0 and recall >= 0.999, (err, hard, recall)
+
+    for r in res:
+        assert r["exp"] == want_exp, (r["exp"], want_exp)  # re-agreed after the outlier row: the exponent of the true maximum
+        same(r["rows"], ref_rows)
+        same(r["queries"], ref_q)
+        assert "inf or NaN" in r["nan"] and "inf or NaN" in r["inf"], (r["nan"], r["inf"])

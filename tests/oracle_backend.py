@@ -36,26 +36,61 @@ class OracleBackend:
     def to_device(self, arr):
         return torch.from_numpy(np.ascontiguousarray(arr))
 
+    SCALE_TARGET_EXP = 6
+
+    @staticmethod
+    def absmax(x) -> float:
+        x = x.numpy() if torch.is_tensor(x) else np.asarray(x)
+        return float(np.abs(x.astype(np.float32)).max(initial=0.0))
+
+    @classmethod
+    def exp_for(cls, absmax: float) -> int:
+        if not np.isfinite(absmax) or absmax <= 0.0:
+            return 0
+        return int(np.clip(cls.SCALE_TARGET_EXP - int(np.floor(np.log2(absmax))), -60, 60))
+
     def pack(self, x, mode, normalize=False, check=False, exp=0):
+        """As the device: the image holds x * 2^exp ("auto": chosen from the data for hi|lo rows), flags report inf / NaN
+        and magnitudes that leave fp16's range under that scale."""
         x = x.numpy() if torch.is_tensor(x) else np.asarray(x)
         x = x.astype(np.float32)
-        if check:
-            if not np.isfinite(x).all():
-                raise ValueError("embeddings contain inf or NaN")
-            if np.abs(x).max(initial=0.0) > 65504.0:
-                raise ValueError("embedding values exceed fp16's range")
-        if normalize:
-            x = x / np.linalg.norm(x, axis=1, keepdims=True)
-        vals = _emulate_storage(x, mode)
+        if exp == "auto":
+            if mode != _capi.PACK_SPLIT or x.shape[0] == 0:
+                exp = 0
+            elif normalize:
+                exp = self.SCALE_TARGET_EXP + 2
+            else:
+                finite = x[np.isfinite(x)]
+                exp = self.exp_for(self.absmax(finite)) if finite.size else 0
+        exp = int(exp)
+        f = 0
+        if not np.isfinite(x).all():
+            f |= _capi.PACK_FLAG_NONFINITE
+        with np.errstate(all="ignore"):
+            if normalize:
+                x = x / np.linalg.norm(x, axis=1, keepdims=True)
+            x = x * np.float32(2.0 ** exp)
+            if np.abs(np.where(np.isfinite(x), x, 0)).max(initial=0.0) > 65504.0:
+                f |= _capi.PACK_FLAG_RANGE
+            if check is True and f:
+                self.raise_for_flags(f)
+            vals = _emulate_storage(x, mode)
         self.calls.append(("pack", vals.shape, mode))
         norms = np.einsum("ij,ij->i", vals, vals, dtype=np.float32)
         return PackedRows(rows=torch.from_numpy(vals), norms=torch.from_numpy(norms), n=vals.shape[0],
-                          d=vals.shape[1] if vals.ndim == 2 else 0, mode=mode)
+                          d=vals.shape[1] if vals.ndim == 2 else 0, mode=mode, exp=exp,
+                          flags=torch.tensor([f], dtype=torch.int32) if check == "lazy" else None)
+
+    @staticmethod
+    def raise_for_flags(f, what="embeddings"):
+        from lotus_amd.backend import HipBackend
+
+        HipBackend.raise_for_flags(f, what)
 
     def gather(self, src, ids_dev):
         idx = ids_dev.numpy().astype(np.int64)
         self.calls.append(("gather", len(idx)))
-        return PackedRows(rows=src.rows[idx], norms=src.norms[idx], n=len(idx), d=src.d, mode=src.mode)
+        return PackedRows(rows=src.rows[idx], norms=src.norms[idx], n=len(idx), d=src.d, mode=src.mode, exp=src.exp)
 
     def search_keys(self, corpus, queries, k, metric, id_offset=0, row_ids=None, one_pass=None, stats=None):
         self.calls.append(("search", queries.n, corpus.n, k, metric))
@@ -90,18 +125,23 @@ class OracleBackend:
 
     @staticmethod
     def score_exp_of(corpus, queries):
-        return 0
+        return int(corpus.exp) + int(queries.exp)
 
     def keys_to_result(self, keys, metric, id_map=None, score_exp=0):
         k = keys.numpy().view(np.uint64)
         D, I = _finish(k, metric, None if id_map is None else id_map.numpy())
+        if score_exp:
+            D = np.where(I >= 0, D * np.float32(2.0 ** -score_exp), D).astype(np.float32)  # exact; pads stay +-FLT_MAX
         return torch.from_numpy(D), torch.from_numpy(I)
 
     def scores(self, corpus, queries, metric):
         xb, xq = corpus.rows.numpy(), queries.rows.numpy()
+        if metric == 1 and corpus.exp != queries.exp:
+            raise ValueError("squared L2 needs both operands packed with the same scale exponent")
         s = xq @ xb.T
         if metric == 1:
             s = -np.maximum((queries.norms.numpy()[:, None] + corpus.norms.numpy()[None, :]) - 2 * s, 0)
+        s = s.astype(np.float32) * np.float32(2.0 ** -self.score_exp_of(corpus, queries))
         return torch.from_numpy(s.astype(np.float32))
 
     def rank_all(self, corpus, queries, metric, id_offset=0):
@@ -116,11 +156,12 @@ class OracleBackend:
 
     def unpack(self, src, ids_dev=None, raw=False):
         rows = src.rows if ids_dev is None else src.rows[ids_dev.numpy().astype(np.int64)]
-        return rows.clone().to(torch.float32)
+        rows = rows.clone().to(torch.float32)
+        return rows if (raw or not src.exp) else rows * float(2.0 ** -src.exp)
 
     @staticmethod
     def slice_rows(src, r0, r1):
-        return PackedRows(rows=src.rows[r0:r1], norms=src.norms[r0:r1], n=r1 - r0, d=src.d, mode=src.mode)
+        return PackedRows(rows=src.rows[r0:r1], norms=src.norms[r0:r1], n=r1 - r0, d=src.d, mode=src.mode, exp=src.exp)
 
     def kmeans_update_centroids(self, sums, counts, centroids):
         c, sm, cn = centroids.numpy(), sums.numpy(), counts.numpy()
@@ -134,6 +175,7 @@ class OracleBackend:
         s = xq @ xb.T
         if metric == 1:
             s = -np.maximum((queries.norms.numpy()[:, None] + corpus.norms.numpy()[None, :]) - 2 * s, 0)
+        s = (s.astype(np.float32) * np.float32(2.0 ** -self.score_exp_of(corpus, queries))).astype(np.float32)
         q, j = np.nonzero(s > np.float32(threshold))
         keep = ((q // 256) % stride) == phase  # 256-query tiles, as the kernel deals them
         if q_row0 >= 0:
@@ -164,7 +206,8 @@ class OracleBackend:
         out[0] = float(o)
 
     def kmeans_pack_centroids(self, centroids, mode, exp=0):
-        pk = self.pack(centroids, mode)
+        pk = self.pack(centroids, mode)  # centroids live in the points' scaled domain already
+        pk.exp = int(exp)
         return pk, torch.zeros(2)
 
     def kmeans_finish(self, sums, counts, centroids, n_train, mode, nsplit_out=None, exp=0):
@@ -175,7 +218,7 @@ class OracleBackend:
             ns = self.split_clusters(n_train, hs, centroids.numpy())
         if nsplit_out is not None:
             nsplit_out[0] = ns
-        return self.kmeans_pack_centroids(centroids, mode)
+        return self.kmeans_pack_centroids(centroids, mode, exp)
 
     def rand_perm(self, n, seed, m=None):
         perm = oracle.rand_perm(n, seed)

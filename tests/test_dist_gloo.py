@@ -14,3 +14,11 @@ def test_2d_split_on_four_ranks(tmp_path):
     query groups, sub-groups for the k-means / score-row collectives."""
     res = dist_cases.run_2d(tmp_path, "oracle")
     dist_cases.check_2d(res, exact=True)
+
+
+def test_shard_scale_agreement_and_query_validation_consensus(tmp_path):
+    """fp32 rows whose magnitudes differ per shard get ONE pack exponent (re-agreed when a late row exceeds the sampled
+    head's headroom); under the query split a validation verdict reached on one rank's slice (retry with another
+    exponent, or raise) is taken by every rank."""
+    res = dist_cases.run_scale(tmp_path, "oracle")
+    dist_cases.check_scale(res, exact=True)

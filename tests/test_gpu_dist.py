@@ -22,6 +22,13 @@ def test_2d_split_on_the_hip_backend(tmp_path):
     dist_cases.check_2d(res, exact=False)
 
 
+def test_shard_scale_agreement_and_query_validation_on_the_hip_backend(tmp_path):
+    """fp32 rows with per-shard magnitudes: one agreed pack exponent (re-agreed after an outlier row), and the validation
+    verdict of one rank's query slice taken by both ranks - on the real packers / flag words."""
+    res = dist_cases.run_scale(tmp_path, "hip")
+    dist_cases.check_scale(res, exact=False)
+
+
 def _rccl_worker(port, out_q):
     import os
 

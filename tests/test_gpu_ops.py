@@ -266,6 +266,20 @@ def test_non_finite_and_out_of_range_inputs_are_refused_or_rescaled(hip_backend,
     ref = vs(q, 3)
     assert np.array_equal(big.indices, ref.indices)
     assert np.allclose(big.distances, ref.distances * 1e6, rtol=1e-5)
+    # a mixed batch: only the outliers take the retry, the other queries keep the index's exponent and their accuracy
+    mixed = q.copy()
+    mixed[[1, 6]] *= 1e6
+    factor = np.ones((8, 1), np.float32)
+    factor[[1, 6]] = 1e6
+    got = vs(mixed, 3)
+    assert np.array_equal(got.indices, ref.indices) and np.allclose(got.distances, ref.distances * factor, rtol=1e-5)
+    dev = vs(mixed, 3, return_device=True)
+    assert dev.distances.is_cuda and np.array_equal(dev.indices.cpu().numpy(), ref.indices)
+    assert np.allclose(dev.distances.cpu().numpy(), ref.distances * factor, rtol=1e-5)
+    S = vs.scores(mixed)
+    want = (q.astype(np.float64) @ xb.astype(np.float64).T) * factor
+    assert np.abs(S - want).max() <= 1e-5 * factor.max()
+    assert np.abs(S[[0, 2, 3, 4, 5, 7]] - want[[0, 2, 3, 4, 5, 7]]).max() <= 1e-5
     vl2 = HipVS(backend=hip_backend, metric=1)
     vl2.index(None, xb, str(tmp_path / "l2"), persist=False)
     with pytest.raises(ValueError, match="range"):

@@ -225,3 +225,29 @@ def test_k_equals_n_ranking_goes_through_in_query_blocks(tmp_path, monkeypatch):
     Dr, Ir = oracle.flat_search(xb, xb[:50], 2100)
     err, hard, recall = synth.compare_topk(Dr, Ir, out.distances, out.indices)
     assert err <= 1e-5 and hard == 0 and recall == 1.0
+
+
+def test_query_validation_verdicts_on_every_result_path(tmp_path):
+    """Queries are validated while they are packed: magnitudes that leave fp16's range under the index's scale are searched
+    again with an exponent of their own (inner product), inf / NaN raise - from ``__call__`` and from ``scores()``."""
+    rng = np.random.default_rng(12)
+    xb = (0.05 * rng.standard_normal((400, 24))).astype(np.float32)
+    xq = rng.standard_normal((6, 24)).astype(np.float32)
+    xq[4] *= 1.0e7
+    vs = HipVS(backend=OracleBackend())
+    vs.index(None, xb, str(tmp_path / "i"), persist=False)
+    out = vs(xq, 5)
+    Dr, Ir = oracle.flat_search(xb, xq, 5, 0)
+    assert np.array_equal(out.indices[:4], Ir[:4]) and np.array_equal(out.indices[4], Ir[4])
+    assert np.allclose(out.distances, Dr, rtol=2e-5)
+    S = vs.scores(xq)
+    assert np.allclose(S, xq @ xb.T, rtol=1e-4, atol=1e-4 * np.abs(xq @ xb.T).max(axis=1, keepdims=True))
+    bad = xq.copy()
+    bad[1, 2] = np.inf
+    for call in (lambda: vs(bad, 5), lambda: vs.scores(bad)):
+        with pytest.raises(ValueError, match="inf or NaN"):
+            call()
+    l2 = HipVS(metric=METRIC_L2, backend=OracleBackend())
+    l2.index(None, xb, str(tmp_path / "l2"), persist=False)
+    with pytest.raises(ValueError, match="fp16's range"):  # squared L2 needs one scale on both sides: no retry
+        l2(xq, 5)
