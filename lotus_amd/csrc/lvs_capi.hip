@@ -660,8 +660,27 @@ struct Plan {
     int kpass, npass;
     int gq, lead_slabs;
     int v2;  // 1: 256 x 256 geometry (k <= LVS2_KCAP, TOP1 / SCORES / RANGE); 0: 256 x 128 geometry (k > LVS2_KCAP)
-    int64_t off_gtau, off_partial, off_pass, total;
+    int64_t off_gtau, off_partial, off_pass, off_seed, total;
 };
+
+// Launches with few query tiles split the corpus into many slabs that all start at the same time with empty lists: every
+// (query, slab) then pays its own cold start of ~k (1 + ln(slab rows / k)) lock-protected insertions - at 256 queries x 1 M
+// rows that is 0.36 ms of a 1.08 ms launch.  Such launches are SEEDED: LVS_MODE_SEED scores a sample (the first rows of the
+// shard, one tile per workgroup, no lists), one wave per query takes the k-th largest of the per-tile maxima as the
+// starting threshold, and the list launch only inserts rows that beat it.  Exact for the same reason as the small-batch
+// kernel's seeding (every value is a real row's score, computed by the same instructions in the same order as the list
+// mode computes it).  Returns the sample rows (a whole number of tiles, >= k of them) or 0: no seeding.
+#define LVS_TILE_SEED_ROWS 16384
+#define LVS_TILE_SEED_MAXQT 64
+int64_t tile_seed_rows(int64_t nq, int64_t nb, int k) {
+    if (lvs_tune("LVS_TILE_SEED", 1) == 0 || k < 1 || k > LVS_KPASS) return 0;
+    long long maxqt = lvs_tune("LVS_TILE_SEED_MAXQT", LVS_TILE_SEED_MAXQT);  // the workspace holds seeds for this many at most
+    if (maxqt > LVS_TILE_SEED_MAXQT) maxqt = LVS_TILE_SEED_MAXQT;
+    if (lvs_ceil_div(nq, LVS2_BQ) > maxqt) return 0;
+    int64_t s = nb / 16 / LVS_BC * LVS_BC;
+    if (s > LVS_TILE_SEED_ROWS) s = LVS_TILE_SEED_ROWS;
+    return s >= (int64_t)LVS_BC * (k > 8 ? k : 8) ? s : 0;
+}
 
 int make_plan(int64_t nq, int64_t nb, int32_t d, int32_t xb_pack, int32_t xq_pack, int32_t k, Plan& p,
               bool force_v2 = false, int64_t min_slabs = 0, int64_t max_slabs_cap = 0) {
@@ -793,6 +812,9 @@ int make_plan(int64_t nq, int64_t nb, int32_t d, int32_t xb_pack, int32_t xq_pac
     // scores of the sample that seeds its thresholds
     if (nq <= LVS_STREAM_MAXQ && k <= LVS_KPASS)
         off += lvs_stream_parts_bytes(nq, k) + lvs_round_up((int64_t)(nq > 0 ? nq : 1) * (LVS_STREAM_MAXWG + 8) * 4, 256);
+    p.off_seed = off;  // [sample tiles][nq] per-tile best scores of a seeded list launch (tile_seed_rows)
+    if (lvs_ceil_div(nq > 0 ? nq : 1, LVS2_BQ) <= LVS_TILE_SEED_MAXQT)
+        off += lvs_round_up((int64_t)(nq > 0 ? nq : 1) * (LVS_TILE_SEED_ROWS / LVS_BC) * 4, 256);
     p.total = off;
     return LVS_OK;
 }
@@ -1151,7 +1173,11 @@ extern "C" int32_t lvs_flat_search_keys(const void* xb, int32_t xb_pack, int64_t
         int kcap = 0, nqb = 0, groups = 0;
         const bool fits = lvs_stream_plan(nq, k, nqseg * jper, &kcap, &nqb, &groups) > 0;
         const bool want = lvs_tune("LVS_STREAM", 1) != 0 && nq <= lvs_tune("LVS_STREAM_MAXQ_RT", LVS_STREAM_MAXQ);
-        if (want && fits && nb >= 4096) {
+        // several sibling workgroups per corpus range (beyond 96 fp16 queries) leave the HBM-bound regime - the siblings'
+        // re-reads are bound by the fabric behind the L2 (0.45 / 0.70 ms at 128 / 256 queries x 1 M rows) - while the seeded
+        // list kernel runs such batches near its MFMA rate: the stream kernel keeps the single-group batches
+        const bool beyond = groups > lvs_tune("LVS_STREAM_MAXG", 1) && p.npass == 1 && tile_seed_rows(nq, nb, k) > 0;
+        if (want && fits && nb >= 4096 && !beyond) {
             LvsStreamArgs sa;
             memset(&sa, 0, sizeof(sa));
             sa.xb = xb;
@@ -1231,7 +1257,27 @@ extern "C" int32_t lvs_flat_search_keys(const void* xb, int32_t xb_pack, int64_t
         // pass > 0: only keys strictly below the last key of the previous pass take part
         a.ub = pass == 0 ? nullptr : (const u64*)out_keys + (col0 - 1);
         a.ub_stride = k;
-        LVS_HIP_CHECK(hipMemsetAsync(gtau, 0, (size_t)nq * 4, st));
+        const int64_t seed_rows = (pass == 0 && p.npass == 1 && !pred && !use_top1) ? tile_seed_rows(nq, nb, kp) : 0;
+        if (seed_rows > 0) {  // few query tiles: thresholds seeded from a sample instead of a cold start in every slab
+            float* seeds = (float*)(ws + p.off_seed);
+            LvsTileArgs sd = a;
+            sd.nb = seed_rows;
+            sd.ntiles = sd.nslab = (int)(seed_rows / LVS_BC);
+            sd.tiles_per_slab = 1;
+            sd.nqt = (int)lvs_ceil_div(nq, LVS2_BQ);
+            sd.bq = LVS2_BQ;
+            sd.gq = 1;
+            sd.lead_slabs = 0;
+            sd.k = 1;
+            sd.ub = nullptr;
+            sd.seed_out = seeds;
+            LVS_HIP_CHECK(lvs_tile_launch(LVS_MODE_SEED, sd, st));
+            hipLaunchKernelGGL(seed_kth_kernel, dim3((unsigned)lvs_ceil_div(nq, 4)), dim3(256), 0, st, (const float*)seeds,
+                               sd.nslab, (long long)nq, kp, gtau);  // writes every gtau[q]
+            LVS_HIP_CHECK(hipGetLastError());
+        } else {
+            LVS_HIP_CHECK(hipMemsetAsync(gtau, 0, (size_t)nq * 4, st));
+        }
         if (pred) {  // predicated fallback pass: not a measurement of the dominant kernel
             LVS_HIP_CHECK(lvs_tile_launch(LVS_MODE_TOPK, a, st));
         } else {

@@ -17,6 +17,7 @@
 #define LVS_MODE_RANGE 3
 #define LVS_MODE_COLLECT 4
 #define LVS_MODE_TOP2 5     // TOP1 + the runner-up score per query (certified nearest-row search, lvs_nearest_hi)
+#define LVS_MODE_SEED 6     // best TOPK-domain score of every (slab, query): seeds the thresholds of a launch with few query tiles
 
 struct LvsTileArgs {
     const void* xb;           // [nb][ld] fp16 packed corpus shard
@@ -29,6 +30,7 @@ struct LvsTileArgs {
     uint32_t* gtau;           // [nq] shared running thresholds (ord32 of the k-th best score), zero-initialised
     u64* out;                 // [nslab][nq][k] per-slab candidate keys
     float* out_second;        // LVS_MODE_TOP2: [nslab][nq] runner-up score ("better" domain) of every slab
+    float* seed_out;          // LVS_MODE_SEED: [nslab][nq] best score of every slab, bit-identical to the score LVS_MODE_TOPK ranks
     float* scores;            // LVS_MODE_SCORES: [nq][ld_scores]
     // LVS_MODE_RANGE: emit (query, corpus row, score) for score > threshold
     long long* pair_q;

@@ -546,7 +546,14 @@ __global__ __launch_bounds__(512, 2) void lvs_tile_kernel(const LvsTileArgs a) {
                         }
                     }
             }
-
+        if constexpr (MODE == LVS_MODE_SEED) {
+            // the scores are the ones the list mode ranks (same K order, same expression): keep the best per lane.  The
+            // caller hands over whole tiles only (nb a multiple of BC), so every score belongs to a real row.
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) bestv[ni] = fmaxf(bestv[ni], max16(acc[mi][ni]));
+        } else {
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni)
             if (qvalid[ni]) {
@@ -726,6 +733,7 @@ __global__ __launch_bounds__(512, 2) void lvs_tile_kernel(const LvsTileArgs a) {
                 if (qvalid[ni] && lane < 32 && wm == 0 && lo > gord[ni]) atomicMax(&a.gtau[q0 + qloc[ni]], lo);
             }
         }
+        }  // TOPK
         }  // MODE
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
@@ -746,6 +754,18 @@ __global__ __launch_bounds__(512, 2) void lvs_tile_kernel(const LvsTileArgs a) {
     }
 #endif
     if constexpr (MODE == LVS_MODE_RANGE || MODE == LVS_MODE_SCORES || MODE == LVS_MODE_COLLECT) return;
+    if constexpr (MODE == LVS_MODE_SEED) {
+        // four lanes (l, l + 32 of waves wm = 0, 1) hold partial maxima of each query
+        float* pmax = (float*)part;
+        __syncthreads();
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) pmax[qloc[ni] * 4 + wm * 2 + (lane >> 5)] = bestv[ni];
+        __syncthreads();
+        if (tid < BQ && q0 + tid < a.nq)
+            a.seed_out[(long long)slab * a.nq + q0 + tid] =
+                fmaxf(fmaxf(pmax[tid * 4], pmax[tid * 4 + 1]), fmaxf(pmax[tid * 4 + 2], pmax[tid * 4 + 3]));
+        return;
+    }
     if constexpr (MODE == LVS_MODE_TOP1 || MODE == LVS_MODE_TOP2) {
         {
             // row from (tile, position: TOP2 carries it in the value's low mantissa bits, TOP1 beside it); score =
@@ -829,5 +849,6 @@ hipError_t lvs_tile_launch(int mode, const LvsTileArgs& a, hipStream_t stream) {
     if (mode == LVS_MODE_RANGE) return launch_one<LVS_MODE_RANGE, 4>(a, stream);
     if (mode == LVS_MODE_SCORES) return launch_one<LVS_MODE_SCORES, 4>(a, stream);
     if (mode == LVS_MODE_COLLECT) return launch_one<LVS_MODE_COLLECT, 4>(a, stream);
+    if (mode == LVS_MODE_SEED) return (a.seed_out && a.nb % LVS_BC == 0) ? launch_one<LVS_MODE_SEED, 4>(a, stream) : hipErrorInvalidValue;
     return launch_one<LVS_MODE_TOPK, 4>(a, stream);
 }

@@ -446,6 +446,39 @@ def test_seeded_streaming_search_with_duplicates_across_the_sample_boundary(hip_
         assert np.abs(D - Dr).max() <= 1e-5
 
 
+@pytest.mark.parametrize("nq,nb,d,k,mode,metric", [
+    (300, 100_000, 128, 10, F16, IP),    # two query tiles, 256-query geometry
+    (300, 70_001, 64, 1, F16, L2),       # k = 1 through the list kernel (long slabs), ragged row count
+    (520, 131_072, 96, 15, F16, L2),     # largest k of the 256-query geometry
+    (260, 150_000, 64, 30, F16, IP),     # 128-query / 56-slot geometry: the sample must hold >= k tiles
+    (400, 250_000, 32, 56, F16, L2),     # largest single-pass k: 56 of the 61 sample tiles set the threshold
+    (1000, 90_000, 200, 10, SPLIT, IP),  # fp32-accurate operands (three K segments in the sample pass too)
+    (3000, 66_000, 64, 5, SPLIT, L2),
+    (130, 400_000, 64, 10, F16, IP),     # <= 256 queries beyond one sibling group: the list kernel, not the stream kernel
+])
+def test_seeded_list_kernel(hip_backend, nq, nb, d, k, mode, metric):
+    """Launches with few query tiles seed their thresholds from a sample (LVS_MODE_SEED + k-th largest per-tile maximum)
+    instead of a cold start in every slab.  Same results as the oracle; rows that tie exactly across the sample boundary,
+    a block of identical rows (their score IS the threshold) and the sample rows themselves all stay candidates."""
+    xb = synth.corpus(nb, d, seed=nb % 83)
+    xb[nb // 2:nb // 2 + 300] = xb[:300]   # duplicates of sample rows inside the main range
+    xb[nb - 200:] = xb[40]                 # 202 identical rows: one in the sample, one mid-range, 200 at the very end
+    xq, _ = synth.queries(xb, nq, seed=29)
+    xq[:8] = xb[[3, 40, 41, 299, nb // 2 + 7, nb - 1, 1000, 17]]
+    if metric == L2:
+        xb, xq = xb * 1.3, xq * 1.3
+    D, I, _ = _run(hip_backend, xb, xq, k, mode, metric)
+    Dr, Ir = oracle.flat_search(_stored(xb, mode), _stored(xq, mode), k, metric)
+    atol = 1e-5 if metric == IP else 4e-5
+    err, hard, recall = synth.compare_topk(Dr, Ir, D, I, atol=atol)
+    assert err <= atol and hard == 0 and recall >= 0.9999, (err, hard, recall)
+    # exact ties come back lowest id first, as the oracle's strict-better insertion leaves them
+    same = np.concatenate([[40, nb // 2 + 40], np.arange(nb - 200, nb)])  # 202 identical rows
+    assert np.array_equal(I[1, :k], same[:k]) and np.array_equal(I[5, :k], same[:k])
+    if k >= 2:
+        assert set(I[0, :2]) == {3, nb // 2 + 3} and I[0, 0] == 3
+
+
 @pytest.mark.parametrize("cmode,qmode,metric,nq,nb,d,k", [
     (SPLIT, SPLIT, IP, 3000, 60_000, 384, 10),   # LOTUS's default: fp32 embeddings on both sides (3 passes -> 1)
     (SPLIT, F16, L2, 2000, 50_000, 200, 5),

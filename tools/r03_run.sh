@@ -8,6 +8,7 @@ for w in $what; do
   case $w in
     pytest) timeout -k 10 1500 python -m pytest tests -m gpu -q --maxfail=25 --timeout 600 --durations=15 -p no:cacheprovider > $out/pytest_gpu.log 2>&1; tail -40 $out/pytest_gpu.log ;;
     opb) timeout -k 10 900 python tools/op_bench.py > $out/op_bench.json 2> $out/op_bench.err; tail -30 $out/op_bench.json ;;
+    pypar) timeout -k 10 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_random_parity.py -m gpu -q --maxfail=10 --timeout 600 --durations=8 -p no:cacheprovider > $out/pytest_par.log 2>&1; tail -25 $out/pytest_par.log ;;
     pykm) timeout -k 10 900 python -m pytest tests/test_gpu_kmeans.py -m gpu -q --timeout 600 -p no:cacheprovider > $out/pytest_km.log 2>&1; tail -15 $out/pytest_km.log ;;
     pyacc) timeout -k 10 600 python -m pytest tests/test_gpu_kmeans.py -m gpu -q -k "accumulate or counting or objective or golden" --timeout 600 -p no:cacheprovider > $out/pytest_acc.log 2>&1; tail -3 $out/pytest_acc.log ;;
     pydur) timeout -k 10 900 python -m pytest tests/test_gpu_dist.py tests/test_gpu_parity.py -m gpu -q -k "rccl or ranking or rank_all or 2d_split" --durations=12 --timeout 600 -p no:cacheprovider > $out/pytest_dur.log 2>&1; tail -25 $out/pytest_dur.log ;;

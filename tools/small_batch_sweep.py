@@ -1,5 +1,5 @@
-"""Small-batch calls (1 .. 256 queries x 1 M rows x 768 fp16, k = 10): stream kernel ms (library HIP events) and wall us per
-call, streaming path vs tile path (TUNING build: LVS_STREAM_MAXQ_RT caps the streaming path), seeded vs unseeded.
+"""Small and medium batches (1 .. 10 000 queries x 1 M rows x 768 fp16, k = 10): main-kernel us (library HIP events) and wall us
+per call of the shipped dispatch against its alternatives (TUNING build knobs), results compared bit for bit.
 Development aid.  usage: python tools/small_batch_sweep.py [rows] [trace]   ("trace": few calls only, for rocprofv3)"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -38,13 +38,28 @@ if trace:
     for nq in (1, 32, 64, 96, 128, 192, 256):
         run(be.slice_rows(cq, 0, nq), reps=5)
     sys.exit(0)
-for nq in (1, 2, 8, 32, 64, 96, 128, 160, 192, 256):
+KNOBS = ("LVS_STREAM_SEED", "LVS_STREAM_MAXQ_RT", "LVS_STREAM_MAXG", "LVS_TILE_SEED")
+VARIANTS = (("shipped", {}),                                    # stream kernel up to one sibling group, seeded list kernel beyond
+            ("stream-siblings", {"LVS_STREAM_MAXG": "4"}),      # round 3's first form: 2-4 sibling groups per corpus range
+            ("list-seeded", {"LVS_STREAM_MAXQ_RT": "1"}),       # the list (tile) kernel with seeded thresholds at every size
+            ("list-cold", {"LVS_STREAM_MAXQ_RT": "1", "LVS_TILE_SEED": "0"}))
+sizes = (1, 32, 64, 96, 128, 160, 192, 256, 512, 1024, 2048, 4096, 10000)
+nmax = max(sizes)
+j = torch.randint(0, nb, (nmax,), generator=g, device=be.device)
+xq = torch.nn.functional.normalize(0.7 * xb[j].float() + 0.7 * torch.nn.functional.normalize(torch.randn((nmax, d), generator=g, device=be.device), dim=1), dim=1).to(torch.float16)
+cq = be.pack(xq, _capi.PACK_F16)
+for nq in sizes:
     q = be.slice_rows(cq, 0, nq)
-    out = []
-    for tag, env in (("stream", {}), ("stream-unseeded", {"LVS_STREAM_SEED": "0"}), ("tile", {"LVS_STREAM_MAXQ_RT": "1"})):
-        for kk in ("LVS_STREAM_SEED", "LVS_STREAM_MAXQ_RT"):
+    out, ref = [], None
+    for tag, env in VARIANTS:
+        for kk in KNOBS:
             os.environ.pop(kk, None)
         os.environ.update(env)
-        kus, wus = run(q)
-        out.append(f"{tag}: kernel {kus:7.1f} wall {wus:7.1f}")
-    print(f"nq={nq:3d} x {nb}: " + "   ".join(out) + "   (us)", flush=True)
+        if nq > 256 and tag == "stream-siblings":
+            continue
+        kus, wus = run(q, reps=20 if nq <= 1024 else 5)
+        keys = be.search_keys(cb, q, k, 0)
+        same = "" if ref is None else (" =" if torch.equal(keys, ref) else " DIFFERENT")
+        ref = keys if ref is None else ref
+        out.append(f"{tag}: kernel {kus:7.1f} wall {wus:7.1f}{same}")
+    print(f"nq={nq:5d} x {nb}: " + "   ".join(out) + "   (us)", flush=True)
