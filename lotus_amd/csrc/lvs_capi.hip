@@ -768,7 +768,10 @@ int make_plan(int64_t nq, int64_t nb, int32_t d, int32_t xb_pack, int32_t xq_pac
     // with the slab count swept (profiles/r02_tuning.md): 100 k x 1 M at 21 slabs 142.8-147.6 ms, 17 140.5-142.4,
     // 13 139.2-139.6.  So among the slab counts near the heuristic's choice (same group shape, slabs not shorter than the
     // heuristic allows) take the one with the smallest estimated time = rounds x (item length + its fixed cost).
-    if (min_slabs == 0 && max_slabs_cap == 0 && (int64_t)p.nqt * s >= 4 * 256 && lvs_tune("LVS_TAIL", 1) != 0) {
+    // (r3: from one full round of items on - launches of a few query tiles run seeded, so an item's fixed cost is the same
+    // two tiles there, and e.g. 256 queries x 1 M rows go from 489 slabs x 8 tiles in two rounds to 245 x 16 in one)
+    if (min_slabs == 0 && max_slabs_cap == 0 && (int64_t)p.nqt * s >= lvs_tune("LVS_TAIL_MIN_ITEMS", 256) &&
+        lvs_tune("LVS_TAIL", 1) != 0) {
         const int64_t lead = p.lead_slabs;
         const int64_t hi_lim = slabs_l2 > 0 ? lead + p.ntiles / lvs_tune("LVS_L2_MIN_TILES", 40) : max_slabs;
         double best_cost = 1e30;
@@ -1288,6 +1291,11 @@ extern "C" int32_t lvs_flat_search_keys(const void* xb, int32_t xb_pack, int64_t
         if (p.npass == 1 && kp == 1) {
             hipLaunchKernelGGL(merge_top1_kernel, dim3((unsigned)lvs_ceil_div(nq, 256)), mblock, 0, st, partial,
                                p.nslab, (long long)nq, (u64*)out_keys, (long long)k);
+        } else if (p.npass == 1 && !pred && p.nslab >= 16 && nq <= 4096) {
+            // few queries, many slabs: one workgroup of 16 waves per query (one wave per query walks hundreds of partial
+            // lists as a chain of dependent loads: 150 us of a 0.5 ms call at 256 queries x 489 slabs)
+            hipLaunchKernelGGL(merge_keys_wide_kernel, dim3((unsigned)nq), dim3(1024), 0, st, partial, p.nslab, (long long)nq,
+                               kp, (u64*)out_keys, (long long)k);
         } else if (p.npass == 1) {
             hipLaunchKernelGGL(merge_keys_kernel, mgrid, mblock, 0, st, partial, p.nslab, (long long)nq, kp,
                                (u64*)out_keys, (long long)k, pred);
