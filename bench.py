@@ -364,7 +364,15 @@ def search_legs(ctx, legs):
         kms, wms, _ = _kernel_leg(ctx, corpus, qs, 20)
         name = "sem_search_1_x_1M" if nq_small == 1 else f"small_batch_{nq_small}_x_1M"
         legs[name] = {"kernel_ms": kms, "ms_per_call": wms, "bound": "hbm", "achieved_gbs": by / (kms * 1e-3) / 1e9,
-                      "frac": by / (kms * 1e-3) / 1e9 / PEAK_HBM_GBS, "algorithmic_bytes_per_launch": by}
+                      "frac": by / (kms * 1e-3) / 1e9 / PEAK_HBM_GBS, "algorithmic_bytes_per_launch": by,
+                      "mfma_frac_secondary": 2.0 * nq_small * corpus.n * ctx["d"] / (kms * 1e-3) / 1e12 / PEAK_FP16_MFMA_TFLOPS}
+    # between the two regimes: a few query tiles x many corpus slabs - the list kernel with thresholds seeded from a sample
+    # (r3; every slab used to start cold)
+    for nq_mid in (512, 1024, 4096):
+        if nq_mid <= queries.n:
+            leg = _mfma_leg(ctx, corpus, be.slice_rows(queries, 0, nq_mid), 10)
+            leg["queries_per_s"] = nq_mid / (leg["ms_per_call"] * 1e-3)
+            legs[f"batch_{nq_mid}_x_1M"] = leg
 
 
 def node_plan_legs(ctx, legs):

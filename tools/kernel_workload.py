@@ -63,11 +63,17 @@ MAIN = ", false>(LvsStreamArgs)"  # the scan itself (the SEED-mode launch over t
 scenario("stream_1q_x_1M_d768", MAIN, lambda: be.search_keys(p1m, be.slice_rows(q100k, 0, 1), 10, IP), 10,
          bytes_per_call=1_000_000 * ld(p1m) * 2)
 for nq_s, note_s in ((32, "one 32-query block per workgroup, thresholds seeded from 32 768 sample rows"),
-                     (64, "two blocks per workgroup (8 waves)"), (96, "three blocks per workgroup"),
-                     (128, "two sibling workgroups per corpus range x 2 blocks: the corpus crosses the fabric twice"),
-                     (192, "two sibling workgroups x 3 blocks"), (256, "three sibling workgroups x 3 blocks")):
+                     (64, "two blocks per workgroup (8 waves)"), (96, "three blocks per workgroup")):
     scenario(f"stream_{nq_s}q_x_1M_d768", MAIN, lambda n_=nq_s: be.search_keys(p1m, be.slice_rows(q100k, 0, n_), 10, IP), 10,
              bytes_per_call=1_000_000 * ld(p1m) * 2, note=note_s)
+# beyond one sibling group (97 .. 256 queries) and up to 64 query tiles: the list kernel with thresholds seeded from a sample
+for nq_s, kern_s, note_s in ((128, "lvs_tile_kernel<0, 2>", "one 128-query tile x 245 slabs, seeded"),
+                             (192, "lvs_tile_kernel<0, 4>", "one 256-query tile (three quarters full) x 245 slabs, seeded"),
+                             (256, "lvs_tile_kernel<0, 4>", "one 256-query tile x 245 slabs, seeded")):
+    scenario(f"list_{nq_s}q_x_1M_d768", kern_s, lambda n_=nq_s: be.search_keys(p1m, be.slice_rows(q100k, 0, n_), 10, IP), 10,
+             bytes_per_call=1_000_000 * ld(p1m) * 2, note=note_s)
+scenario("list_1024q_x_1M_d768", "lvs_tile_kernel<0, 4>", lambda: be.search_keys(p1m, be.slice_rows(q100k, 0, 1024), 10, IP), 5,
+         bound="mfma", flops_per_call=2.0 * 1024 * 1_000_000 * D, note="four query tiles x 127 slabs, seeded")
 scenario("stream_1q_x_4M_d768", MAIN, lambda: be.search_keys(p4m, be.slice_rows(q100k, 0, 1), 10, IP), 10,
          bytes_per_call=N4 * ld(p4m) * 2)
 scenario("stream_32q_x_4M_d768", MAIN, lambda: be.search_keys(p4m, be.slice_rows(q100k, 0, 32), 10, IP), 10,
