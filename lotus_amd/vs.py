@@ -430,7 +430,9 @@ class HipVS(VS):
         Dd, Id = be.keys_to_result(keys, self.metric, id_map, score_exp=score_exp)
         if return_device and k_eff == K:  # results stay in HBM (torch tensors) for a GPU-side consumer
             if flags is not None:
-                self._check_queries(int(flags.item()), query_vectors, K, ids, kwargs)
+                redo = self._check_queries(int(flags.item()), query_vectors, K, ids, kwargs)
+                if redo is not None:
+                    return redo
             return RMOutput(distances=Dd, indices=Id)
         if hasattr(be, "to_host"):  # all copies in flight together, one synchronisation, pinned-backed result arrays
             Dh, Ih, *fh = be.to_host(Dd, Id, *([flags] if flags is not None else []))
