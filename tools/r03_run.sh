@@ -17,6 +17,7 @@ for w in $what; do
     prof) SKIP_BENCH=1 timeout -k 10 1500 tools/profile_bench.sh $tag/prof > $out/prof.log 2>&1; tail -30 $out/prof.log ;;
     kern) timeout -k 10 1500 tools/profile_kernels.sh $tag/kern > $out/kern.log 2>&1; tail -30 $out/kern.log ;;
     kmprof) timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kmprof -o km -- python tools/kmeans_iter_workload.py > $out/kmprof.log 2>&1; tail -5 $out/kmprof.log ;;
+    kmprofb) timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kmprofb -o km -- python tools/kmeans_iter_workload.py 10000000 blobs > $out/kmprofb.log 2>&1; tail -5 $out/kmprofb.log ;;
     sweep) make -C lotus_amd/csrc tuning -j8 > $out/tuning_build.log 2>&1; timeout -k 10 600 python tools/small_batch_sweep.py > $out/small_batch_sweep.log 2>&1; cat $out/small_batch_sweep.log ;;
     sbtrace) timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/sbtrace -o sb -- python tools/small_batch_sweep.py trace > $out/sbtrace.log 2>&1; tail -3 $out/sbtrace.log ;;
     kmdebug) timeout -k 10 600 python tools/kmeans_bounds_debug.py > $out/kmdebug.log 2>&1; tail -60 $out/kmdebug.log ;;
