@@ -183,30 +183,32 @@ __global__ __launch_bounds__(256) void km_scatter_kernel(const KeyT* __restrict_
     }
 }
 
-typedef _Float16 km_half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 km_half4 __attribute__((ext_vector_type(4)));
 
-// grid = (k, ceil(dpad / 512)), one wave per workgroup: lane owns 8 consecutive dimensions of centroid blockIdx.x
-// and walks the bucket in row order, U rows (16-byte loads) in flight at a time.  Per dimension the additions
+// grid = (k, ceil(dpad / 256)), one wave per workgroup: lane owns 4 consecutive dimensions of centroid blockIdx.x
+// and walks the bucket in row order, U rows (8-byte loads) in flight at a time.  Per dimension the additions
 // happen in exactly the bucket (= ascending row) order, so the sums do not depend on U or on the launch shape.
+#define KM_REDUCE_DIMS 256
 template <int SPLIT>
 __global__ __launch_bounds__(64) void km_reduce_kernel(const _Float16* __restrict__ x, long long ld, int d, int dpad,
                                                        const uint32_t* __restrict__ rows,
                                                        const uint32_t* __restrict__ offsets,
                                                        float* __restrict__ sums, float* __restrict__ cnt_out) {
     const int c = blockIdx.x, lane = threadIdx.x;
-    const int j0 = (blockIdx.y * 64 + lane) * 8;
+    const int j0 = (blockIdx.y * 64 + lane) * 4;
     const uint32_t b = offsets[c], e = offsets[c + 1];
     if (blockIdx.y == 0 && lane == 0) cnt_out[c] += (float)(e - b);
     if (j0 >= dpad) return;
-    constexpr int U = SPLIT ? 16 : 32;
-    float acc[8];
+    constexpr int U = SPLIT ? 32 : 64;
+    float acc[4];
 #pragma unroll
-    for (int t = 0; t < 8; ++t) acc[t] = 0.f;
+    for (int t = 0; t < 4; ++t) acc[t] = 0.f;
     const _Float16* xc = x + j0;
     // A bucket is one dependent chain of additions, and a batch of U rows costs what it cannot overlap: a memory latency.
-    // So: many rows per batch (U x 16 B in flight per lane), and the row NUMBERS of the next batch are fetched while this
-    // batch is added (they are wave-uniform: scalar loads), so that a batch waits for one latency, not two.  On configs[4]'s
-    // blob rows, where bucket sizes differ by 4 x in the first iterations, the longest bucket sets the kernel's time.
+    // So: many rows per batch (U x 8 B in flight per lane; four dimensions per lane instead of eight doubled the rows a
+    // batch holds in the same registers), and the row NUMBERS of the next batch are fetched while this batch is added (they
+    // are wave-uniform: scalar loads), so that a batch waits for one latency, not two.  On configs[4]'s blob rows, where
+    // bucket sizes differ by 4 x in the first iterations, the longest bucket sets the kernel's time.
     const uint32_t nfull = (e - b) / U;
     uint32_t p = b;
     if (nfull) {
@@ -214,12 +216,12 @@ __global__ __launch_bounds__(64) void km_reduce_kernel(const _Float16* __restric
 #pragma unroll
         for (int i = 0; i < U; ++i) idx[i] = rows[p + i];
         for (uint32_t kb = 0; kb < nfull; ++kb) {
-            km_half8 hi[U], lo[U];
+            km_half4 hi[U], lo[U];
 #pragma unroll
             for (int i = 0; i < U; ++i) {
                 const _Float16* row = xc + (long long)idx[i] * ld;
-                hi[i] = *(const km_half8*)row;
-                if (SPLIT) lo[i] = *(const km_half8*)(row + dpad);
+                hi[i] = *(const km_half4*)row;
+                if (SPLIT) lo[i] = *(const km_half4*)(row + dpad);
             }
             if (kb + 1 < nfull) {
 #pragma unroll
@@ -228,19 +230,19 @@ __global__ __launch_bounds__(64) void km_reduce_kernel(const _Float16* __restric
 #pragma unroll
             for (int i = 0; i < U; ++i)
 #pragma unroll
-                for (int t = 0; t < 8; ++t) acc[t] += SPLIT ? (float)hi[i][t] + (float)lo[i][t] : (float)hi[i][t];
+                for (int t = 0; t < 4; ++t) acc[t] += SPLIT ? (float)hi[i][t] + (float)lo[i][t] : (float)hi[i][t];
             p += U;
         }
     }
     for (; p < e; ++p) {
         const _Float16* row = xc + (long long)rows[p] * ld;
-        km_half8 h = *(const km_half8*)row, l;
-        if (SPLIT) l = *(const km_half8*)(row + dpad);
+        km_half4 h = *(const km_half4*)row, l;
+        if (SPLIT) l = *(const km_half4*)(row + dpad);
 #pragma unroll
-        for (int t = 0; t < 8; ++t) acc[t] += SPLIT ? (float)h[t] + (float)l[t] : (float)h[t];
+        for (int t = 0; t < 4; ++t) acc[t] += SPLIT ? (float)h[t] + (float)l[t] : (float)h[t];
     }
 #pragma unroll
-    for (int t = 0; t < 8; ++t)
+    for (int t = 0; t < 4; ++t)
         if (j0 + t < d) sums[(long long)c * d + j0 + t] += acc[t];
 }
 
@@ -896,7 +898,7 @@ int32_t km_accumulate(const void* x, int64_t n, int32_t d, int32_t pack_mode, co
     if (rc != LVS_OK) return rc;
     const int dpad = (int)lvs_round_up(d, LVS_BK);
     const long long ld = pack_mode == LVS_PACK_SPLIT ? 2 * dpad : dpad;
-    const dim3 grid((unsigned)k, (unsigned)lvs_ceil_div(dpad, 512));
+    const dim3 grid((unsigned)k, (unsigned)lvs_ceil_div(dpad, KM_REDUCE_DIMS));
     if (pack_mode == LVS_PACK_SPLIT)
         hipLaunchKernelGGL(km_reduce_kernel<1>, grid, dim3(64), 0, st, (const _Float16*)x, ld, d, dpad, rows, offs, sums,
                            counts);
