@@ -76,6 +76,35 @@ def test_accumulate_is_exact_and_in_row_order(hip_backend, mode):
     assert counts[5].item() == 0 and not sums[5].any().item()
 
 
+@pytest.mark.parametrize("mode", [F16, SPLIT])
+def test_accumulate_bucket_sizes_around_the_half_batches(hip_backend, mode):
+    """The sums kernel alternates two half batches of 32 (fp16 rows) / 16 (hi|lo rows) rows with hand-counted waits: buckets
+    of every size around 0 .. 5 half batches (incl. the last bucket of the array, where the row-number prefetch is clamped),
+    d with a partly filled last lane block - bit-identical to in-order float32 sums."""
+    be = hip_backend
+    rng = np.random.default_rng(21)
+    H = 32 if mode == F16 else 16
+    sizes = sorted(set([0, 1, 2, H - 1, H, H + 1, 2 * H - 1, 2 * H, 2 * H + 1, 3 * H - 1, 3 * H, 3 * H + 5, 4 * H, 4 * H + 1,
+                        5 * H + 3, 7 * H, 1000, 1025]))
+    for d in (8, 260, 768):
+        assign = np.repeat(np.arange(len(sizes)), sizes).astype(np.int64)
+        rng.shuffle(assign)
+        n = len(assign)
+        x = (rng.standard_normal((n, d)) * 3).astype(np.float32)
+        pk = be.pack(x.astype(np.float16) if mode == F16 else x, mode)
+        sums, counts = be.kmeans_accumulate(pk, be.to_device(assign), len(sizes))
+        ref = np.zeros((len(sizes), d), np.float32)
+        np.add.at(ref, assign, _stored(x, mode))
+        assert np.array_equal(counts.cpu().numpy(), np.asarray(sizes, np.float32))
+        assert np.array_equal(sums.cpu().numpy(), ref), (mode, d)
+        # the biggest bucket last in the array: its prefetch runs into the clamp
+        order = np.argsort(np.asarray(sizes), kind="stable")
+        remap = np.empty(len(sizes), np.int64)
+        remap[order] = np.arange(len(sizes))
+        sums2, _ = be.kmeans_accumulate(pk, be.to_device(remap[assign]), len(sizes))
+        assert np.array_equal(sums2.cpu().numpy()[remap], ref)
+
+
 def test_host_helpers_match_faiss_restatement(hip_backend):
     be = hip_backend
     for n, seed in ((1, 3), (2, 1234), (1000, 1234), (4097, 1235)):

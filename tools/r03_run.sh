@@ -10,7 +10,7 @@ for w in $what; do
     opb) timeout -k 10 900 python tools/op_bench.py > $out/op_bench.json 2> $out/op_bench.err; tail -30 $out/op_bench.json ;;
     pypar) timeout -k 10 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_random_parity.py -m gpu -q --maxfail=10 --timeout 600 --durations=8 -p no:cacheprovider > $out/pytest_par.log 2>&1; tail -25 $out/pytest_par.log ;;
     pykm) timeout -k 10 900 python -m pytest tests/test_gpu_kmeans.py -m gpu -q --timeout 600 -p no:cacheprovider > $out/pytest_km.log 2>&1; tail -15 $out/pytest_km.log ;;
-    pyacc) timeout -k 10 600 python -m pytest tests/test_gpu_kmeans.py -m gpu -q -k "accumulate or counting or objective or golden" --timeout 600 -p no:cacheprovider > $out/pytest_acc.log 2>&1; tail -3 $out/pytest_acc.log ;;
+    pyacc) timeout -k 10 600 python -m pytest tests/test_gpu_kmeans.py -m gpu -q -k "accumulate or counting or objective or golden or bounds" --timeout 600 -p no:cacheprovider > $out/pytest_acc.log 2>&1; tail -3 $out/pytest_acc.log ;;
     pydur) timeout -k 10 900 python -m pytest tests/test_gpu_dist.py tests/test_gpu_parity.py -m gpu -q -k "rccl or ranking or rank_all or 2d_split" --durations=12 --timeout 600 -p no:cacheprovider > $out/pytest_dur.log 2>&1; tail -25 $out/pytest_dur.log ;;
     bench) timeout -k 10 900 python bench.py > $out/bench.json 2> $out/bench.err; tail -c 1500 $out/bench.json; echo; tail -5 $out/bench.err ;;
     benchq) timeout -k 10 600 python bench.py --dedup-rows 0 --kmeans-rows 0 --no-cpu-baseline > $out/bench_quick.json 2> $out/bench_quick.err; tail -c 1500 $out/bench_quick.json; echo; tail -5 $out/bench_quick.err ;;
