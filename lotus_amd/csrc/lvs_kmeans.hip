@@ -18,7 +18,6 @@
 #include <vector>
 
 #include "lvs_common.h"
-#include <type_traits>
 #include "lvs_tile.h"
 
 namespace {
@@ -184,109 +183,64 @@ __global__ __launch_bounds__(256) void km_scatter_kernel(const KeyT* __restrict_
     }
 }
 
-typedef _Float16 km_half4 __attribute__((ext_vector_type(4)));
+typedef _Float16 km_half8 __attribute__((ext_vector_type(8)));
 
-// grid = (k, ceil(dpad / 256)), one wave per workgroup: lane owns 4 consecutive dimensions of centroid blockIdx.x
-// and walks the bucket in row order, U rows (8-byte loads) in flight at a time.  Per dimension the additions
+// grid = (k, ceil(dpad / 512)), one wave per workgroup: lane owns 8 consecutive dimensions of centroid blockIdx.x
+// and walks the bucket in row order, U rows (16-byte loads) in flight at a time.  Per dimension the additions
 // happen in exactly the bucket (= ascending row) order, so the sums do not depend on U or on the launch shape.
-#define KM_REDUCE_DIMS 256
 template <int SPLIT>
 __global__ __launch_bounds__(64) void km_reduce_kernel(const _Float16* __restrict__ x, long long ld, int d, int dpad,
                                                        const uint32_t* __restrict__ rows,
                                                        const uint32_t* __restrict__ offsets,
                                                        float* __restrict__ sums, float* __restrict__ cnt_out) {
     const int c = blockIdx.x, lane = threadIdx.x;
-    const int j0 = (blockIdx.y * 64 + lane) * 4;
+    const int j0 = (blockIdx.y * 64 + lane) * 8;
     const uint32_t b = offsets[c], e = offsets[c + 1];
     if (blockIdx.y == 0 && lane == 0) cnt_out[c] += (float)(e - b);
     if (j0 >= dpad) return;
-    constexpr int H = SPLIT ? 16 : 32;  // rows per half batch; two half batches are in flight
-    float acc[4];
+    constexpr int U = SPLIT ? 16 : 32;
+    float acc[8];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) acc[t] = 0.f;
+    for (int t = 0; t < 8; ++t) acc[t] = 0.f;
     const _Float16* xc = x + j0;
-    // A bucket is one dependent chain of additions, and what a wave cannot overlap it pays per batch: so two half batches of
-    // H rows (8-byte loads; four dimensions per lane keep 2 x H rows in 128 registers) alternate - while one is added, the
-    // other's loads are in flight (the compiler's vmcnt waits are in issue order) - and the row NUMBERS are wave-uniform scalar
-    // loads.  On configs[4]'s blob rows bucket sizes differ by 3 x, and the longest bucket's chain sets the kernel's time:
-    // single-buffered batches ran it at 6.7 GB/s per wave (tools/km_reduce_probe.py: one 8 x bucket 6.4 ms, blob-like sizes
-    // 4.1 ms against 2.8 ms for equal sizes).
-    const uint32_t nh = (e - b) / H;
-    const unsigned boff = (unsigned)j0 * 2u, boff_lo = ((unsigned)j0 + (unsigned)dpad) * 2u;  // byte offsets inside a row
+    // A bucket is one dependent chain of additions, and a batch of U rows costs what it cannot overlap: a memory latency.
+    // So: many rows per batch (U x 16 B in flight per lane), and the row NUMBERS of the next batch are fetched while this
+    // batch is added (they are wave-uniform: scalar loads), so that a batch waits for one latency, not two.  On configs[4]'s
+    // blob rows, where bucket sizes differ by 4 x in the first iterations, the longest bucket sets the kernel's time.
+    const uint32_t nfull = (e - b) / U;
     uint32_t p = b;
-    if (nh) {
-        km_half4 hA[H], lA[H], hB[H], lB[H];
-        // loads are issued by hand (scalar row base + one per-lane 32-bit byte offset: no address registers per load in
-        // flight; the compiler's own form kept a 64-bit VGPR address per load and serialised on the row-number loads) and
-        // waited for by count: the memory system returns a wave's loads in issue order
-        const uint32_t last = offsets[gridDim.x] - 1u;  // rows[] holds offsets[k] entries
-        uint32_t idx[H];  // row numbers of the half batch issued next: wave-uniform scalar loads, fetched one step ahead
-        auto fetch = [&](uint32_t at) __attribute__((always_inline)) {
+    if (nfull) {
+        uint32_t idx[U];
 #pragma unroll
-            for (int i = 0; i < H; ++i) idx[i] = rows[min(at + (uint32_t)i, last)];  // branch-free: clamped to the array
-        };
-        auto load = [&](km_half4 (&h)[H], km_half4 (&l)[H]) __attribute__((always_inline)) {
+        for (int i = 0; i < U; ++i) idx[i] = rows[p + i];
+        for (uint32_t kb = 0; kb < nfull; ++kb) {
+            km_half8 hi[U], lo[U];
 #pragma unroll
-            for (int i = 0; i < H; ++i) {
-                const _Float16* rowbase = x + (long long)idx[i] * ld;
-                asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(h[i]) : "v"(boff), "s"(rowbase));
-                if (SPLIT) asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(l[i]) : "v"(boff_lo), "s"(rowbase));
+            for (int i = 0; i < U; ++i) {
+                const _Float16* row = xc + (long long)idx[i] * ld;
+                hi[i] = *(const km_half8*)row;
+                if (SPLIT) lo[i] = *(const km_half8*)(row + dpad);
             }
-        };
-        auto add = [&](const km_half4 (&h)[H], const km_half4 (&l)[H]) __attribute__((always_inline)) {
+            if (kb + 1 < nfull) {
 #pragma unroll
-            for (int i = 0; i < H; ++i) {
-#pragma unroll
-                for (int t = 0; t < 4; ++t) acc[t] += SPLIT ? (float)h[i][t] + (float)l[i][t] : (float)h[i][t];
-                // the additions are one dependent chain: without a fence every conversion of the half batch is hoisted
-                // ahead of it (128 live floats)
-                if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+                for (int i = 0; i < U; ++i) idx[i] = rows[p + U + i];
             }
-        };
-        constexpr int INFLIGHT = SPLIT ? 2 * H : H;  // loads of one half batch
-        auto wait = [&](auto n) __attribute__((always_inline)) {  // all but the newest n loads have landed
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(decltype(n)::value) : "memory");
-            __builtin_amdgcn_sched_barrier(0);
-        };
-        using Half = std::integral_constant<int, INFLIGHT>;
-        using None = std::integral_constant<int, 0>;
-        fetch(p);
-        load(hA, lA);
-        fetch(p + H);
-        uint32_t kb = 0;
-        for (; kb + 2 < nh; kb += 2) {  // steady state: A and B alternate, one of them always in flight
-            load(hB, lB);
-            fetch(p + 2 * H);
-            wait(Half{});
-            add(hA, lA);
-            __builtin_amdgcn_sched_barrier(0);
-            load(hA, lA);
-            fetch(p + 3 * H);
-            wait(Half{});
-            add(hB, lB);
-            __builtin_amdgcn_sched_barrier(0);
-            p += 2 * H;
-        }
-        wait(None{});  // one or two half batches left, the first of them in flight (the second reuses its registers)
-        add(hA, lA);
-        __builtin_amdgcn_sched_barrier(0);
-        p += H;
-        if (kb + 1 < nh) {
-            load(hA, lA);
-            wait(None{});
-            add(hA, lA);
-            p += H;
+#pragma unroll
+            for (int i = 0; i < U; ++i)
+#pragma unroll
+                for (int t = 0; t < 8; ++t) acc[t] += SPLIT ? (float)hi[i][t] + (float)lo[i][t] : (float)hi[i][t];
+            p += U;
         }
     }
     for (; p < e; ++p) {
         const _Float16* row = xc + (long long)rows[p] * ld;
-        km_half4 h = *(const km_half4*)row, l;
-        if (SPLIT) l = *(const km_half4*)(row + dpad);
+        km_half8 h = *(const km_half8*)row, l;
+        if (SPLIT) l = *(const km_half8*)(row + dpad);
 #pragma unroll
-        for (int t = 0; t < 4; ++t) acc[t] += SPLIT ? (float)h[t] + (float)l[t] : (float)h[t];
+        for (int t = 0; t < 8; ++t) acc[t] += SPLIT ? (float)h[t] + (float)l[t] : (float)h[t];
     }
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
+    for (int t = 0; t < 8; ++t)
         if (j0 + t < d) sums[(long long)c * d + j0 + t] += acc[t];
 }
 
@@ -942,7 +896,7 @@ int32_t km_accumulate(const void* x, int64_t n, int32_t d, int32_t pack_mode, co
     if (rc != LVS_OK) return rc;
     const int dpad = (int)lvs_round_up(d, LVS_BK);
     const long long ld = pack_mode == LVS_PACK_SPLIT ? 2 * dpad : dpad;
-    const dim3 grid((unsigned)k, (unsigned)lvs_ceil_div(dpad, KM_REDUCE_DIMS));
+    const dim3 grid((unsigned)k, (unsigned)lvs_ceil_div(dpad, 512));
     if (pack_mode == LVS_PACK_SPLIT)
         hipLaunchKernelGGL(km_reduce_kernel<1>, grid, dim3(64), 0, st, (const _Float16*)x, ld, d, dpad, rows, offs, sums,
                            counts);
