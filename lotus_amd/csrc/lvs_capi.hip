@@ -671,14 +671,17 @@ struct Plan {
 // kernel's seeding (every value is a real row's score, computed by the same instructions in the same order as the list
 // mode computes it).  Returns the sample rows (a whole number of tiles, >= k of them) or 0: no seeding.
 #define LVS_TILE_SEED_ROWS 16384
-#define LVS_TILE_SEED_MAXQT 64
+#define LVS_TILE_SEED_MAXQT 64      // shipped: launches of up to this many query tiles are seeded
+#define LVS_TILE_SEED_CAPQT 512     // the workspace holds seeds for this many (tuning builds may raise the limit up to here)
 int64_t tile_seed_rows(int64_t nq, int64_t nb, int k) {
     if (lvs_tune("LVS_TILE_SEED", 1) == 0 || k < 1 || k > LVS_KPASS) return 0;
-    long long maxqt = lvs_tune("LVS_TILE_SEED_MAXQT", LVS_TILE_SEED_MAXQT);  // the workspace holds seeds for this many at most
-    if (maxqt > LVS_TILE_SEED_MAXQT) maxqt = LVS_TILE_SEED_MAXQT;
+    long long maxqt = lvs_tune("LVS_TILE_SEED_MAXQT", LVS_TILE_SEED_MAXQT);
+    if (maxqt > LVS_TILE_SEED_CAPQT) maxqt = LVS_TILE_SEED_CAPQT;
     if (lvs_ceil_div(nq, LVS2_BQ) > maxqt) return 0;
-    int64_t s = nb / 16 / LVS_BC * LVS_BC;
+    int64_t s = nb / lvs_tune("LVS_TILE_SEED_DIV", 16) / LVS_BC * LVS_BC;
     if (s > LVS_TILE_SEED_ROWS) s = LVS_TILE_SEED_ROWS;
+    if (lvs_tune("LVS_TILE_SEED_MIN", 0) != 0 && s < (int64_t)LVS_BC * (k > 8 ? k : 8) && nb >= 16 * (int64_t)LVS_BC * k)
+        s = (int64_t)LVS_BC * (k > 8 ? k : 8);  // tuning aid: the smallest sample that still gives k tile maxima
     return s >= (int64_t)LVS_BC * (k > 8 ? k : 8) ? s : 0;
 }
 
@@ -816,7 +819,7 @@ int make_plan(int64_t nq, int64_t nb, int32_t d, int32_t xb_pack, int32_t xq_pac
     if (nq <= LVS_STREAM_MAXQ && k <= LVS_KPASS)
         off += lvs_stream_parts_bytes(nq, k) + lvs_round_up((int64_t)(nq > 0 ? nq : 1) * (LVS_STREAM_MAXWG + 8) * 4, 256);
     p.off_seed = off;  // [sample tiles][nq] per-tile best scores of a seeded list launch (tile_seed_rows)
-    if (lvs_ceil_div(nq > 0 ? nq : 1, LVS2_BQ) <= LVS_TILE_SEED_MAXQT)
+    if (lvs_ceil_div(nq > 0 ? nq : 1, LVS2_BQ) <= LVS_TILE_SEED_CAPQT)
         off += lvs_round_up((int64_t)(nq > 0 ? nq : 1) * (LVS_TILE_SEED_ROWS / LVS_BC) * 4, 256);
     p.total = off;
     return LVS_OK;
