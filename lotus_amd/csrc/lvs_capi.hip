@@ -663,26 +663,32 @@ struct Plan {
     int64_t off_gtau, off_partial, off_pass, off_seed, total;
 };
 
-// Launches with few query tiles split the corpus into many slabs that all start at the same time with empty lists: every
-// (query, slab) then pays its own cold start of ~k (1 + ln(slab rows / k)) lock-protected insertions - at 256 queries x 1 M
-// rows that is 0.36 ms of a 1.08 ms launch.  Such launches are SEEDED: LVS_MODE_SEED scores a sample (the first rows of the
-// shard, one tile per workgroup, no lists), one wave per query takes the k-th largest of the per-tile maxima as the
-// starting threshold, and the list launch only inserts rows that beat it.  Exact for the same reason as the small-batch
-// kernel's seeding (every value is a real row's score, computed by the same instructions in the same order as the list
-// mode computes it).  Returns the sample rows (a whole number of tiles, >= k of them) or 0: no seeding.
-#define LVS_TILE_SEED_ROWS 16384
-#define LVS_TILE_SEED_MAXQT 64      // shipped: launches of up to this many query tiles are seeded
-#define LVS_TILE_SEED_CAPQT 512     // the workspace holds seeds for this many (tuning builds may raise the limit up to here)
-int64_t tile_seed_rows(int64_t nq, int64_t nb, int k) {
+// Seeded thresholds of a list launch.  A launch cuts the corpus into slabs that run concurrently, and a slab whose queries
+// have no threshold yet pays a cold start of ~k (1 + ln(slab rows / k)) lock-protected insertions per query: with few query
+// tiles EVERY slab starts cold (256 queries x 1 M rows: 0.36 ms of a 1.08 ms launch), with many it is the leading slab of
+// every query tile (100 k x 125 k: 1.3 ms of 21.2).  So LVS_MODE_SEED first scores a sample (the first rows of the shard,
+// one tile per workgroup, no lists), one wave per query takes the k-th largest of the per-tile maxima as the starting
+// threshold, and the list launch only inserts rows that reach it.  Exact for the same reason as the small-batch kernel's
+// seeding: every value is a real row's score, computed by the same instructions in the same order as the list mode
+// computes it, and at least k rows reach the threshold.  Sample size: a sixteenth of the corpus for up to 64 query tiles
+// (the sample pass is negligible there and a tight threshold saves the most), 1 / 128 beyond (it costs MFMA time
+// in proportion to the queries: 100 k x 125 k -4.0 %, 25 k x 500 k -3.9 %, 100 k x 1 M -0.4 .. -1.0 % wall,
+// tools/seed_big_sweep.py); at least max(k, 8) tiles - the threshold is the k-th largest of one maximum per tile - and at
+// most a sixteenth of the corpus and 64 tiles.  Returns the sample tiles or 0: no seeding.
+#define LVS_TILE_SEED_MAXTILES 64
+#define LVS_TILE_SEED_MAXQT 4096  // 2^20 queries: 256 B of seed workspace per query at most
+int tile_seed_tiles(int64_t nq, int64_t nb, int k) {
     if (lvs_tune("LVS_TILE_SEED", 1) == 0 || k < 1 || k > LVS_KPASS) return 0;
+    const int64_t nqt = lvs_ceil_div(nq, LVS2_BQ);
     long long maxqt = lvs_tune("LVS_TILE_SEED_MAXQT", LVS_TILE_SEED_MAXQT);
-    if (maxqt > LVS_TILE_SEED_CAPQT) maxqt = LVS_TILE_SEED_CAPQT;
-    if (lvs_ceil_div(nq, LVS2_BQ) > maxqt) return 0;
-    int64_t s = nb / lvs_tune("LVS_TILE_SEED_DIV", 16) / LVS_BC * LVS_BC;
-    if (s > LVS_TILE_SEED_ROWS) s = LVS_TILE_SEED_ROWS;
-    if (lvs_tune("LVS_TILE_SEED_MIN", 0) != 0 && s < (int64_t)LVS_BC * (k > 8 ? k : 8) && nb >= 16 * (int64_t)LVS_BC * k)
-        s = (int64_t)LVS_BC * (k > 8 ? k : 8);  // tuning aid: the smallest sample that still gives k tile maxima
-    return s >= (int64_t)LVS_BC * (k > 8 ? k : 8) ? s : 0;
+    if (maxqt > LVS_TILE_SEED_MAXQT) maxqt = LVS_TILE_SEED_MAXQT;  // the workspace holds seeds up to here
+    if (nqt > maxqt) return 0;
+    const int64_t kt = k > 8 ? k : 8;
+    if (nb < 16 * (int64_t)LVS_BC * kt) return 0;
+    int64_t tiles = nb / LVS_BC / (nqt <= 64 ? lvs_tune("LVS_TILE_SEED_DIV", 16) : lvs_tune("LVS_TILE_SEED_DIV_BIG", 128));
+    if (tiles < kt) tiles = kt;
+    if (tiles > LVS_TILE_SEED_MAXTILES) tiles = LVS_TILE_SEED_MAXTILES;
+    return (int)tiles;
 }
 
 int make_plan(int64_t nq, int64_t nb, int32_t d, int32_t xb_pack, int32_t xq_pack, int32_t k, Plan& p,
@@ -818,9 +824,8 @@ int make_plan(int64_t nq, int64_t nb, int32_t d, int32_t xb_pack, int32_t xq_pac
     // scores of the sample that seeds its thresholds
     if (nq <= LVS_STREAM_MAXQ && k <= LVS_KPASS)
         off += lvs_stream_parts_bytes(nq, k) + lvs_round_up((int64_t)(nq > 0 ? nq : 1) * (LVS_STREAM_MAXWG + 8) * 4, 256);
-    p.off_seed = off;  // [sample tiles][nq] per-tile best scores of a seeded list launch (tile_seed_rows)
-    if (lvs_ceil_div(nq > 0 ? nq : 1, LVS2_BQ) <= LVS_TILE_SEED_CAPQT)
-        off += lvs_round_up((int64_t)(nq > 0 ? nq : 1) * (LVS_TILE_SEED_ROWS / LVS_BC) * 4, 256);
+    p.off_seed = off;  // [sample tiles][nq] per-tile best scores of a seeded list launch (tile_seed_tiles)
+    if (p.npass == 1) off += lvs_round_up((int64_t)(nq > 0 ? nq : 1) * tile_seed_tiles(nq, nb, k) * 4, 256);
     p.total = off;
     return LVS_OK;
 }
@@ -1182,7 +1187,7 @@ extern "C" int32_t lvs_flat_search_keys(const void* xb, int32_t xb_pack, int64_t
         // several sibling workgroups per corpus range (beyond 96 fp16 queries) leave the HBM-bound regime - the siblings'
         // re-reads are bound by the fabric behind the L2 (0.45 / 0.70 ms at 128 / 256 queries x 1 M rows) - while the seeded
         // list kernel runs such batches near its MFMA rate: the stream kernel keeps the single-group batches
-        const bool beyond = groups > lvs_tune("LVS_STREAM_MAXG", 1) && p.npass == 1 && tile_seed_rows(nq, nb, k) > 0;
+        const bool beyond = groups > lvs_tune("LVS_STREAM_MAXG", 1) && p.npass == 1 && tile_seed_tiles(nq, nb, k) > 0;
         if (want && fits && nb >= 4096 && !beyond) {
             LvsStreamArgs sa;
             memset(&sa, 0, sizeof(sa));
@@ -1263,12 +1268,12 @@ extern "C" int32_t lvs_flat_search_keys(const void* xb, int32_t xb_pack, int64_t
         // pass > 0: only keys strictly below the last key of the previous pass take part
         a.ub = pass == 0 ? nullptr : (const u64*)out_keys + (col0 - 1);
         a.ub_stride = k;
-        const int64_t seed_rows = (pass == 0 && p.npass == 1 && !pred && !use_top1) ? tile_seed_rows(nq, nb, kp) : 0;
-        if (seed_rows > 0) {  // few query tiles: thresholds seeded from a sample instead of a cold start in every slab
+        const int seed_tiles = (pass == 0 && p.npass == 1 && !pred && !use_top1) ? tile_seed_tiles(nq, nb, kp) : 0;
+        if (seed_tiles > 0) {  // thresholds seeded from a sample instead of cold starts (tile_seed_tiles)
             float* seeds = (float*)(ws + p.off_seed);
             LvsTileArgs sd = a;
-            sd.nb = seed_rows;
-            sd.ntiles = sd.nslab = (int)(seed_rows / LVS_BC);
+            sd.nb = (int64_t)seed_tiles * LVS_BC;
+            sd.ntiles = sd.nslab = seed_tiles;
             sd.tiles_per_slab = 1;
             sd.nqt = (int)lvs_ceil_div(nq, LVS2_BQ);
             sd.bq = LVS2_BQ;

@@ -1,5 +1,5 @@
 """Seeded thresholds on BIG list launches (development aid, tuning build): 100 k queries x 125 k / 250 k / 1 M rows and
-25 k x 500 k with the seeding limit raised (LVS_TILE_SEED_MAXQT) and different sample sizes; kernel ms from the library's
+25 k x 500 k unseeded, as shipped, and with other sample sizes; kernel ms from the library's
 HIP events, results compared bit for bit with the unseeded launch.  usage: python tools/seed_big_sweep.py"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -18,11 +18,9 @@ j = torch.randint(0, nb, (nq,), generator=g, device=be.device)
 xq = torch.nn.functional.normalize(0.7 * xb[j].float() + 0.7 * torch.nn.functional.normalize(torch.randn((nq, d), generator=g, device=be.device), dim=1), dim=1).to(torch.float16)
 cb, cq = be.pack(xb, _capi.PACK_F16), be.pack(xq, _capi.PACK_F16)
 del xb, xq
-KNOBS = ("LVS_TILE_SEED_MAXQT", "LVS_TILE_SEED_DIV", "LVS_TILE_SEED_MIN")
-VARIANTS = (("unseeded", {}), ("sample nb/16", {"LVS_TILE_SEED_MAXQT": "512"}),
-            ("sample nb/64", {"LVS_TILE_SEED_MAXQT": "512", "LVS_TILE_SEED_DIV": "64", "LVS_TILE_SEED_MIN": "1"}),
-            ("sample 10 tiles", {"LVS_TILE_SEED_MAXQT": "512", "LVS_TILE_SEED_DIV": "100000", "LVS_TILE_SEED_MIN": "1"}))
-
+KNOBS = ("LVS_TILE_SEED", "LVS_TILE_SEED_DIV_BIG")
+VARIANTS = (("unseeded", {"LVS_TILE_SEED": "0"}), ("shipped (nb/128, >= k tiles)", {}),
+            ("nb/64", {"LVS_TILE_SEED_DIV_BIG": "64"}), ("nb/256", {"LVS_TILE_SEED_DIV_BIG": "256"}))
 
 def run(c, q, reps):
     be.search_keys(c, q, k, 0); be.synchronize()
