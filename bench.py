@@ -327,12 +327,14 @@ def _kernel_leg(ctx, cb, cq, reps, kk=None, id_offset=0):
         be.search_keys(cb, cq, kk, _capi.METRIC_IP, id_offset=id_offset)
     be.synchronize()
     be.timing_enable(True)
-    t0 = time.perf_counter()
-    for _ in range(reps):
-        keys = be.search_keys(cb, cq, kk, _capi.METRIC_IP, id_offset=id_offset)
-        be.keys_to_result(keys, _capi.METRIC_IP)
-    be.synchronize()
-    wall = (time.perf_counter() - t0) / reps
+    wall = 1e9
+    for _ in range(3 if reps >= 10 else 1):  # sub-millisecond calls: the fastest of three loops (the host also generates the
+        t0 = time.perf_counter()             # other configs' rows in background threads while these legs run)
+        for _ in range(reps):
+            keys = be.search_keys(cb, cq, kk, _capi.METRIC_IP, id_offset=id_offset)
+            be.keys_to_result(keys, _capi.METRIC_IP)
+        be.synchronize()
+        wall = min(wall, (time.perf_counter() - t0) / reps)
     tot, cnt = be.timing_read()
     be.timing_enable(False)
     return tot / max(cnt, 1), wall * 1e3, keys
