@@ -36,7 +36,7 @@ if stats:
 counters = collections.defaultdict(list)
 for p in glob.glob(os.path.join(src, "pmc_*", "b_counter_collection.csv")):
     for r in csv.DictReader(open(p)):
-        if KERNEL in r["Kernel_Name"]:
+        if KERNEL in r["Kernel_Name"] and "<0, 4>" in r["Kernel_Name"]:  # the list kernel itself, not its SEED-mode sample pass
             counters[r["Counter_Name"]].append(float(r["Counter_Value"]))
             summary.setdefault("vgpr", int(r["VGPR_Count"]))
             summary.setdefault("sgpr", int(r["SGPR_Count"]))
