@@ -8,16 +8,16 @@ groups (one all-gather, no merge).  ``gc == world`` is BASELINE's row split, ``g
 
 The total MFMA work is the same for every split; what differs is how far the fused top-k kernel runs below its
 long-stream rate on the per-GPU shape.  Measured on one MI355X (bench.py legs ``node_plan_8gpu`` / ``shard_*``; fraction
-of the dense fp16 MFMA roof on two boxes of the pool, profiles/r03a_bench.json / profiles/r03j_bench.json, whose
-100 k x 1 M launches run at 44.0 / 44.6 %):
+of the dense fp16 MFMA roof, profiles/r04c_bench.json - thresholds seeded from a sample, 100 k x 1 M at 45.8 %; in
+brackets the two boxes of profiles/r03a_bench.json / r03j_bench.json with cold lists, 44.0 / 44.6 % there):
 
-    per-GPU shape at 8 GPUs     1 x 8: 100 k x 125 k  35.8 / 37.5 %      2 x 4: 50 k x 250 k  37.0 / 37.4 %
-                                4 x 2: 25 k x 500 k   36.8 / 37.1 %      8 x 1: 12.5 k x 1 M  36.8 / 36.4 %
-    row split at 4 / 2 GPUs     100 k x 250 k  39.6 / 40.1 %             100 k x 500 k  42.3 / 43.0 %
+    per-GPU shape at 8 GPUs     1 x 8: 100 k x 125 k  39.1 % (35.8 / 37.5)     2 x 4: 50 k x 250 k  38.8 % (37.0 / 37.4)
+                                4 x 2: 25 k x 500 k   38.9 % (36.8 / 37.1)     8 x 1: 12.5 k x 1 M  39.1 % (36.8 / 36.4)
+    row split at 4 / 2 GPUs     100 k x 250 k  41.8 % (39.6 / 40.1)            100 k x 500 k  43.9 % (42.3 / 43.0)
 
-Halving the corpus stream costs threshold events per flop (the top-k slow path: ~ln(N) / N, mildly convex: 1.6, 4.4, 7.6
-points after 1, 2, 3 halvings); halving the query count costs L2 sharing of a corpus stream and fuller tail rounds (2.7,
-5.7, 7.7 points, mildly concave).  The sums come out within a point of each other - inside the box-to-box spread - so the
+Halving the corpus stream costs threshold events per flop (the top-k slow path: ~ln(N) / N, mildly convex: 1.9, 4.0, 6.7
+points after 1, 2, 3 halvings); halving the query count costs L2 sharing of a corpus stream and fuller tail rounds (3.0,
+5.0, 6.7 points, mildly concave).  The sums come out within a point of each other - inside the box-to-box spread - so the
 kernel gives no reason to prefer a split, and the tie goes to the one with the most corpus shards: least HBM per GPU, and
 the only split that scales the corpus past one GPU (BASELINE's configuration).  The planner still ranks by the projected
 fraction, so a per-GPU shape that falls off a cliff (a few hundred queries per GPU, a corpus shard of a few tiles) loses.
@@ -28,9 +28,9 @@ import math
 
 # points of the MFMA roof lost after h halvings of the per-GPU corpus stream / query count relative to 100 k x 1 M
 # (measured, see above; linear interpolation between the points, extrapolated with the last slope)
-_LOSS_ROWS = (0.0, 0.016, 0.044, 0.076, 0.115)
-_LOSS_QUERIES = (0.0, 0.027, 0.057, 0.077, 0.10)
-_BASE_FRAC = 0.443
+_LOSS_ROWS = (0.0, 0.019, 0.040, 0.067, 0.10)
+_LOSS_QUERIES = (0.0, 0.030, 0.050, 0.067, 0.09)
+_BASE_FRAC = 0.458
 _REF_QUERIES, _REF_ROWS = 100_000, 1_000_000
 _TIE = 0.01  # projected fractions closer than this are a tie (box-to-box spread of the measurements)
 HBM_BYTES = 288e9
