@@ -671,10 +671,12 @@ struct Plan {
 // threshold, and the list launch only inserts rows that reach it.  Exact for the same reason as the small-batch kernel's
 // seeding: every value is a real row's score, computed by the same instructions in the same order as the list mode
 // computes it, and at least k rows reach the threshold.  Sample size: a sixteenth of the corpus for up to 64 query tiles
-// (the sample pass is negligible there and a tight threshold saves the most), 1 / 128 beyond (it costs MFMA time
-// in proportion to the queries: 100 k x 125 k -4.0 %, 25 k x 500 k -3.9 %, 100 k x 1 M -0.4 .. -1.0 % wall,
-// tools/seed_big_sweep.py); at least max(k, 8) tiles - the threshold is the k-th largest of one maximum per tile - and at
-// most a sixteenth of the corpus and 64 tiles.  Returns the sample tiles or 0: no seeding.
+// (the sample pass is negligible there and a tight threshold saves the most); beyond, the pass costs MFMA time in
+// proportion to the queries, and the smallest useful sample - max(k, 8) tiles: the threshold is the k-th largest of one
+// maximum per tile - already removes the first tiles' insertions, which is most of a cold start (100 k x 1 M, same box:
+// 10 / 61 tiles 138.5 / 139.5 ms against 140.0 unseeded; 100 k x 125 k 21.2 -> 20.4 ms, 25 k x 500 k 20.9 -> 20.3;
+// tools/seed_big_sweep.py), so it is nb / 512 rows there; never more than a sixteenth of the corpus or 64 tiles.
+// Returns the sample tiles or 0: no seeding.
 #define LVS_TILE_SEED_MAXTILES 64
 #define LVS_TILE_SEED_MAXQT 4096  // 2^20 queries: 256 B of seed workspace per query at most
 int tile_seed_tiles(int64_t nq, int64_t nb, int k) {
@@ -685,7 +687,7 @@ int tile_seed_tiles(int64_t nq, int64_t nb, int k) {
     if (nqt > maxqt) return 0;
     const int64_t kt = k > 8 ? k : 8;
     if (nb < 16 * (int64_t)LVS_BC * kt) return 0;
-    int64_t tiles = nb / LVS_BC / (nqt <= 64 ? lvs_tune("LVS_TILE_SEED_DIV", 16) : lvs_tune("LVS_TILE_SEED_DIV_BIG", 128));
+    int64_t tiles = nb / LVS_BC / (nqt <= 64 ? lvs_tune("LVS_TILE_SEED_DIV", 16) : lvs_tune("LVS_TILE_SEED_DIV_BIG", 512));
     if (tiles < kt) tiles = kt;
     if (tiles > LVS_TILE_SEED_MAXTILES) tiles = LVS_TILE_SEED_MAXTILES;
     return (int)tiles;

@@ -18,9 +18,9 @@ j = torch.randint(0, nb, (nq,), generator=g, device=be.device)
 xq = torch.nn.functional.normalize(0.7 * xb[j].float() + 0.7 * torch.nn.functional.normalize(torch.randn((nq, d), generator=g, device=be.device), dim=1), dim=1).to(torch.float16)
 cb, cq = be.pack(xb, _capi.PACK_F16), be.pack(xq, _capi.PACK_F16)
 del xb, xq
-KNOBS = ("LVS_TILE_SEED", "LVS_TILE_SEED_DIV_BIG")
-VARIANTS = (("unseeded", {"LVS_TILE_SEED": "0"}), ("shipped (nb/128, >= k tiles)", {}),
-            ("nb/64", {"LVS_TILE_SEED_DIV_BIG": "64"}), ("nb/256", {"LVS_TILE_SEED_DIV_BIG": "256"}))
+KNOBS = ("LVS_TILE_SEED", "LVS_TILE_SEED_DIV_BIG", "LVS_LEAD")
+VARIANTS = (("unseeded", {"LVS_TILE_SEED": "0"}), ("shipped (max(k, 8) tiles up to 1.3 M rows)", {}),
+            ("nb/128", {"LVS_TILE_SEED_DIV_BIG": "128"}), ("unseeded again", {"LVS_TILE_SEED": "0"}))
 
 def run(c, q, reps):
     be.search_keys(c, q, k, 0); be.synchronize()
