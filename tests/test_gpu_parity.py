@@ -108,19 +108,20 @@ def test_mixed_precision_operands(hip_backend, cmode, qmode, k):
     (40, 200_000, 256, 10, F16, IP),   # long corpus + several queries: sample pass seeds the shared thresholds
     (96, 150_000, 128, 15, F16, L2),
     (8, 70_000, 768, 56, F16, IP),
-    (96, 90_000, 768, 10, F16, IP),    # two sibling workgroups per corpus range (64 + 32 queries), seeded thresholds
-    (128, 140_000, 768, 10, F16, IP),  # 2 groups x 2 blocks, seeded from 8 192 sample rows
-    (129, 70_000, 256, 10, F16, L2),   # 4 groups, the last three nearly / entirely empty
-    (200, 66_000, 384, 15, F16, IP),   # d = 384: the 8-deep pipeline with two blocks per workgroup
-    (256, 100_000, 768, 10, F16, IP),  # the largest small batch: 4 groups x 64 queries
-    (256, 30_000, 128, 56, F16, L2),   # 64-slot lists for 64 queries per workgroup, unseeded (short corpus)
-    (100, 80_000, 768, 10, SPLIT, IP), # fp32-accurate queries: one block per workgroup (96 KB of fragments), 4 groups
+    (96, 90_000, 768, 10, F16, IP),    # three blocks of 32 queries in one workgroup per corpus range, seeded thresholds
+    (128, 140_000, 768, 10, F16, IP),  # beyond one sibling group: the seeded list kernel (one 128-query tile)
+    (129, 70_000, 256, 10, F16, L2),   # one 256-query tile, half empty, seeded from 16 sample tiles
+    (200, 66_000, 384, 15, F16, IP),   # list kernel; the corpus just allows a sample (>= 16 x 15 tiles)
+    (256, 100_000, 768, 10, F16, IP),  # a full 256-query tile x many slabs, seeded
+    (256, 30_000, 128, 56, F16, L2),   # corpus too short to seed: the stream kernel with 4 sibling groups x 64 queries
+    (100, 80_000, 768, 10, SPLIT, IP), # fp32-accurate queries need 4 sibling groups: the seeded list kernel instead
     (130, 20_000, 768, 10, SPLIT, IP), # ... five blocks do not fit four groups: the tile kernel
     (2, 300_000, 768, 10, F16, IP),    # two queries are seeded too
 ])
 def test_small_batch_streaming_kernel(hip_backend, nq, nb, d, k, mode, metric):
-    """nq <= 256 takes the HBM-streaming kernel (lvs_stream.hip) when the query fragments fit the LDS: same results as
-    the tile kernels / the oracle."""
+    """Small batches: the HBM-streaming kernel (lvs_stream.hip) while one workgroup per corpus range holds all queries
+    (<= 96 fp16 queries at d = 768) or the corpus is too short to seed, the seeded list kernel beyond - same results as
+    the oracle either way."""
     xb = synth.corpus(nb, d, seed=nb % 89)
     xq, _ = synth.queries(xb, nq, seed=13)
     if metric == L2:
