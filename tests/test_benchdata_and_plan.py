@@ -53,3 +53,23 @@ def test_split_planner():
     assert plan.pick_split(8, nq=1_000_000, nb=8_000)[0] > 1  # a corpus of a few tiles: split the queries instead
     f = plan.projected_fraction
     assert f(100_000, 1_000_000) > f(100_000, 125_000) > f(1_000, 125_000)
+
+
+def test_bench_cpu_baseline_reports_a_parity_sample_of_the_timed_run():
+    """bench.py's CPU leg times the comparators AND holds the GPU result against their output (here the oracle stands in for
+    the GPU result): the helper must keep working without a GPU, it runs on the driver's box after the timed region."""
+    import bench
+    import oracle
+    import synth
+
+    xb = synth.corpus(70_000, 48, seed=4).astype(np.float16)
+    xq = synth.queries(xb.astype(np.float32), 300, seed=5)[0].astype(np.float16)
+    Dg, Ig = oracle.flat_search(xb.astype(np.float32), xq.astype(np.float32), 10, 0)
+    out = bench.cpu_baseline(np, xb, xq, 300, 10, Dg, Ig)
+    assert out["kind"] == "port" and out["value"] > 0 and out["cores"] >= 1
+    par = out["gpu_parity_on_the_timed_sample"]
+    assert par["recall_at_k"] == 1.0 and par["id_mismatches_outside_near_ties"] == 0 and par["max_abs_score_err"] <= 1e-5
+    wrong = Ig.copy()
+    wrong[7, 0] = (wrong[7, 0] + 12345) % len(xb)  # a planted neighbour replaced by an unrelated row: must be counted
+    bad = bench.cpu_baseline(np, xb, xq, 300, 10, Dg, wrong)["gpu_parity_on_the_timed_sample"]
+    assert bad["id_mismatches_outside_near_ties"] >= 1 and bad["recall_at_k"] < 1.0
