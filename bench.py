@@ -269,6 +269,15 @@ def oracle_check(np, xb_h, xq_h, Dg, Ig, sample, k):
     return res
 
 
+def _cpu_quota():
+    """CPUs this process may use according to its cgroup (cpu.max), or None when unlimited / unknown."""
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if quota == "max" else float(quota) / float(period)
+    except Exception:
+        return None
+
+
 def cpu_baseline(np, xb_h, xq_h, sample, k, Dg=None, Ig=None):
     """Time the CPU comparators on a bounded sample of the same workload - the first `sample` queries against the WHOLE
     corpus, all host cores: (a) faiss's BLAS search path (blocked sgemm + k-best collector) as one fused C + OpenMP loop
@@ -285,14 +294,17 @@ def cpu_baseline(np, xb_h, xq_h, sample, k, Dg=None, Ig=None):
                       blas_twin.flat_search_c))
     impls.append((f"oracle/blas_twin.py (torch-CPU: {blas_twin.QUERY_BLOCK} x {blas_twin.DB_BLOCK} MKL sgemm blocks + topk)",
                   blas_twin.flat_search_blas))
-    # the C twin does not scale to every hardware thread of a big host (on 2 x EPYC 9575F: 256 threads 1.0, 128 1.6, 64 2.5
-    # TFLOP/s - two threads of a core evict each other's packed block from the L2): calibrate the thread count on a short
-    # sample and time the best one
+    # the C twin's best thread count is not the host's CPU count (GPU boxes of the pool, 2 x EPYC 9575F, 256 CPUs visible: 32
+    # threads 3.3, 64 2.7, 128 1.75, 256 1.3 TFLOP/s - the rate FALLS with the thread count, as under a CPU quota or with the
+    # packed blocks of SMT siblings sharing an L2): calibrate the thread count on a short sample and time the best one
     twin_threads = os.cpu_count() or 1
     if blas_twin.c_available():
         blas_twin.flat_search_c(xb32[:65536], xq32[:256], k)
         best_rate = 0.0
-        for th in sorted({max(1, (os.cpu_count() or 1) // dv) for dv in (1, 2, 4, 8)}):
+        cands = {max(1, (os.cpu_count() or 1) // dv) for dv in (1, 2, 4, 8, 16)}
+        if _cpu_quota():  # a container may be allowed fewer CPUs than it can see: more threads than that only get throttled
+            cands.add(max(1, int(_cpu_quota())))
+        for th in sorted(cands):
             t0 = time.perf_counter()
             blas_twin.flat_search_c(xb32[:262144], xq32[:1024], k, threads=th)
             rate = 1.0 / (time.perf_counter() - t0)
@@ -325,7 +337,7 @@ def cpu_baseline(np, xb_h, xq_h, sample, k, Dg=None, Ig=None):
     out = {"value": best["queries_per_s"], "unit": "queries/s", "cores": best["threads"], "kind": "port",
            "sample": f"first {best['queries']} queries x full {xb32.shape[0]}-row corpus, d={xb32.shape[1]}, k={k}; {best['impl']}; "
                      f"{best['seconds']:.1f} s",
-           "gflops": best["gflops"], "host_cpus": os.cpu_count(), "comparators_timed": runs}
+           "gflops": best["gflops"], "host_cpus": os.cpu_count(), "host_cpu_quota": _cpu_quota(), "comparators_timed": runs}
     if "gpu_parity" in best:
         out["gpu_parity_on_the_timed_sample"] = best["gpu_parity"]
     return out
