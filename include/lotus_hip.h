@@ -29,10 +29,12 @@
 extern "C" {
 #endif
 
-#define LVS_ABI_VERSION 3 /* 2: pack modes in lvs_flat_search_workspace_bytes, lvs_build_flags, k-means device update;
+#define LVS_ABI_VERSION 4 /* 2: pack modes in lvs_flat_search_workspace_bytes, lvs_build_flags, k-means device update;
                              3: k-means iteration entirely on the device (objective, split, repack, accumulate from keys),
                                 lvs_pack_rows_checked (validation + power-of-two scale), lvs_absmax, lvs_margin_select_stats;
-                                scale exponents in lvs_unpack_rows / lvs_keys_to_result / lvs_scores / lvs_range_join */
+                                scale exponents in lvs_unpack_rows / lvs_keys_to_result / lvs_scores / lvs_range_join;
+                             4: pooled sample thresholds of a sharded join (lvs_flat_search_seed_tiles / _seed_scores /
+                                lvs_flat_search_keys_seeded) */
 
 #define LVS_OK 0
 #define LVS_EINVAL (-1)   /* bad argument */
@@ -120,6 +122,30 @@ int32_t lvs_flat_search_keys(const void* xb, int32_t xb_pack, int64_t nb, const 
                              int32_t d, int32_t metric, int32_t k, const float* xb_norms_sq, const float* xq_norms_sq,
                              int64_t id_offset, const uint32_t* row_ids, uint64_t* out_keys, void* workspace,
                              int64_t workspace_bytes, void* stream);
+/* ---- a join whose corpus is row-sharded over several GPUs (the split of sem_sim_join.py:132-134): every shard's search
+ * starts from thresholds that only know its own rows, and a 125 k-row shard of an 8-GPU join pays ~3 x the list insertions
+ * per query of the unsharded 1 M-row stream.  So every shard scores a sample of its rows (the first `tiles` tiles of 256
+ * rows, best score per tile and query: lvs_flat_search_seed_scores), the [tiles][nq] blocks are all-gathered (RCCL), and
+ * every shard searches with the k-th largest of ALL shards' sample maxima as its starting threshold
+ * (lvs_flat_search_keys_seeded).  Exact: every value is the score of a real row of the searched set exactly as the search
+ * computes it, and the k-th largest of a subset never exceeds the k-th largest of all rows; a shard may return fewer than k
+ * keys (empty slots = key 0) when fewer of its rows reach the threshold - lvs_merge_keys of all shards' lists is complete.
+ * ---- */
+/* sample tiles a shard of nb rows contributes for nq queries (0: this shape is not seeded; k <= 56 only) */
+int32_t lvs_flat_search_seed_tiles(int64_t nq, int64_t nb, int32_t k);
+/* out_scores [tiles][nq] float32: the best score (larger = better domain, the values lvs_flat_search_keys ranks, operands'
+ * pack scales included) of every query over tile t = rows [256 t, 256 t + 256) of xb; tiles past the shard's last whole
+ * tile are filled with -inf ("no row seen"). */
+int32_t lvs_flat_search_seed_scores(const void* xb, int32_t xb_pack, int64_t nb, const void* xq, int32_t xq_pack, int64_t nq,
+                                    int32_t d, int32_t metric, const float* xb_norms_sq, const float* xq_norms_sq,
+                                    int32_t tiles, float* out_scores, void* stream);
+/* lvs_flat_search_keys with the starting thresholds taken from seed_scores [seed_rows][nq] (scores of rows of the searched
+ * set, e.g. the all-gathered lvs_flat_search_seed_scores blocks of every shard) instead of the call's own sample pass.
+ * Ignored (plain search) when seed_rows < k or k > 56. */
+int32_t lvs_flat_search_keys_seeded(const void* xb, int32_t xb_pack, int64_t nb, const void* xq, int32_t xq_pack, int64_t nq,
+                                    int32_t d, int32_t metric, int32_t k, const float* xb_norms_sq, const float* xq_norms_sq,
+                                    int64_t id_offset, const uint32_t* row_ids, const float* seed_scores, int32_t seed_rows,
+                                    uint64_t* out_keys, void* workspace, int64_t workspace_bytes, void* stream);
 /* The same search over the fp16 "hi" parts of both operands only: ONE MFMA pass whatever the pack modes (hi|lo rows are
  * read at their own leading dimension).  Scores inside the keys are approximations: |s_hi - s| <= |q| |lo_row| + |lo_q| |row|
  * <= 2^-10 |q| |row|.  Used with k1 > k list slots + lvs_rescore_keys + lvs_sort_keys_desc + lvs_certify_topk this gives the

@@ -17,7 +17,7 @@ DTYPE_F32, DTYPE_F16 = 0, 1
 METRIC_IP, METRIC_L2 = 0, 1
 PACK_F16, PACK_SPLIT = 0, 1
 MAX_K = 2048
-ABI_VERSION = 3
+ABI_VERSION = 4
 BUILD_TUNING, BUILD_COUNT_EVENTS = 1, 2
 PACK_FLAG_NONFINITE, PACK_FLAG_RANGE = 1, 2
 
@@ -40,6 +40,10 @@ SIGNATURES = {
     "lvs_flat_search_workspace_bytes": (_i64, [_i64, _i64, _i32, _i32, _i32, _i32]),
     "lvs_flat_search_keys": (_i32, [_vp, _i32, _i64, _vp, _i32, _i64, _i32, _i32, _i32, _vp, _vp, _i64, _vp, _vp,
                                     _vp, _i64, _vp]),
+    "lvs_flat_search_seed_tiles": (_i32, [_i64, _i64, _i32]),
+    "lvs_flat_search_seed_scores": (_i32, [_vp, _i32, _i64, _vp, _i32, _i64, _i32, _i32, _vp, _vp, _i32, _vp, _vp]),
+    "lvs_flat_search_keys_seeded": (_i32, [_vp, _i32, _i64, _vp, _i32, _i64, _i32, _i32, _i32, _vp, _vp, _i64, _vp, _vp, _i32,
+                                           _vp, _vp, _i64, _vp]),
     "lvs_merge_keys": (_i32, [_vp, _i32, _i64, _i32, _vp, _vp]),
     "lvs_keys_to_result": (_i32, [_vp, _i64, _i32, _i32, _vp, _i32, _vp, _vp, _vp]),
     "lvs_scores": (_i32, [_vp, _i32, _i64, _vp, _i32, _i64, _i32, _i32, _vp, _vp, _i32, _vp, _i64, _vp]),

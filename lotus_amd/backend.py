@@ -255,9 +255,37 @@ class HipBackend:
     CERT_MIN_PAIRS = 1 << 26  # below this many (query, row) pairs the extra launches cost more than the two passes saved
     CERT_MAX_K = 48
 
+    SEED_EXCHANGE_MIN_QUERIES = 2048  # below this a sharded call is too short for an extra collective (see seed_tiles)
+
+    def seed_tiles(self, nq: int, shard_rows: int, k: int, corpus_mode: int, query_mode: int) -> int:
+        """Sample tiles every shard of a row-sharded join contributes to the pooled starting thresholds (0: no exchange).
+        A function of the arguments only - every rank computes it from the NOMINAL shard size, so all ranks agree on the
+        shape of the exchange.  fp32-accurate operands (hi|lo rows) are searched through the certified one-pass path, whose
+        certificate reads a short list as "this shard holds no more rows": no pooled thresholds there."""
+        if nq < self.SEED_EXCHANGE_MIN_QUERIES or corpus_mode != _capi.PACK_F16 or query_mode != _capi.PACK_F16:
+            return 0
+        if not 1 <= k <= 56:
+            return 0
+        return max(0, int(self.lib.lvs_flat_search_seed_tiles(int(nq), int(shard_rows), int(k))))
+
+    def seed_scores(self, corpus: PackedRows, queries: PackedRows, metric: int, tiles: int):
+        """-> float32 [tiles, nq]: best score of every query over each of the first ``tiles`` 256-row tiles of this shard
+        (``lvs_flat_search_seed_scores``; -inf rows where the shard is shorter)."""
+        torch = self.torch
+        out = torch.empty((int(tiles), queries.n), dtype=torch.float32, device=self.device)
+        if tiles and queries.n:
+            self._c("lvs_flat_search_seed_scores", _ptr(corpus.rows), corpus.mode, corpus.n, _ptr(queries.rows), queries.mode,
+                    queries.n, corpus.d, metric, _ptr(corpus.norms), _ptr(queries.norms), int(tiles), _ptr(out),
+                    self._stream())
+        return out
+
     def search_keys(self, corpus: PackedRows, queries: PackedRows, k: int, metric: int, id_offset: int = 0,
-                    row_ids=None, one_pass: bool | None = None, stats: dict | None = None):
+                    row_ids=None, one_pass: bool | None = None, stats: dict | None = None, seed_scores=None):
         """-> int64 tensor [nq, k] holding the uint64 result keys (bit pattern).
+
+        ``seed_scores`` (float32 [rows, nq], optional): scores of rows of the WHOLE searched set - the all-gathered
+        ``seed_scores`` blocks of every corpus shard - whose k-th largest per query becomes the launch's starting threshold
+        (``lvs_flat_search_keys_seeded``); a shard may then return fewer than k keys (key 0 slots).
 
         fp32-accurate operands (fp16 hi|lo rows) need 2-3 MFMA passes in the plain search.  For large calls with
         k <= 48 the same exact result comes from ONE pass (``one_pass``: None = decide by size, False = never):
@@ -281,6 +309,14 @@ class HipBackend:
         if need < 0:
             raise LotusHipError("lvs_flat_search_workspace_bytes rejected the shape")
         ws = self._workspace(need)
+        if seed_scores is not None and int(seed_scores.shape[0]) > 0:
+            if seed_scores.dim() != 2 or int(seed_scores.shape[1]) != queries.n or seed_scores.dtype != torch.float32:
+                raise ValueError("seed_scores must be float32 [rows, nq]")
+            seed_scores = seed_scores.contiguous()
+            self._c("lvs_flat_search_keys_seeded", _ptr(corpus.rows), corpus.mode, corpus.n, _ptr(queries.rows), queries.mode,
+                    queries.n, corpus.d, metric, k, _ptr(corpus.norms), _ptr(queries.norms), int(id_offset), _ptr(row_ids),
+                    _ptr(seed_scores), int(seed_scores.shape[0]), _ptr(keys), _ptr(ws), int(ws.numel()), self._stream())
+            return keys
         self._c("lvs_flat_search_keys", _ptr(corpus.rows), corpus.mode, corpus.n, _ptr(queries.rows), queries.mode,
                 queries.n, corpus.d, metric, k, _ptr(corpus.norms), _ptr(queries.norms), int(id_offset), _ptr(row_ids),
                 _ptr(keys), _ptr(ws), int(ws.numel()), self._stream())

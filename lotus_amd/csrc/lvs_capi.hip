@@ -1025,6 +1025,11 @@ __global__ __launch_bounds__(256) void seed_kth_kernel(const float* __restrict__
     if (lane == 0) gtau[q] = kth;
 }
 
+__global__ __launch_bounds__(256) void fill_f32_kernel(float* __restrict__ dst, long long n, float v) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = v;
+}
+
 __global__ void copy_pass_kernel(const u64* __restrict__ src, long long nq, int kp, u64* __restrict__ dst, int k,
                                  int col0, const uint32_t* __restrict__ pred) {
     if (pred && *pred == 0u) return;
@@ -1045,10 +1050,14 @@ extern "C" int64_t lvs_flat_search_workspace_bytes(int64_t nq, int64_t nb, int32
     return p.total;
 }
 
-extern "C" int32_t lvs_flat_search_keys(const void* xb, int32_t xb_pack, int64_t nb, const void* xq, int32_t xq_pack,
-                                        int64_t nq, int32_t d, int32_t metric, int32_t k, const float* xb_norms_sq,
-                                        const float* xq_norms_sq, int64_t id_offset, const uint32_t* row_ids,
-                                        uint64_t* out_keys, void* workspace, int64_t workspace_bytes, void* stream) {
+// ext_seeds (nullable): [ext_rows][nq] scores of real rows of the SEARCHED SET (any shard of it, e.g. the all-gathered
+// sample maxima of every corpus shard of a multi-GPU join, lvs_flat_search_seed_scores): the k-th largest per query replaces
+// the launch's own sample pass as its starting threshold.
+static int32_t flat_search_impl(const void* xb, int32_t xb_pack, int64_t nb, const void* xq, int32_t xq_pack,
+                                int64_t nq, int32_t d, int32_t metric, int32_t k, const float* xb_norms_sq,
+                                const float* xq_norms_sq, int64_t id_offset, const uint32_t* row_ids,
+                                uint64_t* out_keys, void* workspace, int64_t workspace_bytes, void* stream,
+                                const float* ext_seeds, int32_t ext_rows) {
     Plan p;
     LVS_REQUIRE(make_plan(nq, nb, d, xb_pack, xq_pack, k, p) == LVS_OK,
                 "bad shape nq=%lld nb=%lld d=%d k=%d pack=%d/%d", (long long)nq, (long long)nb, d, k, xb_pack, xq_pack);
@@ -1231,7 +1240,11 @@ extern "C" int32_t lvs_flat_search_keys(const void* xb, int32_t xb_pack, int64_t
             // rows themselves are scanned again with the rest.
             int64_t sample = nb / 8 / 1024 * 1024;
             if (sample > LVS_STREAM_SEED_ROWS) sample = LVS_STREAM_SEED_ROWS;
-            if (nq >= lvs_tune("LVS_STREAM_SEED_MINQ", 2) && sample >= 4096 && lvs_tune("LVS_STREAM_SEED", 1) != 0) {
+            if (ext_seeds && ext_rows >= k) {  // the caller's pooled sample scores
+                hipLaunchKernelGGL(seed_kth_kernel, dim3((unsigned)lvs_ceil_div(nq, 4)), dim3(256), 0, st, ext_seeds,
+                                   (int)ext_rows, (long long)nq, k, gtau);
+                LVS_HIP_CHECK(hipGetLastError());
+            } else if (nq >= lvs_tune("LVS_STREAM_SEED_MINQ", 2) && sample >= 4096 && lvs_tune("LVS_STREAM_SEED", 1) != 0) {
                 float* seeds = (float*)((char*)partial + lvs_stream_parts_bytes(nq, k));  // [ranges][nq]
                 LvsStreamArgs ss = sa;
                 ss.nb = sample;
@@ -1270,8 +1283,13 @@ extern "C" int32_t lvs_flat_search_keys(const void* xb, int32_t xb_pack, int64_t
         // pass > 0: only keys strictly below the last key of the previous pass take part
         a.ub = pass == 0 ? nullptr : (const u64*)out_keys + (col0 - 1);
         a.ub_stride = k;
-        const int seed_tiles = (pass == 0 && p.npass == 1 && !pred && !use_top1) ? tile_seed_tiles(nq, nb, kp) : 0;
-        if (seed_tiles > 0) {  // thresholds seeded from a sample instead of cold starts (tile_seed_tiles)
+        const bool seedable = pass == 0 && p.npass == 1 && !pred && !use_top1;
+        const int seed_tiles = seedable ? tile_seed_tiles(nq, nb, kp) : 0;
+        if (seedable && ext_seeds && ext_rows >= kp) {  // the caller's pooled sample scores (every shard's sample)
+            hipLaunchKernelGGL(seed_kth_kernel, dim3((unsigned)lvs_ceil_div(nq, 4)), dim3(256), 0, st, ext_seeds, (int)ext_rows,
+                               (long long)nq, kp, gtau);  // writes every gtau[q]
+            LVS_HIP_CHECK(hipGetLastError());
+        } else if (seed_tiles > 0) {  // thresholds seeded from a sample instead of cold starts (tile_seed_tiles)
             float* seeds = (float*)(ws + p.off_seed);
             LvsTileArgs sd = a;
             sd.nb = (int64_t)seed_tiles * LVS_BC;
@@ -1331,6 +1349,80 @@ extern "C" int32_t lvs_flat_search_keys(const void* xb, int32_t xb_pack, int64_t
                 (double)h[5] / (double)(h[2] ? h[2] : 1), (double)(h[4] - h[5]) / (double)(h[0] ? h[0] : 1),
                 (double)h[5] / (double)(h[1] ? h[1] : 1));
     }
+    return LVS_OK;
+}
+
+extern "C" int32_t lvs_flat_search_keys(const void* xb, int32_t xb_pack, int64_t nb, const void* xq, int32_t xq_pack,
+                                        int64_t nq, int32_t d, int32_t metric, int32_t k, const float* xb_norms_sq,
+                                        const float* xq_norms_sq, int64_t id_offset, const uint32_t* row_ids,
+                                        uint64_t* out_keys, void* workspace, int64_t workspace_bytes, void* stream) {
+    return flat_search_impl(xb, xb_pack, nb, xq, xq_pack, nq, d, metric, k, xb_norms_sq, xq_norms_sq, id_offset, row_ids,
+                            out_keys, workspace, workspace_bytes, stream, nullptr, 0);
+}
+
+extern "C" int32_t lvs_flat_search_keys_seeded(const void* xb, int32_t xb_pack, int64_t nb, const void* xq, int32_t xq_pack,
+                                               int64_t nq, int32_t d, int32_t metric, int32_t k, const float* xb_norms_sq,
+                                               const float* xq_norms_sq, int64_t id_offset, const uint32_t* row_ids,
+                                               const float* seed_scores, int32_t seed_rows, uint64_t* out_keys,
+                                               void* workspace, int64_t workspace_bytes, void* stream) {
+    LVS_REQUIRE(seed_rows >= 0 && (seed_rows == 0 || seed_scores), "bad seed scores");
+    return flat_search_impl(xb, xb_pack, nb, xq, xq_pack, nq, d, metric, k, xb_norms_sq, xq_norms_sq, id_offset, row_ids,
+                            out_keys, workspace, workspace_bytes, stream, seed_rows > 0 ? seed_scores : nullptr, seed_rows);
+}
+
+extern "C" int32_t lvs_flat_search_seed_tiles(int64_t nq, int64_t nb, int32_t k) {
+    if (nq < 0 || nb < 0 || k < 1) return LVS_EINVAL;
+    return tile_seed_tiles(nq, nb, k);
+}
+
+extern "C" int32_t lvs_flat_search_seed_scores(const void* xb, int32_t xb_pack, int64_t nb, const void* xq, int32_t xq_pack,
+                                               int64_t nq, int32_t d, int32_t metric, const float* xb_norms_sq,
+                                               const float* xq_norms_sq, int32_t tiles, float* out_scores, void* stream) {
+    Plan p;
+    LVS_REQUIRE(make_plan(nq, nb, d, xb_pack, xq_pack, 1, p, true) == LVS_OK, "bad shape nq=%lld nb=%lld d=%d pack=%d/%d",
+                (long long)nq, (long long)nb, d, xb_pack, xq_pack);
+    LVS_REQUIRE(metric == LVS_METRIC_IP || metric == LVS_METRIC_L2, "bad metric %d", metric);
+    LVS_REQUIRE(tiles >= 0, "bad tile count %d", tiles);
+    if (nq == 0 || tiles == 0) return LVS_OK;
+    LVS_REQUIRE(out_scores, "out_scores is NULL");
+    LVS_REQUIRE(metric != LVS_METRIC_L2 || (xb_norms_sq && xq_norms_sq), "L2 needs both norm vectors");
+    LVS_DEVICE_GUARD(stream);
+    hipStream_t st = (hipStream_t)stream;
+    const int have = (int)(nb / LVS_BC < tiles ? nb / LVS_BC : tiles);  // whole tiles of real rows only
+    if (have < tiles) {  // -inf: "that tile saw no row" (seed_kth_kernel skips it)
+        const long long cnt = (long long)(tiles - have) * nq;
+        float* dst = out_scores + (long long)have * nq;
+        hipLaunchKernelGGL(fill_f32_kernel, dim3((unsigned)lvs_ceil_div(cnt, 256)), dim3(256), 0, st, dst, cnt, -INFINITY);
+        LVS_HIP_CHECK(hipGetLastError());
+    }
+    if (have == 0) return LVS_OK;
+    LVS_REQUIRE(xb && xq, "NULL rows");
+    LvsTileArgs a;
+    memset(&a, 0, sizeof(a));
+    a.xb = xb;
+    a.xq = xq;
+    a.bn = xb_norms_sq;
+    a.qn = xq_norms_sq;
+    a.nb = (int64_t)have * LVS_BC;
+    a.nq = nq;
+    a.ldb = p.ldb;
+    a.ldq = p.ldq;
+    a.nseg = p.nseg;
+    for (int i = 0; i < 3; ++i) {
+        a.seg_q[i] = p.seg_q[i];
+        a.seg_c[i] = p.seg_c[i];
+    }
+    a.nkd = p.nkd;
+    a.nk = p.nk;
+    a.metric = metric;
+    a.k = 1;
+    a.ntiles = a.nslab = have;
+    a.tiles_per_slab = 1;
+    a.nqt = (int)lvs_ceil_div(nq, LVS2_BQ);
+    a.bq = LVS2_BQ;
+    a.gq = 1;
+    a.seed_out = out_scores;
+    LVS_HIP_CHECK(lvs_tile_launch(LVS_MODE_SEED, a, st));
     return LVS_OK;
 }
 

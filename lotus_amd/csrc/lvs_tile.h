@@ -71,19 +71,33 @@ struct LvsTileArgs {
 };
 
 // ---- the (query tile, slab) items of a launch in XCD groups of 32 slots (see item_of_block in lvs_tile.hip) ----
+// Three regions, in launch order:
+//   lead       the first lead_slabs slab(s) of every query tile in 32-wide groups (32 query tiles x 1 slab);
+//   full       the nqt / gq whole query groups: gq query tiles x 32 / gq slabs per group, walking the query groups first,
+//              then the slabs;
+//   remainder  the last nqt % gq query tiles.  Dealt like the others they would fill (nqt % gq) / gq of every group's slots
+//              (49 tiles with gq = 8: one tile x 4 slabs in a 32-slot group, 28 CUs of an XCD idle for every 7th group), so
+//              they get groups of their own shape: gqr = the power of two >= the remainder query tiles x 32 / gqr slabs.
 struct LvsTileGroups {
-    int nqg32, n0;   // 32-wide groups of the leading slab(s): nqg32 per slab, n0 in all
-    int nqg, nsg;    // narrow groups: nqg along the query tiles x nsg along the slabs
-    int total, full; // all groups; the largest multiple of 8 below (whole generations: one group per XCD)
+    int nqg32, n0;        // lead region: nqg32 groups per slab, n0 in all
+    int nqf, nsg, n1;     // full region: nqf query groups x nsg slab groups = n1 groups
+    int rem, gqr, nsgr;   // remainder region: rem query tiles, gqr x (32 / gqr) slots per group, nsgr groups
+    int total, full;      // all groups; the largest multiple of 8 below (whole generations: one group per XCD)
 };
 __host__ __device__ inline LvsTileGroups lvs_tile_groups(int nqt, int nslab, int gq, int lead_slabs) {
     LvsTileGroups g;
     const int gs = 32 / gq;
+    const int rest = nslab - lead_slabs;
     g.nqg32 = (nqt + 31) / 32;
     g.n0 = g.nqg32 * lead_slabs;
-    g.nqg = (nqt + gq - 1) / gq;
-    g.nsg = (nslab - lead_slabs + gs - 1) / gs;
-    g.total = g.n0 + g.nqg * g.nsg;
+    g.nqf = nqt / gq;
+    g.nsg = (rest + gs - 1) / gs;
+    g.n1 = g.nqf * g.nsg;
+    g.rem = nqt - g.nqf * gq;
+    g.gqr = 1;
+    while (g.gqr < g.rem) g.gqr <<= 1;
+    g.nsgr = g.rem ? (rest + 32 / g.gqr - 1) / (32 / g.gqr) : 0;
+    g.total = g.n0 + g.n1 + g.nsgr;
     g.full = g.total & ~7;
     return g;
 }
@@ -93,12 +107,35 @@ __host__ __device__ inline bool lvs_tile_group_slot(int nqt, int nslab, int gq, 
     if (g < gr.n0) {
         slab = g / gr.nqg32;
         qt = (g % gr.nqg32) * 32 + r;
-    } else {
+    } else if (g < gr.n0 + gr.n1) {
         const int h = g - gr.n0;
-        qt = (h % gr.nqg) * gq + (r % gq);
-        slab = lead_slabs + (h / gr.nqg) * (32 / gq) + (r / gq);
+        qt = (h % gr.nqf) * gq + (r % gq);
+        slab = lead_slabs + (h / gr.nqf) * (32 / gq) + (r / gq);
+    } else {
+        const int h = g - gr.n0 - gr.n1;
+        if ((r % gr.gqr) >= gr.rem) return false;
+        qt = gr.nqf * gq + (r % gr.gqr);
+        slab = lead_slabs + h * (32 / gr.gqr) + (r / gr.gqr);
     }
     return qt < nqt && slab < nslab;
+}
+// valid slots of group g
+__host__ __device__ inline int lvs_tile_group_items(int nqt, int nslab, int gq, int lead_slabs, const LvsTileGroups& gr, int g) {
+    int vq, vs;
+    if (g < gr.n0) {
+        vq = nqt - (g % gr.nqg32) * 32;
+        vq = vq > 32 ? 32 : vq;
+        vs = 1;
+    } else if (g < gr.n0 + gr.n1) {
+        vq = gq;
+        vs = nslab - lead_slabs - ((g - gr.n0) / gr.nqf) * (32 / gq);
+        vs = vs > 32 / gq ? 32 / gq : vs;
+    } else {
+        vq = gr.rem;
+        vs = nslab - lead_slabs - (g - gr.n0 - gr.n1) * (32 / gr.gqr);
+        vs = vs > 32 / gr.gqr ? 32 / gr.gqr : vs;
+    }
+    return (vq < 0 ? 0 : vq) * (vs < 0 ? 0 : vs);
 }
 // block b of the launch -> (group, slot).  Whole generations: XCD b % 8 runs slot (b / 8) % 32 of group (b / 256) * 8 + b % 8;
 // the last total % 8 groups are dealt slot by slot across all XCDs (slot r on XCD r % 8).  false: b is past the last group.
@@ -123,22 +160,7 @@ inline int lvs_tile_grid_blocks(int nqt, int nslab, int gq, int lead_slabs) {
 inline int lvs_tile_xcd_rounds(int nqt, int nslab, int gq, int lead_slabs) {
     const LvsTileGroups gr = lvs_tile_groups(nqt, nslab, gq, lead_slabs);
     long long items[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    const int gs = 32 / gq;
-    for (int g = 0; g < gr.full; ++g) {
-        int vq, vs;
-        if (g < gr.n0) {
-            vq = nqt - (g % gr.nqg32) * 32;
-            vq = vq < 0 ? 0 : (vq > 32 ? 32 : vq);
-            vs = 1;
-        } else {
-            const int h = g - gr.n0;
-            vq = nqt - (h % gr.nqg) * gq;
-            vq = vq < 0 ? 0 : (vq > gq ? gq : vq);
-            vs = nslab - lead_slabs - (h / gr.nqg) * gs;
-            vs = vs < 0 ? 0 : (vs > gs ? gs : vs);
-        }
-        items[g & 7] += (long long)vq * vs;
-    }
+    for (int g = 0; g < gr.full; ++g) items[g & 7] += lvs_tile_group_items(nqt, nslab, gq, lead_slabs, gr, g);
     for (int g = gr.full; g < gr.total; ++g)
         for (int r = 0; r < 32; ++r) {
             int qt, slab;

@@ -407,7 +407,8 @@ class HipVS(VS):
                 id_map = be.to_device(order)
             world = 1  # already complete on every rank: nothing left to merge
         elif sub is None:
-            keys = be.search_keys(ent.packed, queries, k_eff, self.metric, id_offset=ent.lo)
+            keys = be.search_keys(ent.packed, queries, k_eff, self.metric, id_offset=ent.lo,
+                                  seed_scores=self._pooled_seed_scores(ent, queries, k_eff, world))
         else:
             # positions (in `ids`) of the subset rows that live in this rank's shard
             pos = np.flatnonzero((sub >= ent.lo) & (sub < ent.hi))
@@ -635,6 +636,23 @@ class HipVS(VS):
         return res if return_result else res.assign
 
     # ------------------------------------------------------------------------------------------ multi-GPU
+    def _pooled_seed_scores(self, ent: _Resident, queries, k: int, world: int):
+        """Row-sharded join: every shard scores a small sample of its own rows and the blocks are all-gathered inside the
+        corpus group, so that every shard starts from thresholds that know ALL shards' samples (an 8 x larger sample at no
+        extra MFMA cost per GPU; ``lvs_flat_search_keys_seeded``).  None when the shape is not worth a collective; the
+        decision depends on the call's arguments and the nominal shard size only, so every rank takes it alike."""
+        be = self.backend
+        if world <= 1 or not hasattr(be, "seed_tiles"):
+            return None
+        per = -(-ent.n // world) if ent.n else 0
+        tiles = be.seed_tiles(queries.n, per, k, ent.packed.mode, queries.mode)
+        if tiles <= 0:
+            return None
+        from . import _dist
+
+        mine = be.seed_scores(ent.packed, queries, self.metric, tiles)                    # [tiles, nq]
+        return _dist.all_gather_rows(mine, self._pg_corpus()).reshape(world * tiles, queries.n)
+
     def _allgather_merge(self, keys, world: int):
         """All-gather the per-shard candidate keys [Q,k] (8 B each; ONE RCCL all-gather over xGMI on a GPU node, staged
         through the host for any other process-group backend) and merge them on every rank (``lvs_merge_keys``)."""

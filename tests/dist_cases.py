@@ -39,6 +39,19 @@ def search_data():
     return xb.astype(np.float16), xq.astype(np.float16)
 
 
+SEED_NB, SEED_D, SEED_NQ, SEED_K = 90_001, 32, 2100, 10
+
+
+def seeded_data():
+    """A row-sharded join large enough for the pooled sample thresholds (lvs_flat_search_seed_scores + one all-gather +
+    lvs_flat_search_keys_seeded): >= 2048 queries, shards of >= 16 x 256 x k rows."""
+    import synth
+
+    xb = synth.corpus(SEED_NB, SEED_D, seed=31)
+    xq, _ = synth.queries(xb, SEED_NQ, seed=32)
+    return xb.astype(np.float16), xq.astype(np.float16)
+
+
 def subset_ids():
     return np.random.default_rng(5).choice(NB, 1500, replace=False).tolist()
 
@@ -107,6 +120,18 @@ def worker(rank, world, port, tmp, out_q, backend_kind):
         res["q_index"] = (len(writes), vq2._resident[vq2.index_dir].sig, np.asarray(vq2(xq[:9], 3).indices))
         res["scores"] = vs.scores(xq[:6])
         res["scores_sub"] = vs.scores(xq[:6], ids=ids[:77])
+        # a join big enough for the pooled sample thresholds: every shard scores a sample, one all-gather, seeded search
+        xsb, xsq = seeded_data()
+        calls = []
+        orig_seed = be.seed_scores
+        be.seed_scores = lambda *a, **k: (calls.append(int(a[3])), orig_seed(*a, **k))[1]
+        vseed = HipVS(backend=be, shard=True)
+        vseed.index(None, xsb, os.path.join(tmp, "seeded"), persist=False)
+        out = vseed(xsq, SEED_K)
+        out_small = vseed(xsq[:100], SEED_K)  # below the exchange's query floor: plain sharded search
+        be.seed_scores = orig_seed
+        res["seeded"] = (np.asarray(out.distances), np.asarray(out.indices), list(calls))
+        res["seeded_small"] = (np.asarray(out_small.distances), np.asarray(out_small.indices))
         # k-means on the row-sharded index: all rows, then a subset of rows
         xk = km_data()
         vk = HipVS(backend=be, shard=True)
@@ -186,6 +211,13 @@ def check(res, exact: bool):
         same_topk(r["rank_sub"], ref_rsub, 2600)  # ... and on a subset of the rows (ids remapped through the shards)
         assert r["scores"].shape == (6, NB) and np.abs(r["scores"] - S).max() <= 1e-5
         assert np.abs(r["scores_sub"] - S[:, ids[:77]]).max() <= 1e-5
+    xsb, xsq = seeded_data()
+    ref_seed = oracle.flat_search(xsb.astype(np.float32), xsq.astype(np.float32), SEED_K)
+    for r in res:
+        same_topk(r["seeded"][:2], ref_seed, SEED_K)
+        assert len(r["seeded"][2]) == 1 and r["seeded"][2][0] >= SEED_K  # ONE exchange, only for the big call
+        same_topk(r["seeded_small"], (ref_seed[0][:100], ref_seed[1][:100]), SEED_K)
+    assert np.array_equal(res[0]["seeded"][1], res[1]["seeded"][1])
     ref_qf = oracle.flat_search(xb32, xq32[:299], 7)
     ref_qs = oracle.flat_search(xb32, xq32[:299], 7, ids=ids)
     ref_q1 = oracle.flat_search(xb32, xq32[:1], 5)

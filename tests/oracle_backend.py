@@ -92,7 +92,29 @@ class OracleBackend:
         self.calls.append(("gather", len(idx)))
         return PackedRows(rows=src.rows[idx], norms=src.norms[idx], n=len(idx), d=src.d, mode=src.mode, exp=src.exp)
 
-    def search_keys(self, corpus, queries, k, metric, id_offset=0, row_ids=None, one_pass=None, stats=None):
+    SEED_EXCHANGE_MIN_QUERIES = 2048
+
+    def seed_tiles(self, nq, shard_rows, k, corpus_mode, query_mode):
+        """Same rule as HipBackend.seed_tiles (the tile count comes from the library's host-side planner)."""
+        if nq < self.SEED_EXCHANGE_MIN_QUERIES or corpus_mode != _capi.PACK_F16 or query_mode != _capi.PACK_F16:
+            return 0
+        if not 1 <= k <= 56:
+            return 0
+        return max(0, int(_capi.load().lvs_flat_search_seed_tiles(int(nq), int(shard_rows), int(k))))
+
+    def seed_scores(self, corpus, queries, metric, tiles):
+        """[tiles, nq]: best score of every query over each of the first `tiles` 256-row tiles (-inf past the shard)."""
+        self.calls.append(("seed", queries.n, corpus.n, tiles))
+        out = np.full((tiles, queries.n), -np.inf, np.float32)
+        xb, xq = corpus.rows.numpy(), queries.rows.numpy()
+        for t in range(min(tiles, corpus.n // 256)):
+            s = xq @ xb[256 * t:256 * t + 256].T
+            if metric == 1:
+                s = -np.maximum((queries.norms.numpy()[:, None] + corpus.norms.numpy()[None, 256 * t:256 * t + 256]) - 2 * s, 0)
+            out[t] = s.max(axis=1)
+        return torch.from_numpy(out)
+
+    def search_keys(self, corpus, queries, k, metric, id_offset=0, row_ids=None, one_pass=None, stats=None, seed_scores=None):
         self.calls.append(("search", queries.n, corpus.n, k, metric))
         xb, xq = corpus.rows.numpy(), queries.rows.numpy()
         if corpus.n == 0:
@@ -100,6 +122,12 @@ class OracleBackend:
         D, I = oracle.flat_search(xb, xq, min(k, corpus.n), metric)
         better = D if metric == 0 else -D
         valid = I >= 0
+        if seed_scores is not None and seed_scores.shape[0] >= k:
+            # as the device: rows below the k-th largest pooled sample score are never listed (a shard may come back short);
+            # a float32 ulp of slack - the double's sample scores and search scores come from different sgemm shapes
+            thr = np.sort(seed_scores.numpy(), axis=0)[::-1][k - 1]
+            valid &= better >= (thr - 1e-6 * np.abs(thr))[:, None]
+            self.calls.append(("seeded", int((~valid).sum())))
         if row_ids is not None:
             rid = row_ids.numpy().view(np.uint32).astype(np.int64)
             ids = np.where(valid, rid[np.where(valid, I, 0)], 0)
