@@ -27,6 +27,10 @@ Extra objects:
                   configs[4] (k-means, full-data iteration and faiss-parity mode), fp32 embeddings, and T_call
                   (`HipVS.__call__` host ndarray -> host (D, I)).
 All GPU work runs first and back to back; the CPU-side checks and the CPU baseline follow.
+
+The stdout line is kept below 6 KB (floats at 5 significant digits, one short object per leg, the figures that matter once
+more in a flat `legs_summary` printed LAST) so that a tail of the line still holds every leg; the verbose form of the same
+objects (notes, per-iteration lists) goes to stderr as `BENCH_DETAILS {...}`.
 """
 from __future__ import annotations
 
@@ -43,6 +47,28 @@ sys.path.insert(0, ROOT)
 
 PEAK_FP16_MFMA_TFLOPS = 2500.0  # dense, /opt/skills/guides/MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0
+
+
+def sig(x, digits=5):
+    """Floats rounded to `digits` significant digits, recursively (the line stays short; nothing is measured to more)."""
+    if isinstance(x, float):
+        return float(f"{x:.{digits}g}") if x == x and abs(x) != float("inf") else x
+    if isinstance(x, dict):
+        return {k: sig(v, digits) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [sig(v, digits) for v in x]
+    return x
+
+
+DETAIL_KEYS = ("note", "objective", "searched_row_fraction_per_iteration", "comparators_timed", "algorithmic_flops",
+               "algorithmic_flops_per_iteration", "mfma_frac_secondary")
+
+
+def compact(x):
+    """The stdout form of a leg: verbose keys dropped (they go to stderr)."""
+    if isinstance(x, dict):
+        return {k: compact(v) for k, v in x.items() if k not in DETAIL_KEYS}
+    return x
 
 
 def parse():
@@ -124,8 +150,15 @@ def main():
     queries = be.pack(xq_h, _capi.PACK_F16)  # replicated
     planted = torch.from_numpy(planted_h).to(device)
 
+    # row-sharded join: every shard's starting thresholds come from ALL shards' samples (one small all-gather before the
+    # search, lvs_flat_search_seed_scores / lvs_flat_search_keys_seeded - what HipVS(shard=True).__call__ does)
+    seed_tiles = be.seed_tiles(nq, per, k, _capi.PACK_F16, _capi.PACK_F16) if world > 1 else 0
+
     def step():
-        keys = be.search_keys(corpus, queries, k, _capi.METRIC_IP, id_offset=lo)
+        seeds = None
+        if seed_tiles:
+            seeds = _dist.all_gather_rows(be.seed_scores(corpus, queries, _capi.METRIC_IP, seed_tiles)).reshape(world * seed_tiles, nq)
+        keys = be.search_keys(corpus, queries, k, _capi.METRIC_IP, id_offset=lo, seed_scores=seeds)
         if world > 1:
             keys = be.merge_keys(_dist.all_gather_rows(keys))  # one RCCL all-gather of [Q,k] uint64 keys + merge
         return keys, be.keys_to_result(keys, _capi.METRIC_IP)
@@ -173,28 +206,25 @@ def main():
             "vs_baseline": None,
             "dtype": "f16",
             "data": "synthetic",
-            "config": {"workload": f"sem_sim_join: {nq} left x {n} right rows, d={d} fp16, k={k}, inner product; "
-                                   f"corpus row-sharded over {world} GPU(s), RCCL all-gather top-k merge; "
-                                   "timed device-resident queries -> device-resident (D, I)",
-                       "queries": nq, "corpus_rows": n, "dim": d, "k": k, "shard_rows": hi - lo,
-                       "inputs": f"benchdata.py: numpy SeedSequence([{benchdata.SEED}, {benchdata.CFG_JOIN}, block]), "
-                                 f"1 M-row blocks, host-generated in {gen_s:.1f} s"},
+            "config": {"workload": f"sem_sim_join {nq} x {n} rows, d={d} fp16, k={k}, IP; corpus row-sharded over {world} "
+                                   f"GPU(s) ({hi - lo} rows each), pooled sample thresholds + RCCL all-gather top-k merge; "
+                                   "device-resident in/out",
+                       "inputs": f"benchdata.py SeedSequence([{benchdata.SEED},{benchdata.CFG_JOIN},block])"},
             "planted_neighbour_at_rank1": planted_at_1,
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP16_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP16_MFMA_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": "lvs_tile_kernel<TOPK, 256x256>", "kernel_ms": kernel_ms, "launches": klaunches,
-                         "algorithmic_flops_per_launch": flops_per_launch,
-                         "algorithmic_bytes_per_launch": alg_bytes,
-                         "hbm_frac_secondary": alg_bytes / (kernel_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                         "kernel": "lvs_tile_kernel<TOPK,256x256>", "kernel_ms": kernel_ms, "launches": klaunches,
+                         "algorithmic_flops_per_launch": flops_per_launch, "algorithmic_bytes_per_launch": alg_bytes,
                          "csrc_sha": csrc_hash()},
         }
+        details = {"gen_s": gen_s, "hbm_frac_secondary": alg_bytes / (kernel_ms * 1e-3) / 1e9 / PEAK_HBM_GBS}
         n_chk = max(args.check_sample, args.cpu_sample if (world == 1 and not args.no_cpu_baseline) else 0, 1)
         D_h, I_h = D[:n_chk].cpu().numpy(), I[:n_chk].cpu().numpy()
         checks = []  # CPU-side work deferred until every GPU leg has run
+        legs = {}
         if legs_on:
             ctx = dict(np=np, torch=torch, be=be, _capi=_capi, xb_h=xb_h, xq_h=xq_h, corpus=corpus, queries=queries, k=k,
                        d=d, keys=keys, args=args)
-            legs = {}
             search_legs(ctx, legs)
             node_plan_legs(ctx, legs)
             world8_rehearsal(ctx, legs, checks)
@@ -204,7 +234,6 @@ def main():
                 dedup_leg(ctx, legs, checks, fut_dedup)
             if fut_km is not None:
                 kmeans_legs(ctx, legs, checks, fut_km)
-            out["legs"] = legs
         be.synchronize()
         # ---- CPU side ----
         if args.check_sample > 0:
@@ -213,11 +242,41 @@ def main():
             fn()
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(np, xb_h, xq_h, args.cpu_sample, k, D_h, I_h)
-        print(json.dumps(out), flush=True)
+        if legs:
+            out["legs"] = legs
+            out["legs_summary"] = legs_summary(out, legs)  # printed LAST: the tail of the line holds the figures that matter
+        details["line"] = out
+        print("BENCH_DETAILS " + json.dumps(sig(details, 7)), file=sys.stderr, flush=True)
+        print(json.dumps(sig(compact(out))), flush=True)
     pool.shutdown(wait=False, cancel_futures=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def legs_summary(out, legs):
+    """The numbers a reader looks for first, flat: fraction of the binding roof per BASELINE config / regime."""
+    g = lambda name, key="frac": (legs.get(name) or {}).get(key)
+    plan = (legs.get("node_plan_8gpu") or {}).get("splits", {})
+    w8 = legs.get("world8_rehearsal") or {}
+    km = legs.get("kmeans_parity_mode") or {}
+    return {
+        "cfg3_join_100k_x_1M_mfma_frac": out["roofline"]["frac"],
+        "cfg2_10k_x_1M_mfma_frac": g("cfg2_10k_x_1M"),
+        "q1_hbm_frac": g("q1"), "q64_hbm_frac": g("q64"), "q128_hbm_frac": g("q128"), "q256_hbm_frac": g("q256"),
+        "q512_mfma_frac": g("q512"), "q1024_mfma_frac": g("q1024"), "q4096_mfma_frac": g("q4096"),
+        "shard_100k_x_125k_mfma_frac": (plan.get("1x8") or {}).get("frac"),
+        "split_8x1_12500_x_1M_mfma_frac": (plan.get("8x1") or {}).get("frac"),
+        "world8_pooled_seeds_ms_per_shard": w8.get("kernel_ms_per_shard"),
+        "world8_projected_node_qps": w8.get("projected_node_qps"),
+        "t_call_ms": g("t_call_host_to_host", "ms_per_call"), "t_call_qps": g("t_call_host_to_host", "queries_per_s"),
+        "cfg4_dedup_5M_mfma_frac": g("range_selfjoin_cfg4"),
+        "cfg5_kmeans_iter_ms": g("kmeans_full_iter_10M_x_1024", "ms_per_iteration"),
+        "cfg5_kmeans_iter_mfma_frac": g("kmeans_full_iter_10M_x_1024"),
+        "kmeans_first_divergence_iteration": km.get("first_divergence_iteration"),
+        "kmeans_all_flips_are_near_ties": km.get("all_flips_are_near_ties"),
+        "fp32_10k_x_1M_ms": (legs.get("fp32_10k_x_1M") or {}).get("one_pass_ms"),
+    }
 
 
 def pmc_traffic(n, nq, world):
@@ -330,14 +389,20 @@ def cpu_baseline(np, xb_h, xq_h, sample, k, Dg=None, Ig=None):
             inter = sum(len(set(a.tolist()) & set(b.tolist())) for a, b in zip(Ic, Ig[:ns]))
             runs[-1]["gpu_parity"] = {"queries": ns, "recall_at_k": inter / float(Ic.size),
                                       "max_abs_score_err": float(np.abs(Dc - Dg[:ns]).max()),
-                                      "id_mismatches_outside_near_ties": _near_tie_mismatches(np, Dc, Ic, Ig[:ns], k),
-                                      "note": "recall counts a swap across the k-th boundary inside a near-tie (scores < 2e-5 "
-                                              "apart, different summation order) as a miss; such swaps are not id mismatches"}
+                                      "id_mismatches_outside_near_ties": _near_tie_mismatches(np, Dc, Ic, Ig[:ns], k)}
+            # (recall counts a swap across the k-th boundary inside a near-tie - scores < 2e-5 apart, different summation
+            # order - as a miss; such swaps are not id mismatches)
     best = max(runs, key=lambda r: r["queries_per_s"])
-    out = {"value": best["queries_per_s"], "unit": "queries/s", "cores": best["threads"], "kind": "port",
-           "sample": f"first {best['queries']} queries x full {xb32.shape[0]}-row corpus, d={xb32.shape[1]}, k={k}; {best['impl']}; "
-                     f"{best['seconds']:.1f} s",
-           "gflops": best["gflops"], "host_cpus": os.cpu_count(), "host_cpu_quota": _cpu_quota(), "comparators_timed": runs}
+    quota = _cpu_quota()
+    # cores = CPUs the timed comparator could actually occupy: its threads, capped by the container's cgroup quota
+    cores = int(min(best["threads"], quota)) if quota else int(best["threads"])
+    cores_note = (f"{best['threads']} threads under a cgroup quota of {quota:g} CPUs ({os.cpu_count()} visible)" if quota else
+                  f"{best['threads']} threads, {os.cpu_count()} CPUs visible, no cgroup quota")
+    short = "C+OpenMP AVX-512 sgemm+k-best twin" if "lvs_blas_twin.c" in best["impl"] else "torch-CPU MKL sgemm+topk"
+    out = {"value": best["queries_per_s"], "unit": "queries/s", "cores": cores, "cores_note": cores_note, "kind": "port",
+           "sample": f"first {best['queries']} queries x full {xb32.shape[0]}-row corpus, {short}, {best['seconds']:.1f} s",
+           "gflops": best["gflops"], "threads": best["threads"], "host_cpus": os.cpu_count(), "host_cpu_quota": quota,
+           "comparators_timed": runs}
     if "gpu_parity" in best:
         out["gpu_parity_on_the_timed_sample"] = best["gpu_parity"]
     return out
@@ -370,8 +435,7 @@ def _kernel_leg(ctx, cb, cq, reps, kk=None, id_offset=0):
 def _mfma_leg(ctx, cb, cq, reps, **extra):
     kms, wms, _ = _kernel_leg(ctx, cb, cq, reps)
     fl = 2.0 * cq.n * cb.n * ctx["d"]
-    leg = {"kernel_ms": kms, "ms_per_call": wms, "bound": "mfma", "achieved_tflops": fl / (kms * 1e-3) / 1e12,
-           "frac": fl / (kms * 1e-3) / 1e12 / PEAK_FP16_MFMA_TFLOPS}
+    leg = {"kernel_ms": kms, "ms_per_call": wms, "bound": "mfma", "frac": fl / (kms * 1e-3) / 1e12 / PEAK_FP16_MFMA_TFLOPS}
     leg.update(extra)
     return leg
 
@@ -384,76 +448,84 @@ def search_legs(ctx, legs):
     leg["queries_per_s"] = q10k.n / (leg["ms_per_call"] * 1e-3)
     legs["cfg2_10k_x_1M"] = leg
     # the HBM-bound regime: the literal sem_search issues ONE query per call (sem_search.py:121-122); small sim-joins and the
-    # K-doubling loop send a few dozen to a few hundred.  Every corpus byte exactly once = the algorithmic bytes.
+    # K-doubling loop send a few dozen to a few hundred.  Every corpus byte exactly once = the algorithmic bytes (1.536 GB).
     by = corpus.n * int(corpus.rows.shape[1]) * 2.0
     for nq_small in (1, 32, 64, 96, 128, 192, 256):
         if nq_small > queries.n:
             continue
         qs = be.slice_rows(queries, 0, nq_small)
         kms, wms, _ = _kernel_leg(ctx, corpus, qs, 20)
-        name = "sem_search_1_x_1M" if nq_small == 1 else f"small_batch_{nq_small}_x_1M"
-        legs[name] = {"kernel_ms": kms, "ms_per_call": wms, "bound": "hbm", "achieved_gbs": by / (kms * 1e-3) / 1e9,
-                      "frac": by / (kms * 1e-3) / 1e9 / PEAK_HBM_GBS, "algorithmic_bytes_per_launch": by,
-                      "mfma_frac_secondary": 2.0 * nq_small * corpus.n * ctx["d"] / (kms * 1e-3) / 1e12 / PEAK_FP16_MFMA_TFLOPS}
+        legs[f"q{nq_small}"] = {"kernel_ms": kms, "ms_per_call": wms, "bound": "hbm", "frac": by / (kms * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                                "mfma_frac_secondary": 2.0 * nq_small * corpus.n * ctx["d"] / (kms * 1e-3) / 1e12 / PEAK_FP16_MFMA_TFLOPS}
     # between the two regimes: a few query tiles x many corpus slabs - the list kernel with thresholds seeded from a sample
-    # (r3; every slab used to start cold)
     for nq_mid in (512, 1024, 4096):
         if nq_mid <= queries.n:
-            leg = _mfma_leg(ctx, corpus, be.slice_rows(queries, 0, nq_mid), 10)
-            leg["queries_per_s"] = nq_mid / (leg["ms_per_call"] * 1e-3)
-            legs[f"batch_{nq_mid}_x_1M"] = leg
+            legs[f"q{nq_mid}"] = _mfma_leg(ctx, corpus, be.slice_rows(queries, 0, nq_mid), 10)
 
 
 def node_plan_legs(ctx, legs):
     """What ONE of 8 GPUs does under every (query groups x corpus shards) split of the same 100k x 1M join, measured here
-    on one GPU: gq x gc = 1 x 8 (BASELINE's row split), 2 x 4, 4 x 2, 8 x 1 (the query split).  The node's kernel-side
-    ceiling is Q / (per-GPU kernel time); `HipVS(shard=(gq, gc))` runs any of them, `lotus_amd.plan.pick_split` chooses."""
+    on one GPU with the shard's OWN sample thresholds: gq x gc = 1 x 8 (BASELINE's row split), 2 x 4, 4 x 2, 8 x 1 (the query
+    split).  The node's kernel-side ceiling is Q / (per-GPU kernel time); `HipVS(shard=(gq, gc))` runs any of them,
+    `lotus_amd.plan.pick_split` chooses.  (world8_rehearsal runs the row split with the POOLED thresholds of all shards.)"""
     be, corpus, queries, d = ctx["be"], ctx["corpus"], ctx["queries"], ctx["d"]
     plan = {}
     for gq, gc in ((1, 8), (2, 4), (4, 2), (8, 1)):
         rows, qn = -(-corpus.n // gc), -(-queries.n // gq)
         leg = _mfma_leg(ctx, be.slice_rows(corpus, 0, rows), be.slice_rows(queries, 0, qn), 3 if rows * qn > 2e10 else 5)
-        leg["per_gpu_shape"] = f"{qn} x {rows}"
-        leg["node_queries_per_s_if_8_gpus"] = queries.n / (leg["kernel_ms"] * 1e-3)
+        leg["shape"] = f"{qn}x{rows}"
+        leg["node_qps_if_8_gpus"] = queries.n / (leg["kernel_ms"] * 1e-3)
+        del leg["bound"]
         plan[f"{gq}x{gc}"] = leg
-    best = max(plan, key=lambda s: plan[s]["node_queries_per_s_if_8_gpus"])
-    legs["node_plan_8gpu"] = {"splits_query_groups_x_corpus_shards": plan, "best_split": best,
-                              "best_projected_node_queries_per_s": plan[best]["node_queries_per_s_if_8_gpus"],
-                              "mfma_floor_node_queries_per_s": 8 * PEAK_FP16_MFMA_TFLOPS * 1e12 / (2.0 * corpus.n * d),
-                              "note": "kernel side only: the all-gather of 8 MB of keys per rank and the merge come on top "
-                                      "(see world8_rehearsal for the merge)"}
+    best = max(plan, key=lambda s: plan[s]["node_qps_if_8_gpus"])
+    legs["node_plan_8gpu"] = {"splits": plan, "best_split": best, "best_node_qps": plan[best]["node_qps_if_8_gpus"],
+                              "mfma_floor_node_qps": 8 * PEAK_FP16_MFMA_TFLOPS * 1e12 / (2.0 * corpus.n * d),
+                              "note": "kernel side only: the all-gathers and the merge come on top (world8_rehearsal)"}
     # the N = 2 / 4 shapes of the row split the driver's scaling run uses
     for rows, ng in ((500_000, 2), (250_000, 4)):
         if rows <= corpus.n:
             leg = _mfma_leg(ctx, be.slice_rows(corpus, 0, rows), queries, 3)
-            leg[f"node_queries_per_s_if_{ng}_gpus"] = queries.n / (leg["kernel_ms"] * 1e-3)
+            leg[f"node_qps_if_{ng}_gpus"] = queries.n / (leg["kernel_ms"] * 1e-3)
             legs[f"shard_100k_x_{rows // 1000}k"] = leg
 
 
 def world8_rehearsal(ctx, legs, checks):
-    """The device-side half of the 8-GPU run at full size, on one GPU: all eight shards of the corpus are searched in turn
-    with their REAL id offsets, the eight [Q, k] key lists are merged with lvs_merge_keys exactly as after the RCCL
-    all-gather, and the merged result is compared with the single-launch result (bit for bit: keys are a total order) and
-    with the CPU oracle."""
+    """The device-side half of the 8-GPU run at full size, on one GPU, exactly as bench.py's N = 8 step / HipVS(shard=True)
+    run it: every shard scores its sample tiles (lvs_flat_search_seed_scores), the eight blocks are laid side by side as the
+    all-gather would, all eight shards are searched in turn with those POOLED starting thresholds and their REAL id offsets,
+    and the eight [Q, k] key lists are merged with lvs_merge_keys.  The merged result is compared with the single-launch
+    result (bit for bit: keys are a total order) and with the CPU oracle.  The same eight searches with each shard's own
+    sample thresholds are timed beside it."""
     np, torch, be, _capi = ctx["np"], ctx["torch"], ctx["be"], ctx["_capi"]
     corpus, queries, k = ctx["corpus"], ctx["queries"], ctx["k"]
     W = 8
     per = -(-corpus.n // W)
     bounds = [(min(corpus.n, r * per), min(corpus.n, (r + 1) * per)) for r in range(W)]
+    shards = [be.slice_rows(corpus, lo, hi) for lo, hi in bounds]
+    tiles = be.seed_tiles(queries.n, per, k, corpus.mode, queries.mode)
 
-    def run():
-        parts = []
-        for lo, hi in bounds:
-            parts.append(be.search_keys(be.slice_rows(corpus, lo, hi), queries, k, _capi.METRIC_IP, id_offset=lo))
-        return torch.stack(parts)
+    def pooled():
+        return torch.cat([be.seed_scores(sh, queries, _capi.METRIC_IP, tiles) for sh in shards]) if tiles else None
 
-    run()
-    be.synchronize()
-    be.timing_enable(True)
-    parts = run()
-    be.synchronize()
-    ktot, kcnt = be.timing_read()
-    be.timing_enable(False)
+    def run(seeds):
+        return torch.stack([be.search_keys(sh, queries, k, _capi.METRIC_IP, id_offset=lo, seed_scores=seeds)
+                            for sh, (lo, _) in zip(shards, bounds)])
+
+    res = {}
+    for tag in ("own", "pooled"):
+        run(pooled() if tag == "pooled" else None)
+        be.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        seeds = pooled() if tag == "pooled" else None
+        e1.record()
+        be.timing_enable(True)
+        parts = run(seeds)
+        be.synchronize()
+        ktot, kcnt = be.timing_read()
+        be.timing_enable(False)
+        res[tag] = (ktot / max(kcnt, 1), e0.elapsed_time(e1) / W, parts)
+    shard_ms, seed_ms, parts = res["pooled"]
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     be.merge_keys(parts)
     e0.record()
@@ -463,14 +535,20 @@ def world8_rehearsal(ctx, legs, checks):
     be.synchronize()
     merge_ms = e0.elapsed_time(e1) / 5
     same = bool(torch.equal(merged, ctx["keys"]))
-    shard_ms = ktot / max(kcnt, 1)
+    same_own = bool(torch.equal(be.merge_keys(res["own"][2]), ctx["keys"]))
     D, I = be.keys_to_result(merged, _capi.METRIC_IP)
     sample = min(ctx["args"].check_sample, queries.n)
     D_h, I_h = D[:sample].cpu().numpy(), I[:sample].cpu().numpy()
-    leg = {"shards": W, "shard_rows": per, "sum_kernel_ms": ktot, "kernel_ms_per_shard": shard_ms, "merge_ms": merge_ms,
-           "merged_equals_single_gpu_keys": same, "ids_from_every_shard": int(torch.unique(I // per).numel()),
-           "projected_node_queries_per_s": queries.n / ((shard_ms + merge_ms) * 1e-3),
-           "note": "projection = Q / (mean per-shard kernel + 8-way merge); the 64 MB all-gather over xGMI (~0.1 ms) is not in it"}
+    fl = 2.0 * queries.n * per * ctx["d"]
+    leg = {"shards": W, "shard_rows": per, "seed_tiles_per_shard": tiles, "kernel_ms_per_shard": shard_ms,
+           "frac": fl / (shard_ms * 1e-3) / 1e12 / PEAK_FP16_MFMA_TFLOPS, "seed_pass_ms_per_shard": seed_ms,
+           "kernel_ms_per_shard_own_seeds": res["own"][0], "merge_ms": merge_ms,
+           "merged_equals_single_gpu_keys": same, "own_seeds_merged_equals_single_gpu_keys": same_own,
+           "short_lists_slots": int((parts == 0).sum().item()),
+           "ids_from_every_shard": int(torch.unique(I // per).numel()),
+           "projected_node_qps": queries.n / ((shard_ms + seed_ms + merge_ms) * 1e-3),
+           "note": "projection = Q / (sample pass + per-shard kernel + 8-way merge); the two all-gathers over xGMI (4 MB of "
+                   "sample scores and 8 MB of keys per rank) are not in it"}
     legs["world8_rehearsal"] = leg
     if sample > 0:
         checks.append(lambda: leg.update({"oracle_" + a: b for a, b in
@@ -492,7 +570,7 @@ def fp32_leg(ctx, legs):
     xq += 1e-4 * torch.randn(xq.shape, generator=g, device=dev)
     q32 = be.pack(torch.nn.functional.normalize(xq, dim=1), _capi.PACK_SPLIT)
     res32, got = {}, {}
-    for tag, one_pass in (("plain_3_segments", False), ("one_pass_certified", True)):
+    for tag, one_pass in (("plain_3seg", False), ("one_pass", True)):
         stats = {}
         for _ in range(2):
             be.search_keys(c32, q32, k, _capi.METRIC_IP, one_pass=one_pass)
@@ -501,19 +579,20 @@ def fp32_leg(ctx, legs):
         for _ in range(3):
             got[tag] = be.search_keys(c32, q32, k, _capi.METRIC_IP, one_pass=one_pass, stats=stats)
         be.synchronize()
-        ms = (time.perf_counter() - t0) / 3 * 1e3
-        res32[tag] = {"ms_per_call": ms, "algorithmic_tflops": 2.0 * q32.n * c32.n * d / (ms * 1e-3) / 1e12}
+        res32[tag + "_ms"] = (time.perf_counter() - t0) / 3 * 1e3
         if one_pass:
-            res32[tag]["uncertified_fraction"] = stats["uncertified"] / max(1, stats["queries"])
-    _, Ia = be.keys_to_result(got["plain_3_segments"], _capi.METRIC_IP)
-    _, Ib = be.keys_to_result(got["one_pass_certified"], _capi.METRIC_IP)
+            res32["uncertified_fraction"] = stats["uncertified"] / max(1, stats["queries"])
+    _, Ia = be.keys_to_result(got["plain_3seg"], _capi.METRIC_IP)
+    _, Ib = be.keys_to_result(got["one_pass"], _capi.METRIC_IP)
     res32["one_pass_ids_equal_plain"] = float((Ia == Ib).float().mean().item())
-    legs["fp32_embeddings_10k_x_1M"] = res32
+    res32["fp16_same_shape_ms"] = (legs.get("cfg2_10k_x_1M") or {}).get("ms_per_call")
+    legs["fp32_10k_x_1M"] = res32
 
 
 def t_call_leg(ctx, legs):
     """T_call: VS.__call__(host ndarray) -> host (D, I), corpus resident; includes packing the queries,
-    the H2D copy of 154 MB and the D2H copy of the results."""
+    the H2D copy of 154 MB and the D2H copy of the results.  Reported beside `value`, never as `value`: the bench contract
+    times device-resident inputs."""
     from lotus_amd.vs import HipVS, _Resident
 
     be, corpus, xq_h, k, d = ctx["be"], ctx["corpus"], ctx["xq_h"], ctx["k"], ctx["d"]
@@ -529,7 +608,10 @@ def t_call_leg(ctx, legs):
         ts.append(time.perf_counter() - t0)
     tcall = sorted(ts)[len(ts) // 2]
     assert out.indices.shape == (xq_h.shape[0], k)
+    same = bool((ctx["torch"].from_numpy(out.indices[:4096]).to(ctx["keys"].device) ==
+                 be.keys_to_result(ctx["keys"][:4096], ctx["_capi"].METRIC_IP)[1]).all().item())
     legs["t_call_host_to_host"] = {"ms_per_call": tcall * 1e3, "queries_per_s": xq_h.shape[0] / tcall,
+                                   "same_ids_as_the_timed_step": same,
                                    "note": "HipVS.__call__(numpy fp16 [Q,d]) -> numpy (D, I); PCIe and packing included; "
                                            "median of 5"}
 
@@ -557,8 +639,7 @@ def dedup_leg(ctx, legs, checks, fut):
     be.timing_enable(False)
     del pk
     leg = {"rows": n, "threshold": tau, "seconds": dt, "kernel_seconds": ktot * 1e-3, "kernel_launches": kcnt,
-           "pairs": int(len(i)), "bound": "mfma",
-           "algorithmic_flops": 1.0 * n * n * d, "achieved_tflops": n * n * d / (ktot * 1e-3) / 1e12,
+           "pairs": int(len(i)), "bound": "mfma", "algorithmic_flops": 1.0 * n * n * d,
            "frac": n * n * d / (ktot * 1e-3) / 1e12 / PEAK_FP16_MFMA_TFLOPS,
            "note": "algorithmic flops = N^2 d (each unordered pair once; only the upper triangle is computed); "
                    "kernel_seconds = sum of the tile kernel's launches (HIP events)"}
@@ -609,9 +690,10 @@ def kmeans_legs(ctx, legs, checks, fut):
     """BASELINE configs[4]: k-means K = 1024 on 10 M rows, d = 768 (fp16 points, fp32-accurate centroids).
     (i) full-data mode: every row every iteration (what BASELINE's wording implies) - per-iteration time from the slope
     between runs of different lengths; (ii) faiss-parity mode: what the reference does (utils.py:61-65): faiss subsamples
-    K * 256 = 262 144 training rows, 20 iterations, then assigns all rows.  In-run checks: train ids, objective and
-    centroids of (ii) against oracle.kmeans_faiss on the same rows, and the final assignment of a row sample against a
-    brute-force float32 nearest-centroid search."""
+    K * 256 = 262 144 training rows, 20 iterations, then assigns all rows.  In-run checks: train ids and the trajectory of
+    (ii) against oracle.kmeans_faiss on the same rows, iteration by iteration (identical assignments and bit-identical
+    centroids up to the first differing iteration, whose differing rows must all be near-ties), and the final assignment of
+    a row sample against a brute-force float32 nearest-centroid search."""
     np, be, _capi, d, args = ctx["np"], ctx["be"], ctx["_capi"], ctx["d"], ctx["args"]
     from lotus_amd.cluster import kmeans
 
@@ -629,6 +711,13 @@ def kmeans_legs(ctx, legs, checks, fut):
            "objective_first_last": [float(r.obj[0]), float(r.obj[-1])], "empty_clusters_reseeded": int(r.nsplit.sum()),
            "blob_purity": _purity(np, r.assign, labels, K)}
     legs["kmeans_parity_mode"] = par
+    # the first iterations once more with every iteration's centroids and assignment kept (same run: the loop is deterministic)
+    NIT_CMP = 6
+    tr = []
+    rt = kmeans(None, K, niter=NIT_CMP, backend=be, packed=pk, final_assign=False, trace=tr)
+    tr_host = [{"centroids": t["centroids"].cpu().numpy(),
+                "assign": be.keys_to_result(t["keys"], _capi.METRIC_L2)[1].reshape(-1).cpu().numpy()} for t in tr]
+    del tr
     # (i) full-data mode, exhaustive: every row searched every iteration.  Slope between niter = 2 and niter = 6 (set-up -
     # the init permutation, centroid unpack - cancels)
     kw = dict(backend=be, packed=pk, max_points_per_centroid=None, final_assign=False)
@@ -644,7 +733,7 @@ def kmeans_legs(ctx, legs, checks, fut):
     fl = 2.0 * n * K * d
     legs["kmeans_full_iter_10M_x_1024"] = {
         "rows": n, "k": K, "ms_per_iteration": per_iter * 1e3, "bound": "mfma", "algorithmic_flops_per_iteration": fl,
-        "achieved_tflops": fl / per_iter / 1e12, "frac": fl / per_iter / 1e12 / PEAK_FP16_MFMA_TFLOPS,
+        "frac": fl / per_iter / 1e12 / PEAK_FP16_MFMA_TFLOPS,
         "uncertified_fraction": stats.get("uncertified", 0) / max(1, stats.get("queries", 0)),
         "objective_decreasing": bool(np.all(np.diff(rf.obj) <= 1e-6 * np.abs(rf.obj[:-1]))),
         "objective": [float(v) for v in rf.obj],
@@ -660,9 +749,10 @@ def kmeans_legs(ctx, legs, checks, fut):
     rb = kmeans(None, K, niter=20, stats=st2, bounds=True, **kw)
     be.synchronize()
     t_b = time.perf_counter() - t0
-    legs["kmeans_full_data_20_iters_exact_bounds"] = {
+    legs["kmeans_bounds_20_iters"] = {
         "rows": n, "k": K, "seconds": t_b, "ms_per_iteration_mean": t_b / 20 * 1e3,
         "searched_row_fraction_per_iteration": [round(v / n, 4) for v in st2.get("searched_rows", [])],
+        "searched_row_fraction_mean": float(np.mean(st2.get("searched_rows", [n]))) / n,
         "first_objectives_equal_exhaustive": bool(np.array_equal(rb.obj[:6], rf.obj[:6])),
         "objective_last": float(rb.obj[-1]), "empty_clusters_reseeded": int(rb.nsplit.sum()),
         "note": "Hamerly distance bounds (lvs_kmeans_bounds_step): same assignments, sums, centroids and objectives as the "
@@ -679,29 +769,37 @@ def kmeans_legs(ctx, legs, checks, fut):
         rows = rng.integers(0, n, 65536)
         _, Ir = oracle.flat_search(r.centroids, x_h[rows].astype(np.float32), 1, 1)
         par["final_assign_agreement_sample"] = float((Ir[:, 0] == r.assign[rows]).mean())
-        # (b) the training trajectory against oracle.kmeans_faiss on the same 262 144 rows.  On blob data dozens of clusters
-        # run empty early and faiss's split_clusters re-seeds them from an RNG walk over the cluster sizes: a single row
-        # flipping on a near-tie (SURVEY.md 8(c) allows 1e-4) can shift that stream, after which the two runs follow
-        # different, equally valid paths - so objectives are compared over the common prefix of split decisions
+        # (b) the training trajectory against oracle.kmeans_faiss on the same 262 144 rows, iteration by iteration.  Lloyd's
+        # iteration at K = 1024 is chaotic (one row flipping on a float32 near-tie moves two centroids, and on blob data can
+        # shift faiss's split_clusters RNG walk), so what is required is: identical assignments, bit-identical centroids,
+        # equal split counts and objectives up to the first iteration in which any row differs - and THERE every differing
+        # row must be a near-tie (its two candidate distances within 2e-5 relative in the oracle's arithmetic)
         want_ids = oracle.rand_perm(n, 1234)[:K * 256] if n > K * 256 else np.arange(n)
         par["train_ids_equal_oracle"] = bool(np.array_equal(r.train_ids, want_ids))
-        nit = 4
         try:
             from threadpoolctl import threadpool_limits
             lim = threadpool_limits(limits=min(64, os.cpu_count() or 1))
         except Exception:
             lim = None
-        ref = oracle.kmeans_faiss(x_h[r.train_ids].astype(np.float32), K, niter=nit, final_assign=False)
+        trace = []
+        xt32 = x_h[r.train_ids].astype(np.float32)
+        ref = oracle.kmeans_faiss(xt32, K, niter=NIT_CMP, final_assign=False, trace=trace, max_points_per_centroid=1 << 30)
         if lim is not None:
             lim.restore_original_limits()
-        same = np.asarray(r.nsplit[:nit]) == np.asarray(ref.nsplit)
-        pre = int(nit if same.all() else np.argmin(same))
-        par["oracle_iterations"] = nit
-        par["split_counts"] = [int(v) for v in r.nsplit[:nit]]
+        par["oracle_iterations"] = NIT_CMP
+        par["split_counts"] = [int(v) for v in rt.nsplit[:NIT_CMP]]
         par["oracle_split_counts"] = [int(v) for v in ref.nsplit]
-        par["common_prefix_iterations"] = pre
-        par["objective_max_rel_err_on_prefix"] = float(np.max(np.abs(r.obj[:pre] - ref.obj[:pre]) / np.abs(ref.obj[:pre]))) if pre else None
-        par["oracle_seconds"] = time.perf_counter() - t0
+        first, flips, near, gap, same_c, obj_err = None, 0, True, 0.0, True, 0.0
+        for it in range(NIT_CMP):
+            same_c &= bool(np.array_equal(tr_host[it]["centroids"], trace[it]["centroids"]))
+            obj_err = max(obj_err, abs(float(rt.obj[it]) / float(ref.obj[it]) - 1))
+            fl_ = oracle.flipped_rows(xt32, trace[it]["centroids"], tr_host[it]["assign"], trace[it]["assign"])
+            if len(fl_["rows"]):
+                first, flips, near, gap = it, int(len(fl_["rows"])), bool(fl_["all_near_ties"]), float(fl_["gaps"].max())
+                break
+        par.update({"first_divergence_iteration": first, "flipped_rows": flips, "all_flips_are_near_ties": near,
+                    "max_flip_rel_gap": gap, "centroids_bit_identical_until_divergence": same_c,
+                    "objective_max_rel_err_until_divergence": obj_err, "oracle_seconds": time.perf_counter() - t0})
 
     checks.append(check)
 

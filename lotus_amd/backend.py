@@ -41,10 +41,13 @@ class HipBackend:
         self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
         self._ws = None
         # host -> device staging (see _h2d): a pinned buffer, a copy stream and a few threads that fill the buffer
-        self._stage_buf = None
-        self._stage_done = None
+        self._stage_buf = None   # pinned ring [H2D_SLOTS, H2D_SLICE_BYTES]; False: pinning failed, plain copies
+        self._stage_done = None  # per ring slot: event of the last DMA that read it
         self._copy_stream = None
         self._pool = None
+        import threading
+
+        self._h2d_lock = threading.Lock()
 
     # ---- plumbing ----
     def _stream(self) -> int:
@@ -69,51 +72,92 @@ class HipBackend:
 
     # ---- host <-> device transfers at the boundary (VS.__call__ hands over host ndarrays, faiss_vs.py:43-77) ----
     H2D_SLICE_BYTES = 16 << 20
+    H2D_SLOTS = 4       # pinned ring: H2D_SLOTS x H2D_SLICE_BYTES = 64 MB whatever the matrix (a pack chunk may be GBs)
     H2D_THREADS = 4
 
-    def _h2d(self, c: np.ndarray):
-        """Device copy of a C-contiguous float16 / float32 host matrix.  A pageable ndarray reaches the GPU through a
-        pinned staging buffer either way; doing that staging here, in slices - a few threads copy slice i + 1 into the
-        pinned buffer (numpy releases the GIL) while the DMA engine moves slice i on a side stream - makes the transfer
-        run at the slower of (multi-threaded memcpy, PCIe) instead of a single-threaded memcpy followed by the DMA:
-        154 MB of queries in ~4 ms instead of ~15-25.  The compute stream waits on an event; the host does not wait."""
+    def _h2d_ring(self):
+        """The pinned staging ring, its copy stream and thread pool (created once; None when pinning fails - e.g. under a
+        container's memlock limit - and the plain ``.to()`` path is used from then on)."""
         torch = self.torch
-        nbytes = int(c.nbytes)
-        if nbytes < (4 << 20) or c.ndim != 2:
-            if not c.flags.writeable:  # a read-only memory map (store.py): the host view is only read by the copy
-                import warnings
-
-                with warnings.catch_warnings():
-                    warnings.simplefilter("ignore", UserWarning)
-                    return torch.from_numpy(c).to(self.device)
-            return torch.from_numpy(c).to(self.device)
-        tdt = torch.float16 if c.dtype == np.float16 else torch.float32
-        if self._pool is None:
+        if self._stage_buf is False:
+            return None
+        if self._stage_buf is None:
+            try:
+                self._stage_buf = torch.empty((self.H2D_SLOTS, self.H2D_SLICE_BYTES), dtype=torch.uint8, pin_memory=True)
+            except Exception:  # cannot page-lock: fall back for good
+                self._stage_buf = False
+                return None
             from concurrent.futures import ThreadPoolExecutor
 
             self._pool = ThreadPoolExecutor(self.H2D_THREADS)
             self._copy_stream = torch.cuda.Stream(device=self.device)
-        if self._stage_done is not None:  # the previous transfer still reads the staging buffer
-            self._stage_done.synchronize()
-        if self._stage_buf is None or self._stage_buf.numel() < nbytes:
-            self._stage_buf = torch.empty(max(nbytes, 64 << 20), dtype=torch.uint8, pin_memory=True)
-        stage_t = self._stage_buf[:nbytes].view(tdt).reshape(c.shape)
-        stage_np = stage_t.numpy()
-        dev = torch.empty(c.shape, dtype=tdt, device=self.device)
-        rows = int(c.shape[0])
-        per = max(1, self.H2D_SLICE_BYTES // max(1, int(c.shape[1]) * c.itemsize))
+            self._stage_done = [None] * self.H2D_SLOTS
+        return self._stage_buf
+
+    def _h2d(self, c: np.ndarray, out=None, after=None):
+        """``out`` / ``after``: copy into this preallocated device tensor, the side stream waiting for the event ``after``
+        (recorded when ``out`` was allocated) instead of for everything queued on the compute stream - a transfer that must
+        overlap a search already in flight (``search_host_pipelined``).
+
+        Device copy of a C-contiguous float16 / float32 host matrix.  A pageable ndarray reaches the GPU through a
+        pinned staging buffer either way; doing that staging here, in 16 MB slices through a small ring - a few threads copy
+        the next slices into free ring slots (numpy releases the GIL) while the DMA engine moves the finished ones on a side
+        stream - makes the transfer run at the slower of (multi-threaded memcpy, PCIe) instead of a single-threaded memcpy
+        followed by the DMA: 154 MB of queries in ~4 ms instead of ~15-25.  The compute stream waits on an event.  The ring
+        is bounded (64 MB) and guarded by a lock: two threads sharing a backend take turns."""
+        torch = self.torch
+        nbytes = int(c.nbytes)
+        ring = None
+        if nbytes >= (4 << 20) and c.ndim == 2 and int(c.shape[1]) * c.itemsize <= self.H2D_SLICE_BYTES:
+            ring = self._h2d_ring()
+        if ring is None:
+            import warnings
+
+            with warnings.catch_warnings():  # a read-only memory map (store.py): the host view is only read by the copy
+                warnings.simplefilter("ignore", UserWarning)
+                t = torch.from_numpy(c)
+            if out is not None:
+                out.copy_(t)
+                return out
+            return t.to(self.device)
+        tdt = torch.float16 if c.dtype == np.float16 else torch.float32
+        rows, row_bytes = int(c.shape[0]), int(c.shape[1]) * c.itemsize
+        per = max(1, self.H2D_SLICE_BYTES // row_bytes)
         bounds = [(a, min(rows, a + per)) for a in range(0, rows, per)]
-        futs = [self._pool.submit(np.copyto, stage_np[a:b], c[a:b]) for a, b in bounds]
-        cur = torch.cuda.current_stream(self.device)
-        cs = self._copy_stream
-        cs.wait_stream(cur)  # `dev` was allocated on the compute stream
-        with torch.cuda.stream(cs):
-            for (a, b), f in zip(bounds, futs):
-                f.result()
-                dev[a:b].copy_(stage_t[a:b], non_blocking=True)
-            self._stage_done = cs.record_event()
-        dev.record_stream(cs)
-        cur.wait_event(self._stage_done)
+        with self._h2d_lock:
+            dev = out if out is not None else torch.empty(c.shape, dtype=tdt, device=self.device)
+            cur = torch.cuda.current_stream(self.device)
+            cs = self._copy_stream
+            if out is not None and after is not None:
+                cs.wait_event(after)
+            else:
+                cs.wait_stream(cur)  # `dev` was allocated on the compute stream
+            slots = [ring[i][:per * row_bytes].view(tdt).reshape(per, int(c.shape[1])) for i in range(self.H2D_SLOTS)]
+            slots_np = [t.numpy() for t in slots]
+            pending, nxt = [], 0
+
+            def submit():  # keep up to H2D_SLOTS host copies in flight; a slot is reused once its previous DMA has finished
+                nonlocal nxt
+                while nxt < len(bounds) and len(pending) < self.H2D_SLOTS:
+                    slot = nxt % self.H2D_SLOTS
+                    if self._stage_done[slot] is not None:
+                        self._stage_done[slot].synchronize()
+                    a, b = bounds[nxt]
+                    pending.append((nxt, self._pool.submit(np.copyto, slots_np[slot][:b - a], c[a:b])))
+                    nxt += 1
+
+            last = None
+            with torch.cuda.stream(cs):
+                while nxt < len(bounds) or pending:
+                    submit()
+                    i, f = pending.pop(0)
+                    f.result()
+                    a, b = bounds[i]
+                    dev[a:b].copy_(slots[i % self.H2D_SLOTS][:b - a], non_blocking=True)
+                    last = self._stage_done[i % self.H2D_SLOTS] = cs.record_event()
+            dev.record_stream(cs)
+            if last is not None:
+                cur.wait_event(last)
         return dev
 
     def to_host(self, *tensors):
@@ -127,6 +171,54 @@ class HipBackend:
             outs.append(h)
         torch.cuda.current_stream(self.device).synchronize()
         return tuple(h.numpy() for h in outs)
+
+    CALL_PIPELINE_MIN_QUERIES = 32768
+    CALL_PIPELINE = (0.2, 0.8)  # shares of the queries per stage: a short first stage (its H2D is the exposed one)
+
+    def search_host_pipelined(self, corpus: PackedRows, q: np.ndarray, k: int, metric: int, id_offset: int = 0,
+                              normalize: bool = False, exp: int = 0):
+        """``VS.__call__`` for a large host query matrix (faiss_vs.py:75): the queries go through in two stages so that the
+        host -> device copy of the second overlaps the search of the first and the device -> host copy of the first stage's
+        results overlaps the search of the second (results are per query: staging is exact).  Only the first stage's H2D
+        and the last stage's D2H are exposed.  -> (D float32 [nq,k], I int64 [nq,k] pinned-backed numpy arrays, flag word)."""
+        torch = self.torch
+        nq, d = int(q.shape[0]), int(q.shape[1])
+        cuts = [0]
+        for share in self.CALL_PIPELINE[:-1]:
+            cuts.append(min(nq, (int(nq * share) + cuts[-1] + 255) // 256 * 256))
+        cuts.append(nq)
+        stages = [(a, b) for a, b in zip(cuts[:-1], cuts[1:]) if b > a]
+        tdt = torch.float16 if q.dtype == np.float16 else torch.float32
+        cur = torch.cuda.current_stream(self.device)
+        # every stage's device buffer exists before the first search is queued: its copy need not wait for that search
+        bufs = [torch.empty((b - a, d), dtype=tdt, device=self.device) for a, b in stages]
+        allocated = cur.record_event()
+        if getattr(self, "_d2h_stream", None) is None:
+            self._d2h_stream = torch.cuda.Stream(device=self.device)
+        Dh = torch.empty((nq, k), dtype=torch.float32, pin_memory=True)
+        Ih = torch.empty((nq, k), dtype=torch.int64, pin_memory=True)
+        flags = torch.zeros((1,), dtype=torch.int32, device=self.device)
+        mode = corpus.mode
+        for (a, b), buf in zip(stages, bufs):
+            c = np.ascontiguousarray(q[a:b], dtype=np.float16 if q.dtype == np.float16 else np.float32)
+            self._h2d(c, out=buf, after=allocated)
+            queries = self.pack(buf, mode, normalize=normalize, exp=exp, check="lazy")
+            if queries.flags is not None:
+                flags |= queries.flags
+            keys = self.search_keys(corpus, queries, k, metric, id_offset=id_offset)
+            Dd, Id = self.keys_to_result(keys, metric, None, score_exp=self.score_exp_of(corpus, queries))
+            done = cur.record_event()
+            with torch.cuda.stream(self._d2h_stream):
+                self._d2h_stream.wait_event(done)
+                Dh[a:b].copy_(Dd, non_blocking=True)
+                Ih[a:b].copy_(Id, non_blocking=True)
+            Dd.record_stream(self._d2h_stream)
+            Id.record_stream(self._d2h_stream)
+        fh = torch.empty((1,), dtype=torch.int32, pin_memory=True)
+        fh.copy_(flags, non_blocking=True)
+        cur.synchronize()
+        self._d2h_stream.synchronize()
+        return Dh.numpy(), Ih.numpy(), int(fh[0])
 
     # ---- packing ----
     SCALE_TARGET_EXP = 6  # exp="auto": the largest |x| lands in [2^6, 2^7) - components ~10x smaller still have their lo half

@@ -33,7 +33,8 @@ class KMeansResult:
 def kmeans(x, k: int, niter: int = 20, seed: int = 1234, max_points_per_centroid: int | None = 256, backend=None,
            pack_mode: int | None = None, packed=None, shard: bool = False, process_group=None,
            final_assign: bool = True, centroid_precision: str = "fp32", n_total: int | None = None,
-           local_pos=None, stats: dict | None = None, bounds: bool | None = None) -> KMeansResult:
+           local_pos=None, stats: dict | None = None, bounds: bool | None = None,
+           trace: list | None = None) -> KMeansResult:
     """faiss-parity k-means (``faiss.Kmeans(d, k, niter).train(x)`` + ``index.search(x, 1)``, ``lotus/utils.py:61-65``).
 
     ``x``: host matrix [n,d] (float16/32/64) and/or ``packed``: its device image.  Everything after the packing runs
@@ -58,6 +59,9 @@ def kmeans(x, k: int, niter: int = 20, seed: int = 1234, max_points_per_centroid
         assigns the rows it holds.
       Either way one all-reduce of the ``[k,d]`` sums, ``[k]`` counts and the objective per iteration, and one
       all-gather of the final cluster ids; nothing else crosses the ranks.
+
+    ``trace`` (a list, optional; parity tooling): one dict per iteration with device copies of the centroids the iteration
+    assigned against (``centroids``, float32 [k,d], the rows' scaled domain) and of the assignment's result keys (``keys``).
 
     ``centroid_precision="fp32"`` (default) keeps the centroids fp32-accurate on the device (fp16 hi|lo pair) as
     faiss does, whatever the storage of the points; ``"fp16"`` rounds them to fp16 (half the MFMA work when the
@@ -176,6 +180,8 @@ def kmeans(x, k: int, niter: int = 20, seed: int = 1234, max_points_per_centroid
                 if stats is not None:
                     stats.setdefault("searched_rows", []).append(searched)
                 c_old = centroids.clone()
+            if trace is not None:
+                trace.append({"centroids": centroids.clone(), "keys": keys.clone()})
             sums, counts = be.kmeans_accumulate_keys(train, keys, k)
             # ... because the objective (faiss: sum of the assignment distances) follows from the sums the update needs
             # anyway:  sum_i |x_i - c_a(i)|^2 = sum_i |x_i|^2 - 2 sum_j c_j . S_j + sum_j n_j |c_j|^2   (float64, [k,d])

@@ -49,6 +49,17 @@ class _Resident:
     sig: Any = None  # store.signature() of the directory when it was loaded (None: never persisted)
 
 
+def _serialised(fn):
+    import functools
+
+    @functools.wraps(fn)
+    def run(self, *a, **k):
+        with self._lock:
+            return fn(self, *a, **k)
+
+    return run
+
+
 class HipVS(VS):
     """Exact (brute-force) vector store on MI355X.
 
@@ -98,6 +109,12 @@ class HipVS(VS):
         self._shard_queries = shard == "queries"   # corpus replicated, queries split
         self._pg = process_group
         self._lay = None                           # resolved layout, see _layout()
+        import threading
+
+        # one call at a time per store: the reference's VS is a process-global with mutable state too, and its only concurrent
+        # caller (sem_topk's group-by thread pool, sem_topk.py:770-773 -> sem_index / sem_search) must not interleave the
+        # launches of two searches that share one device workspace
+        self._lock = threading.RLock()
 
     # ------------------------------------------------------------------------------------------------ helpers
     @property
@@ -108,11 +125,13 @@ class HipVS(VS):
             self._backend = HipBackend(self._device)
         return self._backend
 
-    def _layout(self):
+    def _layout(self, sizes=None):
         """-> (qg, gq, cs, gc, pg_query, pg_corpus): this rank's query group / corpus shard under the configured split and
         the process groups its two exchange steps run in (None: nothing to exchange in that direction).  Resolved once,
         at first use: a 2-D split creates its sub-groups here (a collective call - every rank reaches it together, like
-        every other step of a sharded operator)."""
+        every other step of a sharded operator).  ``sizes`` = (rows, d, bytes per stored value) of the index being
+        installed: what ``shard="auto"`` plans with (the split is fixed by the FIRST index this store installs; without
+        sizes - a search before any index - "auto" falls back to the row split, the only one that fits any corpus)."""
         if self._lay is not None:
             return self._lay
         if self._split is False:
@@ -126,7 +145,10 @@ class HipVS(VS):
         if split == "auto":
             from .plan import pick_split
 
-            split = pick_split(world)
+            if sizes is None:
+                split = (1, world)
+            else:
+                split = pick_split(world, nb=int(sizes[0]), d=int(sizes[1]), bytes_per_value=int(sizes[2]))
         if split in (True, "rows"):
             lay = (0, 1, rank, world, None, self._pg)
         elif split == "queries":
@@ -206,12 +228,13 @@ class HipVS(VS):
         """Build the device image of this rank's shard from ``vecs`` ([n,d] ndarray / memmap / CUDA tensor; only rows
         [lo, hi) are touched).  ``stored``: what ``get_vectors_from_index`` serves (None = open on demand)."""
         n, d = int(vecs.shape[0]), int(vecs.shape[1])
-        rank, world = self._dist()
-        per = -(-n // world) if n else 0
-        lo, hi = min(n, rank * per), min(n, (rank + 1) * per)
         is_dev = self._is_device_tensor(vecs)
         dtype = np.float16 if (is_dev and str(vecs.dtype) == "torch.float16") else (np.float32 if is_dev else vecs.dtype)
         mode = self._pack_mode(dtype)
+        lay = self._layout(sizes=(n, d, 2 if mode == _capi.PACK_F16 else 4))  # "auto" plans with THIS index's real size
+        rank, world = lay[2], lay[3]
+        per = -(-n // world) if n else 0
+        lo, hi = min(n, rank * per), min(n, (rank + 1) * per)
         if world > 1 and mode == _capi.PACK_SPLIT and not self.normalize:
             packed = self._pack_shard_agreed(vecs, lo, hi, mode, is_dev)
         else:  # fp32-accurate rows are stored as x * 2^e with e chosen from the data (backend.pack); fp16 rows as given
@@ -259,6 +282,8 @@ class HipVS(VS):
                 f = int(np.bitwise_or.reduce(gathered([int(packed.flags.item())]).astype(np.int64).reshape(-1)))
         be.raise_for_flags(f)
         packed.flags = None
+        if hi == lo:
+            packed.exp = int(exp)  # a rank without rows packs its queries with, and decodes merged keys by, the agreed exponent
         return packed
 
     def _current(self) -> _Resident:
@@ -267,6 +292,7 @@ class HipVS(VS):
         return self._resident[self.index_dir]
 
     # ---------------------------------------------------------------------------------------- plugin methods
+    @_serialised
     def index(self, docs, embeddings, index_dir: str, **kwargs: dict[str, Any]) -> None:
         """Build the index from ``embeddings`` and persist it (``faiss_vs.py:22-30``).  ``docs`` is unused, as in
         ``FaissVS``.  ``embeddings`` may also be a CUDA tensor straight from an encoder (no host round trip for the
@@ -289,6 +315,7 @@ class HipVS(VS):
                       sig=store.signature(index_dir) if persist else None)
         self.index_dir = index_dir
 
+    @_serialised
     def load_index(self, index_dir: str) -> None:
         """Make ``index_dir`` the current index (``faiss_vs.py:32-36``).  Served from HBM when the directory is already
         resident AND unchanged on disk since it was loaded; otherwise this rank's rows are read through a memory map
@@ -304,6 +331,7 @@ class HipVS(VS):
         self._install(index_dir, rows, stored=None, sig=sig)
         self.index_dir = index_dir
 
+    @_serialised
     def get_vectors_from_index(self, index_dir: str, ids) -> np.ndarray:
         """``vecs[ids]`` in the stored dtype (``faiss_vs.py:38-41``); ``ids`` may be a list or a pandas Index.  Rows
         come from the caller's array (same process), from the row store's memory map (only the touched pages are read)
@@ -326,6 +354,7 @@ class HipVS(VS):
                 ent.vecs = vecs
         return np.asarray(vecs[sel])
 
+    @_serialised
     def __call__(self, query_vectors, K: int, ids: list[int] | None = None, **kwargs: dict[str, Any]) -> RMOutput:
         """Top-``K`` rows for every query vector (``faiss_vs.py:43-77``)."""
         ent = self._current()
@@ -365,6 +394,14 @@ class HipVS(VS):
         # queries share the index's power-of-two scale (required for L2; for inner products it keeps one exponent per
         # index); they are validated while they are packed, the flag word comes back together with the results
         qexp = kwargs.get("_query_exp", ent.packed.exp)
+        if (sub is None and not rank_all and world == 1 and qworld == 1 and not return_device and k_eff == K
+                and not self._is_device_tensor(q) and qexp != "auto" and hasattr(be, "search_host_pipelined")
+                and nq >= be.CALL_PIPELINE_MIN_QUERIES and not self._fp32_path(ent, q)):
+            # the plain big call (sem_sim_join.py:132-134 -> faiss_vs.py:75): transfers overlapped with the search
+            Dh, Ih, f = be.search_host_pipelined(ent.packed, q, k_eff, self.metric, id_offset=ent.lo,
+                                                 normalize=self.normalize, exp=int(qexp))
+            redo = self._check_queries(f, query_vectors, K, ids, kwargs)
+            return redo if redo is not None else RMOutput(distances=Dh, indices=Ih)
         if qexp == "auto" and qworld > 1:
             # the finished lists of all query groups are decoded with ONE score exponent: agree it from the largest magnitude
             import torch
@@ -451,6 +488,12 @@ class HipVS(VS):
         I[:, :k_eff] = Ih
         return RMOutput(distances=D, indices=I)
 
+    @staticmethod
+    def _fp32_path(ent, q) -> bool:
+        """fp32-accurate (hi|lo) operands take the certified one-pass search, which reads a count back mid-call: the staged
+        pipeline is for the plain fp16 search."""
+        return ent.packed.mode != _capi.PACK_F16
+
     def _check_queries(self, f: int, query_vectors, K, ids, kwargs):
         """Validation flags of the packed queries (``lvs_pack_rows_checked``).  inf / NaN raise.  Magnitudes that leave
         fp16's range under the INDEX's scale are searched again with an exponent of their own when the metric allows it
@@ -499,6 +542,7 @@ class HipVS(VS):
         rowmax = q.abs().amax(dim=1).float().cpu().numpy() if self._is_device_tensor(q) else np.abs(q).max(axis=1, initial=0.0)
         return np.asarray(rowmax, dtype=np.float64) * 2.0 ** ent.packed.exp > 65504.0
 
+    @_serialised
     def scores(self, query_vectors, ids: list[int] | None = None, _query_exp=None):
         """Similarity of every query to every indexed row (or to rows ``ids``, in that order) as one float32 matrix
         [Q, N] - what the K = N callers actually want (``sem_filter.py:491-497`` takes ``vec_scores`` of ALL rows,
@@ -602,6 +646,7 @@ class HipVS(VS):
             raise IndexError("ids out of range for the loaded index")
         return self.backend.gather(ent.packed, self.backend.to_device(sub))
 
+    @_serialised
     def kmeans(self, vec_set, ncentroids: int, niter: int = 20, ids=None, return_result: bool = False, **kw):
         """faiss-parity k-means of the current index's rows ``ids`` (``lotus/utils.py:61-65``) on the GPU(s) that already
         hold them; returns the cluster id of every row (all rows on every rank).  ``vec_set`` is not needed (the device

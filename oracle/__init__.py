@@ -22,5 +22,5 @@ leg may import this package; nothing under ``lotus_amd/`` does.
 """
 from .flat import (METRIC_INNER_PRODUCT, METRIC_L2, flat_search, as_f32, pack_keys, unpack_keys,
                    flat_search_exact64)
-from .kmeans import kmeans_faiss, rand_perm, KMeansResult
+from .kmeans import kmeans_faiss, rand_perm, KMeansResult, pair_distances, flipped_rows
 from .dedup import range_self_join, dedup_components, dedup_keep_mask

@@ -101,8 +101,42 @@ def _split_clusters(n, hassign, centroids, use_c):
     return nsplit
 
 
+def pair_distances(x, centroids, rows, cols) -> np.ndarray:
+    """Squared L2 of (x[rows[i]], centroids[cols[i]]) in the arithmetic of the assignment search above: float32
+    ``|x|^2 + |c|^2 - 2 <x, c>`` clamped at 0 (faiss's BLAS path, ``flat._block_better``), the inner product as one float32
+    dot per pair."""
+    xr = as_f32(x[np.asarray(rows, dtype=np.int64)])
+    cr = as_f32(centroids[np.asarray(cols, dtype=np.int64)])
+    ip = np.einsum("ij,ij->i", xr, cr, dtype=np.float32)
+    from .flat import row_norms_sq
+
+    dis = (row_norms_sq(xr) + row_norms_sq(cr)) - np.float32(2.0) * ip
+    return np.maximum(dis, np.float32(0.0)).astype(np.float32)
+
+
+def flipped_rows(x, centroids, assign_a, assign_b, rel: float = 2e-5):
+    """Rows two assignments of ``x`` to ``centroids`` disagree on, and whether every disagreement is a NEAR-TIE: the row's
+    distances to its two candidate centroids differ by at most ``rel`` x the larger one in the oracle's float32
+    arithmetic (``pair_distances``) - the band inside which a different summation order may pick either.
+    -> dict(rows, gaps (relative), near_tie (bool per row), all_near_ties)."""
+    a = np.asarray(assign_a, dtype=np.int64).reshape(-1)
+    b = np.asarray(assign_b, dtype=np.int64).reshape(-1)
+    rows = np.flatnonzero(a != b)
+    if len(rows) == 0:
+        return {"rows": rows, "gaps": np.zeros(0, np.float32), "near_tie": np.zeros(0, bool), "all_near_ties": True}
+    da = pair_distances(x, centroids, rows, a[rows]).astype(np.float64)
+    db = pair_distances(x, centroids, rows, b[rows]).astype(np.float64)
+    gaps = np.abs(da - db) / np.maximum(np.maximum(da, db), 1e-30)
+    near = gaps <= rel
+    return {"rows": rows, "gaps": gaps.astype(np.float32), "near_tie": near, "all_near_ties": bool(near.all())}
+
+
 def kmeans_faiss(x, k: int, niter: int = 20, seed: int = 1234, max_points_per_centroid: int = 256,
-                 use_c: bool | None = None, final_assign: bool = True) -> KMeansResult:
+                 use_c: bool | None = None, final_assign: bool = True, trace: list | None = None) -> KMeansResult:
+    """``trace`` (a list, optional) receives one dict per iteration: ``centroids`` (the centroids the iteration assigns
+    against), ``assign`` / ``dist`` (the search's result on the training rows), ``hassign`` (cluster sizes BEFORE the split),
+    ``divided`` (centroids after compute_centroids, before split_clusters), ``hassign_after`` (sizes after the split) and
+    ``next`` (the centroids the next iteration starts from) - what a step-by-step parity check feeds to the device."""
     x = as_f32(x)
     n, d = x.shape
     if n < k:
@@ -124,8 +158,16 @@ def kmeans_faiss(x, k: int, niter: int = 20, seed: int = 1234, max_points_per_ce
         for it in range(niter):
             D, I = flat_search(centroids, xt, 1, METRIC_L2, use_c=use_c)
             obj[it] = np.float32(D[:, 0].sum(dtype=np.float32))
+            rec = None
+            if trace is not None:
+                rec = {"centroids": centroids.copy(), "assign": I[:, 0].copy(), "dist": D[:, 0].copy()}
             hassign = _compute_centroids(xt, I[:, 0], centroids, use_c)
+            if rec is not None:
+                rec["hassign"], rec["divided"] = hassign.copy(), centroids.copy()
             nsplits[it] = _split_clusters(nt, hassign, centroids, use_c)
+            if rec is not None:
+                rec["hassign_after"], rec["next"] = hassign.copy(), centroids.copy()
+                trace.append(rec)
     assign = np.zeros(0, np.int64)
     if final_assign:
         _, I = flat_search(centroids, x, 1, METRIC_L2, use_c=use_c)

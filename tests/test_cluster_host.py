@@ -86,3 +86,24 @@ def test_installed_cluster_matches_the_reference_function(tmp_path):
         lcluster.uninstall()
     assert lotus.utils.cluster is not lcluster.cluster
     assert a["cluster_id"].tolist() == b["cluster_id"].tolist() and len(set(a["cluster_id"])) == 4
+
+
+def test_step_by_step_harness_on_the_cpu_double():
+    """tests/km_steps.py (the teacher-forced and free-run k-means parity checks the GPU suite runs at configs[4]'s shape)
+    over the oracle-backed test double on a small blob set with empty-cluster splits: the harness itself is sound."""
+    import km_steps
+    from oracle_backend import OracleBackend
+
+    rng = np.random.default_rng(5)
+    K, d, n = 48, 24, 20_000
+    cen = rng.standard_normal((12, d)).astype(np.float32)
+    x = (cen[rng.integers(0, 12, n)] + 0.15 * rng.standard_normal((n, d))).astype(np.float16)
+    x[: n // 4] = x[n // 2: n // 2 + 10].repeat(n // 40, axis=0)[: n // 4]  # duplicates: duplicate initial centroids run empty
+    c = km_steps.reference(x, K, 5)
+    assert len(c["ref"].train_ids) == K * 256 and c["ref"].nsplit.sum() > 0
+    be = OracleBackend()
+    # the double keeps the centroids as fp16 hi|lo pairs like the device (~22 significant bits): a handful of near-tie flips
+    # against the float32 oracle are legitimate - the harness has checked that each one IS a near-tie
+    assert km_steps.teacher_forced(be, c) <= 2
+    rep = km_steps.free_run(be, c)
+    assert rep["iterations_compared"] == 5 and rep["all_flips_are_near_ties"]

@@ -419,3 +419,61 @@ def test_distance_bounds_skip_rows_without_changing_any_result(hip_backend, mode
     a = kmeans(xu, 40, niter=5, backend=hip_backend, max_points_per_centroid=None, bounds=False)
     b = kmeans(xu, 40, niter=5, backend=hip_backend, max_points_per_centroid=None, bounds=True)
     assert np.array_equal(a.centroids, b.centroids) and np.array_equal(a.obj, b.obj) and np.array_equal(a.assign, b.assign)
+
+
+# ---- step-by-step parity at configs[4]'s own shape: K = 1 024, d = 768, faiss's 262 144-row subsample of blob rows -------------
+def test_kmeans_teacher_forced_steps_at_the_configs_shape(hip_backend):
+    """Every iteration pinned on its own (lotus/utils.py:61-62) - see km_steps.teacher_forced:
+    the ORACLE's centroids of iteration i go into ONE device step, so a near-tie flip cannot compound over iterations.
+    Blob rows of SURVEY.md 8(d), K = 1 024, d = 768, 300 000 rows (faiss's 262 144-row subsample engages), 8 iterations."""
+    import km_steps
+
+    c5 = km_steps.cfg5_reference()
+    assert len(c5["ref"].train_ids) == c5["K"] * 256 and c5["ref"].nsplit.sum() >= 100  # subsample engaged, splits exercised
+    flips = km_steps.teacher_forced(hip_backend, c5)
+    print(f"teacher-forced: {flips} near-tie flips in {c5['nit']} x {len(c5['ref'].train_ids)} assignments")
+
+
+def test_kmeans_free_run_diverges_from_the_oracle_only_through_near_ties(hip_backend):
+    """The free-running device k-means against oracle.kmeans_faiss on the same rows (km_steps.free_run): identical up to the
+    first iteration in which any row is assigned differently, and there every differing row is a near-tie."""
+    import km_steps
+
+    c5 = km_steps.cfg5_reference()
+    rep = km_steps.free_run(hip_backend, c5)
+    print(f"free run: {rep}")
+
+
+@pytest.mark.parametrize("mode", [F16, SPLIT])
+def test_distance_bounds_at_the_default_on_size_with_ties_splits_and_50_iterations(hip_backend, mode):
+    """The Hamerly bounds switch themselves on from 2^20 training rows (lotus_amd/cluster.py): at that size, over 50
+    iterations, on rows with exact duplicates, rows planted half way between two blob centres (near-ties of the assignment)
+    and blobs that start with two centroids or none (empty-cluster splits), the run with bounds must return bit-identical
+    objectives, centroids, split counts and assignments to the exhaustive run - the float32 margins of
+    lvs_kmeans_bounds_set / _fix / _step (ub += delta, lb -= max delta, 1e-5 relative guard) may only ever skip rows whose
+    nearest centroid is provably unchanged."""
+    import benchdata
+    from lotus_amd.cluster import kmeans
+
+    K, n, d = 256, 1 << 20, 64
+    x16, lab = benchdata.blobs(benchdata.CFG_KMEANS, n, d, K)
+    x = x16.astype(np.float32)
+    cen = benchdata.blob_centres(benchdata.CFG_KMEANS, K, d)
+    rng = np.random.default_rng(17)
+    a, b = rng.integers(0, K, 30_000), rng.integers(0, K, 30_000)
+    mid = cen[a] + cen[b] + 1e-3 * rng.standard_normal((30_000, d)).astype(np.float32)
+    x[200_000:230_000] = mid / np.linalg.norm(mid, axis=1, keepdims=True)      # half way between two centres
+    x[300_000:400_000] = x[:100_000]                                             # exact duplicates
+    if mode == F16:
+        x = x.astype(np.float16)
+    else:
+        x = x * np.float32(1.0 + 2.0 ** -13)  # values that need the lo half
+    kw = dict(niter=50, backend=hip_backend, max_points_per_centroid=None)
+    st = {}
+    fast = kmeans(x, K, stats=st, **kw)  # bounds=None: the default must have switched them on at this size
+    assert "searched_rows" in st and len(st["searched_rows"]) == 50 and min(st["searched_rows"]) < n // 2
+    plain = kmeans(x, K, bounds=False, **kw)
+    assert plain.nsplit.sum() >= 5
+    assert np.array_equal(fast.nsplit, plain.nsplit)
+    assert np.array_equal(fast.obj, plain.obj) and np.array_equal(fast.centroids, plain.centroids)
+    assert np.array_equal(fast.assign, plain.assign)

@@ -315,3 +315,47 @@ def test_kmeans_and_dedup_on_scaled_rows(hip_backend, tmp_path):
     vd.index(None, xd, str(tmp_path / "dd"), persist=False)
     i, j, s = threshold_pairs(hip_backend, vd.packed_rows(), 0.95 * 2500.0)
     assert len(i) == 100 and np.array_equal(j - i, np.full(100, 1500)) and np.allclose(s, 2500.0 * (1 + 1e-3), rtol=1e-4)
+
+
+def test_large_host_call_is_staged_and_equals_the_single_launch(hip_backend, tmp_path):
+    """VS.__call__ with tens of thousands of host queries (faiss_vs.py:75 as sem_sim_join.py:132-134 calls it) goes through
+    in two stages - H2D of the second stage under the first stage's search, D2H of the first stage's results under the
+    second's (HipBackend.search_host_pipelined, through the bounded pinned ring of _h2d): results are per query, so the
+    staged call must return exactly what one launch over all queries returns - also for queries that fail validation."""
+    be = hip_backend
+    xb = synth.corpus(60_000, 96, seed=41).astype(np.float16)
+    xq = synth.queries(xb.astype(np.float32), 40_000, seed=42)[0].astype(np.float16)
+    vs = HipVS(backend=be, storage="fp16")
+    vs.index(None, xb, str(tmp_path / "idx"), persist=False)
+    assert xq.shape[0] >= be.CALL_PIPELINE_MIN_QUERIES
+    staged = vs(xq, 10)
+    floor = be.CALL_PIPELINE_MIN_QUERIES
+    try:
+        be.CALL_PIPELINE_MIN_QUERIES = 1 << 40
+        plain = vs(xq, 10)
+    finally:
+        be.CALL_PIPELINE_MIN_QUERIES = floor
+    assert np.array_equal(staged.indices, plain.indices) and np.array_equal(staged.distances, plain.distances)
+    Dr, Ir = oracle.flat_search(xb.astype(np.float32), xq[:2000].astype(np.float32), 10)
+    err, hard, recall = synth.compare_topk(Dr, Ir, staged.distances[:2000], staged.indices[:2000], atol=1e-5)
+    assert err <= 1e-5 and hard == 0 and recall >= 0.9999
+    # a matrix wider than a ring slot's worth of rows per slice, float32 input rounded to fp16 storage, odd row count
+    xq32 = xq[:33_001].astype(np.float32)
+    a = vs(xq32, 3)
+    assert np.array_equal(a.indices, plain.indices[:33_001, :3])
+    bad = xq.copy()
+    bad[35_000, 5] = np.inf
+    with pytest.raises(ValueError):
+        vs(bad, 10)
+    # two threads sharing one backend: the staging ring is guarded, both get their own rows
+    import threading
+
+    outs = {}
+
+    def run(tag, q):
+        outs[tag] = vs(q, 5).indices
+
+    t1 = threading.Thread(target=run, args=("a", xq))
+    t2 = threading.Thread(target=run, args=("b", xq[::-1].copy()))
+    t1.start(); t2.start(); t1.join(); t2.join()
+    assert np.array_equal(outs["a"], plain.indices[:, :5]) and np.array_equal(outs["b"], plain.indices[::-1, :5])

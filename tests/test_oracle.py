@@ -232,3 +232,42 @@ def test_lloyd_iterations_agree_with_an_independent_kmeans():
     assert (res.assign == sk.labels_).mean() > 0.999  # points within rounding of a cell border may differ
     # faiss's objective of the LAST iteration is measured against the centroids BEFORE that iteration's update
     assert res.obj[-1] >= sk.inertia_ * (1 - 1e-5)
+
+
+def test_kmeans_trace_and_flipped_rows():
+    """The per-iteration record a step-by-step parity check feeds to the device (tests/test_gpu_kmeans.py, bench.py) is
+    self-consistent, and flipped_rows separates near-ties from real disagreements."""
+    rng = np.random.default_rng(12)
+    k, d, n = 24, 16, 4000
+    c = rng.standard_normal((k, d)).astype(np.float32) * 3
+    x = (c[rng.integers(0, 6, n)] + 0.2 * rng.standard_normal((n, d))).astype(np.float32)
+    x[: n // 2] = x[n // 2: n // 2 + 40].repeat(n // 80, axis=0)[: n // 2]  # duplicate rows: duplicate initial centroids run empty
+    trace = []
+    r = oracle.kmeans_faiss(x, k, niter=5, trace=trace)
+    assert len(trace) == 5 and r.nsplit.sum() > 0
+    for it, rec in enumerate(trace):
+        D, I = oracle.flat_search(rec["centroids"], x, 1, oracle.METRIC_L2)
+        assert np.array_equal(I[:, 0], rec["assign"]) and np.array_equal(D[:, 0], rec["dist"])
+        assert np.array_equal(np.bincount(rec["assign"], minlength=k).astype(np.float32), rec["hassign"])
+        assert rec["hassign_after"].sum() == n and (rec["hassign"] == 0).sum() == r.nsplit[it]
+        if it + 1 < len(trace):
+            assert np.array_equal(rec["next"], trace[it + 1]["centroids"])
+    assert np.array_equal(trace[-1]["next"], r.centroids)
+    # pair_distances restates the search's expression
+    rec = trace[2]
+    rows = np.arange(0, n, 7)
+    pd = oracle.pair_distances(x, rec["centroids"], rows, rec["assign"][rows])
+    big = float((x ** 2).sum(1).max() + (rec["centroids"] ** 2).sum(1).max())  # the expression's largest term
+    assert np.abs(pd - rec["dist"][rows]).max() <= 4 * np.finfo(np.float32).eps * big
+    # flipped_rows: an exact tie (two identical centroids) is a near-tie, a real change of cluster is not
+    cent = rec["centroids"].copy()
+    a = rec["assign"].copy()
+    cent[23] = cent[a[0]]
+    b = a.copy()
+    b[0] = 23
+    fl = oracle.flipped_rows(x, cent, a, b)
+    assert fl["rows"].tolist() == [0] and fl["all_near_ties"] and fl["gaps"][0] == 0
+    far = int(np.argmax(((x[1][None, :] - cent) ** 2).sum(1)))
+    b[1] = far
+    fl = oracle.flipped_rows(x, cent, a, b)
+    assert fl["rows"].tolist() == [0, 1] and fl["near_tie"].tolist() == [True, False] and not fl["all_near_ties"]
