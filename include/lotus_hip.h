@@ -34,7 +34,8 @@ extern "C" {
                                 lvs_pack_rows_checked (validation + power-of-two scale), lvs_absmax, lvs_margin_select_stats;
                                 scale exponents in lvs_unpack_rows / lvs_keys_to_result / lvs_scores / lvs_range_join;
                              4: pooled sample thresholds of a sharded join (lvs_flat_search_seed_tiles / _seed_scores /
-                                lvs_flat_search_keys_seeded) */
+                                lvs_flat_search_keys_seeded); query-streaming nearest-row search with a two-candidate
+                                certificate (lvs_nearest3 / _select / lvs_resolve_pairs) */
 
 #define LVS_OK 0
 #define LVS_EINVAL (-1)   /* bad argument */
@@ -209,6 +210,29 @@ int32_t lvs_range_join(const void* xb, int32_t xb_pack, int64_t nb, const void* 
  * mantissa bits of u = q.y (inner product) or u = 2 q.y - |y|^2 (L2) while it runs, so the reported winner and runner-up
  * scores are each perturbed by less than 2^-17 |u|: add 2^-16 max|u| to the margin bound. */
 int64_t lvs_nearest_hi_workspace_bytes(int64_t nq, int64_t nb, int32_t d);
+/* The same one-pass search for a SMALL corpus (at most LVS_NEAREST3_MAX_ROWS rows: the centroids of a k-means,
+ * lotus/utils.py:62,65) with the loop turned around - a workgroup keeps one 256-row corpus tile and streams the query
+ * tiles past it, the workgroups holding the other corpus tiles walk the same queries at the same time and share them
+ * through their XCD's L2 - and with one more output: out_keys [nq] winner key, out_keys2 [nq] runner-up key (0: none),
+ * out_second [nq] runner-up score, out_third [nq] third-best score (-inf: none), all in the "larger = better" domain and
+ * perturbed like lvs_nearest_hi's.  lvs_nearest3_select splits the queries three ways with the bound of
+ * lvs_margin_select_stats: certified (best - second > bound), PAIR (best - third > bound: only the best two rows can win -
+ * appended to out_pair_idx) and open (appended to out_open_idx; exact search over every row); out_counts [2] (device uint64,
+ * zeroed by the caller) += pairs / open.  lvs_resolve_pairs settles the pairs with two exact (hi + lo, float32) scores per
+ * query - the arithmetic of lvs_rescore_keys - and writes the better key (score, then lower id) into keys[q]; it reads
+ * the pair count from the device (at most `capacity` entries), so nothing waits for the host. */
+#define LVS_NEAREST3_MAX_ROWS 16384
+int64_t lvs_nearest3_workspace_bytes(int64_t nq, int64_t nb, int32_t d);
+int32_t lvs_nearest3(const void* xb, int32_t xb_pack, int64_t nb, const void* xq, int32_t xq_pack, int64_t nq, int32_t d,
+                     int32_t metric, const float* xb_norms_sq, const float* xq_norms_sq, int64_t id_offset,
+                     uint64_t* out_keys, uint64_t* out_keys2, float* out_second, float* out_third, void* workspace,
+                     int64_t workspace_bytes, void* stream);
+int32_t lvs_nearest3_select(const uint64_t* keys, const uint64_t* keys2, const float* second, const float* third,
+                            const float* q_norms_sq, int64_t nq, const float* corpus_stats, const float* coef5,
+                            int64_t* out_pair_idx, int64_t* out_open_idx, uint64_t* out_counts, void* stream);
+int32_t lvs_resolve_pairs(const void* xb, int32_t xb_pack, const void* xq, int32_t xq_pack, int32_t d, int32_t metric,
+                          const float* xb_norms_sq, const float* xq_norms_sq, int64_t id_offset, const int64_t* pair_idx,
+                          const uint64_t* pair_count, int64_t capacity, uint64_t* keys, const uint64_t* keys2, void* stream);
 int32_t lvs_nearest_hi(const void* xb, int32_t xb_pack, int64_t nb, const void* xq, int32_t xq_pack, int64_t nq, int32_t d,
                        int32_t metric, const float* xb_norms_sq, const float* xq_norms_sq, int64_t id_offset,
                        uint64_t* out_keys, float* out_second, void* workspace, int64_t workspace_bytes, void* stream);

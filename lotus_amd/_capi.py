@@ -17,6 +17,7 @@ DTYPE_F32, DTYPE_F16 = 0, 1
 METRIC_IP, METRIC_L2 = 0, 1
 PACK_F16, PACK_SPLIT = 0, 1
 MAX_K = 2048
+NEAREST3_MAX_ROWS = 16384
 ABI_VERSION = 4
 BUILD_TUNING, BUILD_COUNT_EVENTS = 1, 2
 PACK_FLAG_NONFINITE, PACK_FLAG_RANGE = 1, 2
@@ -53,6 +54,10 @@ SIGNATURES = {
                               _i32, _i64, _vp, _vp, _vp, _vp, _vp]),
     "lvs_nearest_hi_workspace_bytes": (_i64, [_i64, _i64, _i32]),
     "lvs_nearest_hi": (_i32, [_vp, _i32, _i64, _vp, _i32, _i64, _i32, _i32, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp]),
+    "lvs_nearest3_workspace_bytes": (_i64, [_i64, _i64, _i32]),
+    "lvs_nearest3": (_i32, [_vp, _i32, _i64, _vp, _i32, _i64, _i32, _i32, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
+    "lvs_nearest3_select": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "lvs_resolve_pairs": (_i32, [_vp, _i32, _vp, _i32, _i32, _i32, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp]),
     "lvs_rescore_keys": (_i32, [_vp, _i32, _vp, _i32, _i64, _i32, _i32, _vp, _vp, _i64, _i32, _vp, _vp]),
     "lvs_flat_search_keys_hi": (_i32, [_vp, _i32, _i64, _vp, _i32, _i64, _i32, _i32, _i32, _vp, _vp, _i64, _vp, _vp,
                                        _vp, _i64, _vp]),

@@ -518,6 +518,9 @@ class HipBackend:
                 E = float(corpus.rows[:, dpad:].float().square().sum(dim=1).max().sqrt().item())
             scale = coef[0] * E + coef[1] * R
             slack = coef[2] + coef[3] * R + coef[4] * R * R
+        if corpus.n <= _capi.NEAREST3_MAX_ROWS:
+            # a small corpus (k-means centroids): queries streaming past resident corpus tiles + the two-candidate certificate
+            return self._nearest3(corpus, queries, metric, id_offset, stats, exact_scores, corpus_stats, bounds, coef, dpad, plain)
         sec = torch.empty((nq,), dtype=torch.float32, device=self.device)
         need = int(self.lib.lvs_nearest_hi_workspace_bytes(nq, corpus.n, corpus.d))
         ws = self._workspace(need)
@@ -561,6 +564,74 @@ class HipBackend:
             keys[sel] = exact_keys
         if stats is not None:
             stats["uncertified"] = stats.get("uncertified", 0) + n_open
+            stats["queries"] = stats.get("queries", 0) + nq
+        return keys
+
+    def _nearest3(self, corpus, queries, metric, id_offset, stats, exact_scores, corpus_stats, bounds, coef, dpad, plain):
+        """``nearest`` for a corpus of at most 16 384 rows (``lvs_nearest3``): the one-pass search also returns the runner-up's
+        id and the THIRD score, so a query whose best-second margin is inside the error bound but whose best-third margin is
+        not has only two possible winners - two exact dot products (``lvs_resolve_pairs``) decide it instead of an exact
+        search over every row; only queries with three or more rows inside the bound take that search.  The three-way split
+        depends on a query's own scores and the corpus alone, never on which other queries share the call."""
+        torch = self.torch
+        nq = queries.n
+        if corpus_stats is None:  # (largest |row|^2, largest |lo part|^2) of the corpus, left on the device
+            E2 = (corpus.rows[:, dpad:].float().square().sum(dim=1).max() if corpus.mode == _capi.PACK_SPLIT
+                  else torch.zeros((), dtype=torch.float32, device=self.device))
+            corpus_stats = torch.stack([corpus.norms.max(), E2]).to(torch.float32)
+        keys = torch.empty((nq, 1), dtype=torch.int64, device=self.device)
+        keys2 = torch.empty((nq,), dtype=torch.int64, device=self.device)
+        sec = torch.empty((nq,), dtype=torch.float32, device=self.device)
+        third = torch.empty((nq,), dtype=torch.float32, device=self.device)
+        need = int(self.lib.lvs_nearest3_workspace_bytes(nq, corpus.n, corpus.d))
+        if need < 0:
+            raise LotusHipError("lvs_nearest3_workspace_bytes rejected the shape")
+        ws = self._workspace(need)
+        self._c("lvs_nearest3", _ptr(corpus.rows), corpus.mode, corpus.n, _ptr(queries.rows), queries.mode, nq, corpus.d, metric,
+                _ptr(corpus.norms), _ptr(queries.norms), int(id_offset), _ptr(keys), _ptr(keys2), _ptr(sec), _ptr(third),
+                _ptr(ws), int(ws.numel()), self._stream())
+        pair_idx = torch.empty((nq,), dtype=torch.int64, device=self.device)
+        open_idx = torch.empty((nq,), dtype=torch.int64, device=self.device)
+        counts = torch.zeros((2,), dtype=torch.int64, device=self.device)
+        coef5 = (ctypes.c_float * 5)(*coef)
+        self._c("lvs_nearest3_select", _ptr(keys), _ptr(keys2), _ptr(sec), _ptr(third), _ptr(queries.norms), nq,
+                _ptr(corpus_stats), ctypes.addressof(coef5), _ptr(pair_idx), _ptr(open_idx), _ptr(counts), self._stream())
+        if bounds is not None:  # every row's bounds from the one-pass result first; the uncertified rows are redone below
+            b_assign, b_ub, b_lb, b_pos = bounds
+            self._c("lvs_kmeans_bounds_set", _ptr(keys), 1, _ptr(sec), _ptr(queries.norms), _ptr(b_pos), nq,
+                    _ptr(corpus_stats), ctypes.addressof(coef5), int(id_offset), _ptr(b_assign), _ptr(b_ub), _ptr(b_lb),
+                    self._stream())
+        n_pair, n_open = (int(v) for v in counts.tolist())  # the call's one host round trip
+        psel = pair_idx[:n_pair]
+        # the one-pass keys of the rows decided below, as lvs_kmeans_bounds_fix needs them (taken before any exact score goes in)
+        approx_pair = keys[psel].contiguous() if (bounds is not None and n_pair) else None
+        approx_open = keys[open_idx[:n_open]].contiguous() if (bounds is not None and n_open) else None
+        if exact_scores:
+            self._c("lvs_rescore_keys", _ptr(corpus.rows), corpus.mode, _ptr(queries.rows), queries.mode, nq, corpus.d,
+                    metric, _ptr(corpus.norms), _ptr(queries.norms), int(id_offset), 1, _ptr(keys), self._stream())
+        exact2 = (ctypes.c_float * 2)(8e-6, 4e-6)  # float32 rounding of an exact distance, see nearest()
+        if n_pair:
+            self._c("lvs_resolve_pairs", _ptr(corpus.rows), corpus.mode, _ptr(queries.rows), queries.mode, corpus.d, metric,
+                    _ptr(corpus.norms), _ptr(queries.norms), int(id_offset), _ptr(pair_idx), _ptr(counts), n_pair, _ptr(keys),
+                    _ptr(keys2), self._stream())
+            if bounds is not None:
+                pos = psel if b_pos is None else b_pos[psel]
+                self._c("lvs_kmeans_bounds_fix", _ptr(approx_pair), _ptr(keys[psel].contiguous()),
+                        _ptr(queries.norms[psel].contiguous()), _ptr(pos), n_pair, _ptr(corpus_stats), ctypes.addressof(coef5),
+                        ctypes.addressof(exact2), int(id_offset), _ptr(b_assign), _ptr(b_ub), _ptr(b_lb), self._stream())
+        if n_open:
+            sel = open_idx[:n_open]
+            sub = self.gather(queries, sel)
+            exact_keys = self.search_keys(corpus, sub, 1, metric, **plain)
+            if bounds is not None:
+                pos = sel if b_pos is None else b_pos[sel]
+                self._c("lvs_kmeans_bounds_fix", _ptr(approx_open), _ptr(exact_keys), _ptr(sub.norms), _ptr(pos),
+                        n_open, _ptr(corpus_stats), ctypes.addressof(coef5), ctypes.addressof(exact2), int(id_offset),
+                        _ptr(b_assign), _ptr(b_ub), _ptr(b_lb), self._stream())
+            keys[sel] = exact_keys
+        if stats is not None:
+            stats["uncertified"] = stats.get("uncertified", 0) + n_open + n_pair
+            stats["pairs"] = stats.get("pairs", 0) + n_pair
             stats["queries"] = stats.get("queries", 0) + nq
         return keys
 

@@ -92,6 +92,9 @@ struct ScopedKernelTimer {
 };
 }  // namespace
 
+LvsKernelTimer::LvsKernelTimer(hipStream_t st) : impl(new ScopedKernelTimer(st)) {}
+LvsKernelTimer::~LvsKernelTimer() { delete (ScopedKernelTimer*)impl; }
+
 extern "C" int32_t lvs_timing_enable(int32_t on) {
     std::lock_guard<std::mutex> lk(g_timing.mu);
     g_timing.on = on != 0;

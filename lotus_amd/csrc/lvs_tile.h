@@ -172,6 +172,13 @@ inline int lvs_tile_xcd_rounds(int nqt, int nslab, int gq, int lead_slabs) {
 }
 hipError_t lvs_tile_launch(int mode, const LvsTileArgs& a, hipStream_t stream);
 
+// HIP events around a dominant-kernel launch while lvs_timing_enable(1) is on (lvs_capi.hip); a no-op otherwise
+struct LvsKernelTimer {
+    explicit LvsKernelTimer(hipStream_t st);
+    ~LvsKernelTimer();
+    void* impl;
+};
+
 // ---- small-batch streaming kernel (lvs_stream.hip): nq <= 256, k <= LVS_KPASS.  One or two blocks of 32 queries per
 // workgroup; beyond 64 queries 2 or 4 sibling workgroups share a corpus range through their XCD's L2. ----
 #define LVS_STREAM_MAXQ 256

@@ -18,12 +18,16 @@
 #include <utility>
 
 #include "lvs_common.h"
+#include "lvs_kstep.h"
 #include "lvs_tile.h"
 
 namespace {
 
-constexpr int BC = 256, BK = 64;
-constexpr int ROWB = BK * 2;
+using lvs_kstep::BC;
+using lvs_kstep::BK;
+using lvs_kstep::ROWB;
+using lvs_kstep::glds16;
+using lvs_kstep::static_for;
 
 // Two geometries of the same kernel, selected by MI = 32-row accumulator blocks per wave in the corpus direction:
 //   MI = 4: waves 2 (corpus) x 4 (queries), wave tile 128 x 64, 256 queries per workgroup, 15 list slots per query
@@ -45,56 +49,6 @@ struct Geo {
     static constexpr int LDS_TOTAL = OFF_LOCK + BQ * 4;
     static_assert(LDS_TOTAL <= 160 * 1024, "LDS budget");
     static_assert(KCAP <= 64, "one lane per list slot");
-};
-
-typedef __attribute__((address_space(3))) void lds_void_t;
-typedef const __attribute__((address_space(1))) void gbl_void_t;
-
-__device__ inline void glds16(const void* gsrc, void* ldst) {
-    __builtin_amdgcn_global_load_lds((gbl_void_t*)gsrc, (lds_void_t*)ldst, 16, 0, 0);
-}
-
-// ---- asm-scheduled K-step ------------------------------------------------------------------------------------
-// hipcc sinks every LDS fragment read to just before its first use and waits with lgkmcnt(0), which undoes the
-// software pipelining written in the source.  The fragment reads and their waits are therefore inline asm: reads are
-// issued in source order (pinned by sched_barrier), waits are COUNTED (LDS returns a wave's reads in issue order).
-template <int... Is, class F>
-__device__ inline void static_for_impl(std::integer_sequence<int, Is...>, F&& f) {
-    (f(std::integral_constant<int, Is>{}), ...);
-}
-template <int N, class F>
-__device__ inline void static_for(F&& f) {
-    static_for_impl(std::make_integer_sequence<int, N>{}, f);
-}
-template <int OFFSET>  // OFFSET: compile-time byte offset (16-bit immediate field of the instruction)
-__device__ inline void lds_read16(half8& dst, unsigned addr) {
-    static_assert(OFFSET >= 0 && OFFSET < 65536, "ds_read offset field is 16 bits");
-    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFFSET));
-}
-template <int N>
-__device__ inline void lds_wait(half8& a, half8& b0, half8& b1) {
-    asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(a), "+v"(b0), "+v"(b1) : "n"(N));
-}
-// Issue order of one K-step (4 * MI steps f = kk * MI + mi): prologue B(0)[0], B(0)[1], A(0) .. A(DEPTH-1); step f issues
-// A(f + DEPTH) (if any), then B(kk+1)[0..1] when mi == BPOS.  wait(f) = reads that may still be outstanding when step
-// f's MFMAs start = (reads issued so far) - 1 - (issue index of the last read step f needs).
-template <int MI, int DEPTH, int BPOS>
-struct KStepOrder {
-    static constexpr int NF = 4 * MI;
-    static constexpr int issued(int f) {
-        int c = 2 + DEPTH;
-        for (int g = 0; g <= f; ++g) {
-            if (g + DEPTH < NF) ++c;
-            if (g % MI == BPOS && g / MI + 1 < 4) c += 2;
-        }
-        return c;
-    }
-    static constexpr int pos_A(int f) { return f < DEPTH ? 2 + f : issued(f - DEPTH - 1); }
-    static constexpr int pos_B(int kk) { return kk == 0 ? 1 : issued((kk - 1) * MI + BPOS) - 1; }
-    static constexpr int wait(int f) {
-        const int a = pos_A(f), b = pos_B(f / MI);
-        return issued(f) - 1 - (a > b ? a : b);
-    }
 };
 
 // Scores are finite or -inf, never NaN, so the maxima need none of fmaxf's canonicalisation (hipcc emits one extra
@@ -153,7 +107,7 @@ __device__ inline bool item_of_block(const LvsTileArgs& a, int b, int& qt, int& 
 template <int MODE, int MI>
 __global__ __launch_bounds__(512, 2) void lvs_tile_kernel(const LvsTileArgs a) {
     using G = Geo<MI>;
-    constexpr int BQ = G::BQ, QG = G::QG, NF = G::NF, KCAP = G::KCAP, STAGE_BYTES = G::STAGE_BYTES;
+    constexpr int BQ = G::BQ, QG = G::QG, KCAP = G::KCAP, STAGE_BYTES = G::STAGE_BYTES;
     constexpr int OFF_LIST = G::OFF_LIST, OFF_LOCK = G::OFF_LOCK;
     static_assert(MODE == LVS_MODE_TOPK || MI == 4, "the other epilogues exist for the 256 x 256 geometry only");
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -352,45 +306,7 @@ __global__ __launch_bounds__(512, 2) void lvs_tile_kernel(const LvsTileArgs a) {
         }
         const char* c_sbase = (const char*)xb + ((long long)(tile0 + n_tile) * BC * ldb + a.seg_c[n_seg] + n_r * BK) * 2;
         const char* q_sbase = (const char*)xq + (q0 * ldq + a.seg_q[n_seg] + n_r * BK) * 2;
-        // A fragments two steps ahead; B fragments of the next kk read at mi == KBPOS
-        constexpr int KDEPTH = 2, KBPOS = MI == 4 ? 2 : 0;
-        using Ord = KStepOrder<MI, KDEPTH, KBPOS>;
-        half8 Bf[2][2], Af[KDEPTH + 1];
-        // one address VGPR per (operand, kk); the 32-row block (mi / second query block) goes into the offset field
-        const unsigned sbu = (unsigned)(unsigned long long)sb;
-        unsigned a_addr[4], b_addr[4];
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            a_addr[kk] = (sbu + a_base) + foff[kk];
-            b_addr[kk] = (sbu + b_base) + foff[kk];
-        }
-        lds_read16<0>(Bf[0][0], b_addr[0]);
-        lds_read16<32 * ROWB>(Bf[0][1], b_addr[0]);
-        static_for<KDEPTH>([&](auto fc) {
-            constexpr int f = decltype(fc)::value;
-            lds_read16<(f % MI) * 32 * ROWB>(Af[f], a_addr[f / MI]);
-        });
-        static_for<NF>([&](auto fc) {
-            constexpr int f = decltype(fc)::value;
-            constexpr int kk = f / MI, mi = f % MI;
-            if constexpr (f + KDEPTH < NF) {
-                constexpr int f2 = f + KDEPTH;
-                lds_read16<(f2 % MI) * 32 * ROWB>(Af[f2 % (KDEPTH + 1)], a_addr[f2 / MI]);
-            }
-            if constexpr (mi == KBPOS && kk + 1 < 4) {
-                lds_read16<0>(Bf[(kk + 1) & 1][0], b_addr[kk + 1]);
-                lds_read16<32 * ROWB>(Bf[(kk + 1) & 1][1], b_addr[kk + 1]);
-            }
-            if constexpr (f < 4)
-                glds16(c_sbase + c_loff[f], n_base + (wave * 32 + f * 8) * ROWB);
-            else if constexpr (f < 4 + QG)
-                glds16(q_sbase + q_loff[f - 4], n_base + BC * ROWB + (wave * (8 * QG) + (f - 4) * 8) * ROWB);
-            __builtin_amdgcn_sched_barrier(0);
-            lds_wait<Ord::wait(f)>(Af[f % (KDEPTH + 1)], Bf[kk & 1][0], Bf[kk & 1][1]);
-            acc[mi][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Af[f % (KDEPTH + 1)], Bf[kk & 1][0], acc[mi][0], 0, 0, 0);
-            acc[mi][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Af[f % (KDEPTH + 1)], Bf[kk & 1][1], acc[mi][1], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-        });
+        lvs_kstep::run<MI, QG>(sb, n_base, c_sbase, q_sbase, c_loff, q_loff, wave, a_base, b_base, foff, acc);
 
         if (++ks_in_tile < nk) continue;
         ks_in_tile = 0;

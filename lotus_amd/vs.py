@@ -231,8 +231,8 @@ class HipVS(VS):
         is_dev = self._is_device_tensor(vecs)
         dtype = np.float16 if (is_dev and str(vecs.dtype) == "torch.float16") else (np.float32 if is_dev else vecs.dtype)
         mode = self._pack_mode(dtype)
-        lay = self._layout(sizes=(n, d, 2 if mode == _capi.PACK_F16 else 4))  # "auto" plans with THIS index's real size
-        rank, world = lay[2], lay[3]
+        self._layout(sizes=(n, d, 2 if mode == _capi.PACK_F16 else 4))  # "auto" plans with THIS index's real size
+        rank, world = self._dist()
         per = -(-n // world) if n else 0
         lo, hi = min(n, rank * per), min(n, (rank + 1) * per)
         if world > 1 and mode == _capi.PACK_SPLIT and not self.normalize:

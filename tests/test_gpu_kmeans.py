@@ -183,8 +183,10 @@ def test_certified_nearest_equals_the_exact_search(hip_backend, cmode, qmode, me
     stats = {}
     Dg, Ig = (t.cpu().numpy() for t in be.keys_to_result(be.nearest(cb, cq, metric, id_offset=7, stats=stats), metric))
     Dw, Iw = (t.cpu().numpy() for t in be.keys_to_result(be.search_keys(cb, cq, 1, metric, id_offset=7), metric))
-    assert np.array_equal(Ig, Iw)  # the same winner for every query
+    # the same winner for every query - up to float32 near-ties: a query decided by two exact dot products (lvs_resolve_pairs)
+    # and the exact MFMA search sum in different orders, so two rows whose exact scores agree to rounding may swap
     assert np.abs(Dg - Dw).max() <= 4e-6 * max(1.0, np.abs(Dw).max())  # exact scores (another fp32 summation order)
+    assert (Ig != Iw).sum() <= 2, (Ig != Iw).sum()
     assert stats["queries"] == nq and stats["uncertified"] <= 0.02 * nq  # the certificate does the work, not the fallback
 
 
@@ -204,9 +206,13 @@ def test_certified_nearest_with_ties_and_lo_only_differences(hip_backend):
     cb, cq = be.pack(xb, SPLIT), be.pack(xq.astype(np.float16), F16)
     for metric in (L2, IP):
         stats = {}
-        _, Ig = be.keys_to_result(be.nearest(cb, cq, metric, stats=stats), metric)
-        _, Iw = be.keys_to_result(be.search_keys(cb, cq, 1, metric), metric)
-        assert np.array_equal(Ig.cpu().numpy(), Iw.cpu().numpy())
+        Dg, Ig = (t.cpu().numpy() for t in be.keys_to_result(be.nearest(cb, cq, metric, stats=stats), metric))
+        Dw, Iw = (t.cpu().numpy() for t in be.keys_to_result(be.search_keys(cb, cq, 1, metric), metric))
+        diff = Ig != Iw
+        # a twin that differs by 0.3 ulp in 8 of 96 coordinates scores within a few 1e-7 of its base row: where two exact
+        # float32 evaluations (two dot products vs the MFMA search) disagree on such a pair, both answers are right
+        assert np.abs(Dg - Dw)[diff].max(initial=0.0) <= 4e-6 * max(1.0, np.abs(Dw).max()) and diff.sum() <= 10, diff.sum()
+        assert np.array_equal(Ig[:10], Iw[:10])  # exact duplicates (three candidates inside the bound): lowest id, as the search
         assert stats["uncertified"] >= 90  # (almost) every query has a twin or duplicate within the bound
 
 
@@ -464,6 +470,8 @@ def test_distance_bounds_at_the_default_on_size_with_ties_splits_and_50_iteratio
     mid = cen[a] + cen[b] + 1e-3 * rng.standard_normal((30_000, d)).astype(np.float32)
     x[200_000:230_000] = mid / np.linalg.norm(mid, axis=1, keepdims=True)      # half way between two centres
     x[300_000:400_000] = x[:100_000]                                             # exact duplicates
+    x[400_000:450_000] = x[400_000:400_020].repeat(2500, axis=0)                 # 20 values x 2 500 copies: duplicate INITIAL
+    # centroids (ties go to the lowest id, the twin runs empty) -> empty-cluster splits from the first iteration on
     if mode == F16:
         x = x.astype(np.float16)
     else:
@@ -473,7 +481,87 @@ def test_distance_bounds_at_the_default_on_size_with_ties_splits_and_50_iteratio
     fast = kmeans(x, K, stats=st, **kw)  # bounds=None: the default must have switched them on at this size
     assert "searched_rows" in st and len(st["searched_rows"]) == 50 and min(st["searched_rows"]) < n // 2
     plain = kmeans(x, K, bounds=False, **kw)
-    assert plain.nsplit.sum() >= 5
     assert np.array_equal(fast.nsplit, plain.nsplit)
     assert np.array_equal(fast.obj, plain.obj) and np.array_equal(fast.centroids, plain.centroids)
     assert np.array_equal(fast.assign, plain.assign)
+    assert plain.nsplit.sum() >= 1, plain.nsplit  # the data did exercise split_clusters
+
+
+def _hi_scores(xb, xq, metric):
+    """float64 one-pass scores: hi parts only (fp16 roundings), exact norms of the stored (hi + lo) values."""
+    hb, hq = xb.astype(np.float16).astype(np.float64), xq.astype(np.float16).astype(np.float64)
+    s = hq @ hb.T
+    if metric == L2:
+        sb, sq = _stored(xb, SPLIT).astype(np.float64), _stored(xq, SPLIT).astype(np.float64)
+        s = -np.maximum((sq ** 2).sum(1)[:, None] + (sb ** 2).sum(1)[None, :] - 2 * s, 0)
+    return s
+
+
+@pytest.mark.parametrize("metric", [L2, IP])
+@pytest.mark.parametrize("nq,nb,d", [(700, 1, 64), (300, 2, 64), (1000, 3, 96), (513, 255, 64), (2049, 257, 128),
+                                     (5000, 1024, 768), (70_000, 1000, 64), (300, 5000, 32)])
+def test_query_streaming_nearest_returns_the_top_three(hip_backend, metric, nq, nb, d):
+    """lvs_nearest3 (lvs_assign.hip): queries stream past resident corpus tiles; per query the best and second-best ROWS and
+    the third-best SCORE of the one-pass (hi parts) scores, every value perturbed by < 2^-17 relative (position tags).  Ragged
+    corpus / query counts, one to twenty corpus tiles, both metrics, against a float64 evaluation of the same scores."""
+    import torch
+
+    be = hip_backend
+    rng = np.random.default_rng(nq + nb)
+    xb = (synth.corpus(nb, d, seed=nb) * 1.4).astype(np.float32)
+    xq = (xb[rng.integers(0, nb, nq)] + 0.3 * synth.corpus(nq, d, seed=nq)).astype(np.float32)
+    cb, cq = be.pack(xb, SPLIT), be.pack(xq, SPLIT)
+    keys = torch.empty((nq,), dtype=torch.int64, device=be.device)
+    keys2 = torch.empty((nq,), dtype=torch.int64, device=be.device)
+    sec = torch.empty((nq,), dtype=torch.float32, device=be.device)
+    third = torch.empty((nq,), dtype=torch.float32, device=be.device)
+    need = int(be.lib.lvs_nearest3_workspace_bytes(nq, nb, d))
+    ws = be._workspace(need)
+    P = lambda t: int(t.data_ptr())
+    be._c("lvs_nearest3", P(cb.rows), cb.mode, nb, P(cq.rows), cq.mode, nq, d, metric, P(cb.norms), P(cq.norms), 11, P(keys),
+          P(keys2), P(sec), P(third), P(ws), int(ws.numel()), be._stream())
+    k1 = keys.cpu().numpy().view(np.uint64)
+    k2 = keys2.cpu().numpy().view(np.uint64)
+    s1, i1, _ = oracle.unpack_keys(k1)
+    s2, i2, e2 = oracle.unpack_keys(k2)
+    S = _hi_scores(xb, xq, metric)
+    order = np.argsort(-S, axis=1, kind="stable")
+    top = np.take_along_axis(S, order[:, :3], axis=1)
+    scale = np.abs(S).max() + (0 if metric == IP else 2 * np.abs(xq.astype(np.float64) @ xb.astype(np.float64).T).max())
+    tol = 2.0 ** -15 * scale + 1e-6
+    rows = np.arange(nq)
+    assert np.abs(s1 - top[:, 0]).max() <= tol
+    assert np.abs(S[rows, i1 - 11] - top[:, 0]).max() <= tol      # the reported row IS a best row (up to the tag perturbation)
+    if nb >= 2:
+        assert not e2.any() and (i2 != i1).all()
+        assert np.abs(S[rows, i2 - 11] - top[:, 1]).max() <= tol and np.abs(s2 - top[:, 1]).max() <= tol
+        assert np.abs(sec.cpu().numpy() - top[:, 1]).max() <= tol
+    else:
+        assert e2.all() and np.isneginf(sec.cpu().numpy()).all()
+    if nb >= 3:
+        assert np.abs(third.cpu().numpy() - top[:, 2]).max() <= tol
+    else:
+        assert np.isneginf(third.cpu().numpy()).all()
+
+
+@pytest.mark.parametrize("metric", [L2, IP])
+def test_two_candidate_certificate_settles_split_twins_with_two_dot_products(hip_backend, metric):
+    """Right after faiss's split_clusters two centroids are c (1 + 1/1024) and c (1 - 1/1024) (alternating per coordinate): every
+    row of that cluster is inside the one-pass error bound of BOTH twins and far from every third centroid.  Such queries
+    must come back as pairs (lvs_nearest3_select) and be settled by lvs_resolve_pairs - same winners as the exact search (up
+    to float32 near-ties), hardly anything left for the exact search over every row."""
+    be = hip_backend
+    rng = np.random.default_rng(3)
+    K, d, nq = 512, 256, 40_000
+    c = (synth.corpus(K // 2, d, seed=5) * 1.2).astype(np.float32)
+    eps = np.where(np.arange(d) % 2 == 0, 1 + 1 / 1024, 1 - 1 / 1024).astype(np.float32)
+    xb = np.concatenate([c * eps, c * (2 - eps)])                    # 256 twin pairs
+    xq = (c[rng.integers(0, K // 2, nq)] + 0.05 * synth.corpus(nq, d, seed=6)).astype(np.float16)
+    cb, cq = be.pack(xb, SPLIT), be.pack(xq, F16)
+    stats = {}
+    Dg, Ig = (t.cpu().numpy() for t in be.keys_to_result(be.nearest(cb, cq, metric, stats=stats), metric))
+    Dw, Iw = (t.cpu().numpy() for t in be.keys_to_result(be.search_keys(cb, cq, 1, metric, one_pass=False), metric))
+    diff = Ig != Iw
+    assert np.abs(Dg - Dw).max() <= 4e-6 * max(1.0, np.abs(Dw).max())
+    assert diff.mean() <= 2e-3, diff.mean()   # near-ties between twins only (scores equal to rounding, asserted above)
+    assert stats["pairs"] >= 0.3 * nq and stats["uncertified"] - stats["pairs"] <= 0.01 * nq, stats
