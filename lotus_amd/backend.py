@@ -173,7 +173,9 @@ class HipBackend:
         return tuple(h.numpy() for h in outs)
 
     CALL_PIPELINE_MIN_QUERIES = 32768
-    CALL_PIPELINE = (0.2, 0.8)  # shares of the queries per stage: a short first stage (its H2D is the exposed one)
+    CALL_PIPELINE = (0.1, 0.9)  # shares of the queries per stage: a short first stage (its H2D is the exposed one; measured at
+    # 100 k x 1 M, tools/tcall_probe.py: one stage 144.0 ms, (0.1, 0.9) 139.2, (0.2, 0.8) 141.5, (0.5, 0.5) 145.1, three or four
+    # stages 141.8-150.1 against 135.9 ms device-resident - shorter launches run further below the long-stream rate)
 
     def search_host_pipelined(self, corpus: PackedRows, q: np.ndarray, k: int, metric: int, id_offset: int = 0,
                               normalize: bool = False, exp: int = 0):

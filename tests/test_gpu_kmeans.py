@@ -211,7 +211,7 @@ def test_certified_nearest_with_ties_and_lo_only_differences(hip_backend):
         diff = Ig != Iw
         # a twin that differs by 0.3 ulp in 8 of 96 coordinates scores within a few 1e-7 of its base row: where two exact
         # float32 evaluations (two dot products vs the MFMA search) disagree on such a pair, both answers are right
-        assert np.abs(Dg - Dw)[diff].max(initial=0.0) <= 4e-6 * max(1.0, np.abs(Dw).max()) and diff.sum() <= 10, diff.sum()
+        assert np.abs(Dg - Dw)[diff].max(initial=0.0) <= 1e-6 * max(1.0, np.abs(Dw).max()) and diff.sum() <= 40, diff.sum()
         assert np.array_equal(Ig[:10], Iw[:10])  # exact duplicates (three candidates inside the bound): lowest id, as the search
         assert stats["uncertified"] >= 90  # (almost) every query has a twin or duplicate within the bound
 
@@ -561,7 +561,19 @@ def test_two_candidate_certificate_settles_split_twins_with_two_dot_products(hip
     stats = {}
     Dg, Ig = (t.cpu().numpy() for t in be.keys_to_result(be.nearest(cb, cq, metric, stats=stats), metric))
     Dw, Iw = (t.cpu().numpy() for t in be.keys_to_result(be.search_keys(cb, cq, 1, metric, one_pass=False), metric))
-    diff = Ig != Iw
     assert np.abs(Dg - Dw).max() <= 4e-6 * max(1.0, np.abs(Dw).max())
-    assert diff.mean() <= 2e-3, diff.mean()   # near-ties between twins only (scores equal to rounding, asserted above)
+    # ground truth in float64 on the stored values: the row either path reports must score within float32 noise of the best
+    # one (the twins of a pair are ~3e-4 apart on average, so a few per cent of the queries have them closer than the ~3e-6 by
+    # which the exact MFMA search and two float32 dot products may differ - there the two paths may name different twins)
+    sb, sq = _stored(xb, SPLIT).astype(np.float64), xq.astype(np.float64)
+    truth = sq @ sb.T
+    if metric == L2:
+        truth = -((sq ** 2).sum(1)[:, None] + (sb ** 2).sum(1)[None, :] - 2 * truth)
+    best = truth.max(axis=1)
+    rows = np.arange(nq)
+    tol = 4e-6 * max(1.0, np.abs(best).max())
+    assert (best - truth[rows, Ig[:, 0]]).max() <= tol and (best - truth[rows, Iw[:, 0]]).max() <= tol
+    # ... and the two-dot-product arbiter is at least as often right as the MFMA search
+    assert (Ig[:, 0] != truth.argmax(1)).sum() <= (Iw[:, 0] != truth.argmax(1)).sum() + 0.002 * nq
+    assert (Ig != Iw).mean() <= 0.05
     assert stats["pairs"] >= 0.3 * nq and stats["uncertified"] - stats["pairs"] <= 0.01 * nq, stats
