@@ -721,7 +721,7 @@ int make_plan(int64_t nq, int64_t nb, int32_t d, int32_t xb_pack, int32_t xq_pac
     // geometry: 256 queries per tile with 15 list slots (k <= 15 and every non-top-k mode), else 128 queries / 56 slots
     p.v2 = force_v2 || k <= LVS2_KCAP;
     // a single, at most half-full query tile: the 128-query geometry does half the (padding) MFMA work
-    if (!force_v2 && k > 1 && nq <= lvs_tune("LVS_V3_MAXQ", LVS3_BQ) && lvs_tune("LVS_SMALLQ", 1) != 0) p.v2 = 0;
+    if (!force_v2 && k > 1 && nq <= LVS3_BQ && lvs_tune("LVS_SMALLQ", 1) != 0) p.v2 = 0;
     p.nqt = (int)lvs_ceil_div(nq > 0 ? nq : 1, p.v2 ? LVS2_BQ : LVS3_BQ);
     // XCD group = gq query tiles x (32 / gq) slabs resident on one XCD at a time.  Wide groups (one corpus stream per
     // XCD) are fastest (profiles/r01_tuning.md) but must be full: groups are dealt round-robin to the 8 XCDs, so a

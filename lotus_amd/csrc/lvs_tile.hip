@@ -34,20 +34,17 @@ using lvs_kstep::static_for;
 //           (k <= 15 per pass) - the fast one, everything above describes it;
 //   MI = 2: waves 4 x 2, wave tile 64 x 64, 128 queries per workgroup; the 32 KB of staging this frees hold 56 list
 //           slots per query (16 <= k <= 56 per pass).  Top-k mode only.
-template <int MI, int NST = 2>
+template <int MI>
 struct Geo {
     static_assert(MI == 4 || MI == 2, "two geometries");
-    static_assert(NST == 2 || (NST == 3 && MI == 2), "staging ring: two buffers, or three on the 128-query geometry");
     static constexpr int WN = MI;                    // wave columns (queries); wave rows WM = 8 / WN
     static constexpr int WM = 8 / WN;
     static constexpr int BQ = WN * 64;               // queries per workgroup
     static constexpr int QG = BQ / 64;               // staging loads (8 rows each) per wave for the query rows
     static constexpr int NF = 4 * MI;                // steps (2 MFMAs each) per K-step
     static constexpr int STAGE_BYTES = (BC + BQ) * ROWB;
-    // list slots per query: 15 on the 256-query geometry; on the 128-query one 56 with two staging buffers, 15 with three
-    // (the third 48 KB buffer takes the room of the long lists)
-    static constexpr int KCAP = MI == 4 ? LVS2_KCAP : (NST == 3 ? LVS2_KCAP : LVS3_KCAP);
-    static constexpr int OFF_LIST = NST * STAGE_BYTES;           // u64 [BQ][KCAP] sorted descending, first k used
+    static constexpr int KCAP = MI == 4 ? LVS2_KCAP : LVS3_KCAP;
+    static constexpr int OFF_LIST = 2 * STAGE_BYTES;             // u64 [BQ][KCAP] sorted descending, first k used
     static constexpr int OFF_LOCK = OFF_LIST + BQ * KCAP * 8;    // u32 [BQ] list locks
     static constexpr int LDS_TOTAL = OFF_LOCK + BQ * 4;
     static_assert(LDS_TOTAL <= 160 * 1024, "LDS budget");
@@ -107,11 +104,9 @@ __device__ inline bool item_of_block(const LvsTileArgs& a, int b, int& qt, int& 
 
 // MODE  TOPK: sorted lists (k <= KCAP); TOP1: k == 1, per-lane best; RANGE: threshold join; SCORES: matrix out;
 //       COLLECT: every key >= a per-query threshold key into that query's bucket (second phase of large-k search)
-// NST = 3 (128-query geometry, k <= 15): a ring of three staging buffers, the loads of TWO K-steps in flight per
-// workgroup - for launches of a few query tiles, which are bound by HBM latency (one workgroup per CU), not by MFMA
-template <int MODE, int MI, int NST = 2>
+template <int MODE, int MI>
 __global__ __launch_bounds__(512, 2) void lvs_tile_kernel(const LvsTileArgs a) {
-    using G = Geo<MI, NST>;
+    using G = Geo<MI>;
     constexpr int BQ = G::BQ, QG = G::QG, KCAP = G::KCAP, STAGE_BYTES = G::STAGE_BYTES;
     constexpr int OFF_LIST = G::OFF_LIST, OFF_LOCK = G::OFF_LOCK;
     static_assert(MODE == LVS_MODE_TOPK || MI == 4, "the other epilogues exist for the 256 x 256 geometry only");
@@ -262,22 +257,7 @@ __global__ __launch_bounds__(512, 2) void lvs_tile_kernel(const LvsTileArgs a) {
     int n_tile = 0, n_seg = 0, n_r = 0;  // (tile, segment, k-block) of the K-step being prefetched
 
     const int T = (tile1 - tile0) * nk;
-    constexpr int AHEAD = NST - 1;  // K-steps staged ahead of the one being computed
-    auto advance_prefetch = [&]() {
-        if (++n_r == nkd) {
-            n_r = 0;
-            if (++n_seg == a.nseg) {
-                n_seg = 0;
-                ++n_tile;
-                set_tile_offsets(n_tile);
-            }
-        }
-    };
     stage(0, 0);
-    if constexpr (NST == 3) {  // K-step 1 too (a one-step item stages its only K-step twice; the copy is never read)
-        stage(T > 1 ? 1 : 0, 1);
-        if (T > 1) advance_prefetch();
-    }
     int ks_in_tile = 0, ti = 0;
     // the second-dispatched half of the waves loses VALU/MFMA arbitration to the older half on every segment: one
     // static priority raise evens it out (+2 % on the bare loop, tools/probe_gemm.hip)
@@ -289,19 +269,14 @@ __global__ __launch_bounds__(512, 2) void lvs_tile_kernel(const LvsTileArgs a) {
     unsigned long long c_filter = 0, c_visit = 0, c_ins = 0;  // cycles (s_memtime) in the filter / visit loop / insertions
 #endif
     for (int t = 0; t < T; ++t) {
-        const int buf = NST == 2 ? (t & 1) : (t % 3);
+        const int buf = t & 1;
 #ifdef LVS_TUNING
         if (a.debug_hot == 4) {  // tuning aid: no wait for the staging loads (results are garbage, timing only)
             __builtin_amdgcn_s_barrier();
         } else
 #endif
         {
-            // this K-step's operands have landed; with three buffers the loads of the NEXT K-step (the newest 4 + QG of
-            // this wave, loads return in issue order) stay in flight across the barrier
-            if constexpr (NST == 3)
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 + QG) : "memory");
-            else
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
         }
         if (MODE == LVS_MODE_TOPK && ks_in_tile == nk - 1) {
@@ -318,8 +293,17 @@ __global__ __launch_bounds__(512, 2) void lvs_tile_kernel(const LvsTileArgs a) {
         // next K-step's source: uniform 64-bit bases (SGPRs) + constant per-lane 32-bit byte offsets, advanced
         // incrementally (no divisions, no per-load 64-bit VALU).  The step after the last one re-loads the last
         // K-step into the idle buffer (never read), so there is no branch around the loads.
-        char* n_base = smem + (NST == 2 ? (buf ^ 1) : ((t + 2) % 3)) * STAGE_BYTES;
-        if (t + AHEAD < T) advance_prefetch();
+        char* n_base = smem + (buf ^ 1) * STAGE_BYTES;
+        if (t + 1 < T) {
+            if (++n_r == nkd) {
+                n_r = 0;
+                if (++n_seg == a.nseg) {
+                    n_seg = 0;
+                    ++n_tile;
+                    set_tile_offsets(n_tile);
+                }
+            }
+        }
         const char* c_sbase = (const char*)xb + ((long long)(tile0 + n_tile) * BC * ldb + a.seg_c[n_seg] + n_r * BK) * 2;
         const char* q_sbase = (const char*)xq + (q0 * ldq + a.seg_q[n_seg] + n_r * BK) * 2;
         lvs_kstep::run<MI, QG>(sb, n_base, c_sbase, q_sbase, c_loff, q_loff, wave, a_base, b_base, foff, acc);
@@ -751,20 +735,20 @@ __global__ __launch_bounds__(512, 2) void lvs_tile_kernel(const LvsTileArgs a) {
     }
 }
 
-template <int MODE, int MI, int NST = 2>
+template <int MODE, int MI>
 static hipError_t launch_one(const LvsTileArgs& a, hipStream_t stream) {
     static LvsPerDeviceOnce attr;  // one per instantiation; the attribute is a per-device property
-    constexpr int lds = Geo<MI, NST>::LDS_TOTAL;
+    constexpr int lds = Geo<MI>::LDS_TOTAL;
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
     if (!attr.done(dev, (size_t)lds)) {
-        e = hipFuncSetAttribute((const void*)lvs_tile_kernel<MODE, MI, NST>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        e = hipFuncSetAttribute((const void*)lvs_tile_kernel<MODE, MI>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return e;
         attr.set(dev, (size_t)lds);
     }
     dim3 grid(lvs_tile_grid_blocks(a.nqt, a.nslab, a.gq, a.lead_slabs)), block(512);
-    hipLaunchKernelGGL((lvs_tile_kernel<MODE, MI, NST>), grid, block, lds, stream, a);
+    hipLaunchKernelGGL((lvs_tile_kernel<MODE, MI>), grid, block, lds, stream, a);
     return hipGetLastError();
 }
 
@@ -773,8 +757,6 @@ static hipError_t launch_one(const LvsTileArgs& a, hipStream_t stream) {
 hipError_t lvs_tile_launch(int mode, const LvsTileArgs& a, hipStream_t stream) {
     if (a.bq == LVS3_BQ) {
         if (mode != LVS_MODE_TOPK || a.k > LVS3_KCAP) return hipErrorInvalidValue;
-        // short lists leave room for a third staging buffer: two K-steps of loads in flight (few-query-tile launches)
-        if (a.k <= LVS2_KCAP && !a.ub && lvs_tune("LVS_NST3", 1) != 0) return launch_one<LVS_MODE_TOPK, 2, 3>(a, stream);
         return launch_one<LVS_MODE_TOPK, 2>(a, stream);
     }
     if (a.bq != LVS2_BQ || a.k > LVS2_KCAP || a.ub) return hipErrorInvalidValue;
