@@ -23,6 +23,8 @@ for w in $what; do
     kmdebug) timeout -k 10 600 python tools/kmeans_bounds_debug.py > $out/kmdebug.log 2>&1; tail -60 $out/kmdebug.log ;;
     kmtime) timeout -k 10 600 python tools/kmeans_iter_workload.py 10000000 both blobs > $out/kmtime.log 2>&1; tail -20 $out/kmtime.log ;;
     kmtrace) timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kmtrace -o km -- python tools/kmeans_iter_workload.py 10000000 bounds blobs > $out/kmtrace.log 2>&1; grep iterations $out/kmtrace.log ;;
+    sweep5) timeout -k 10 900 python tools/r05_sweep.py $SWEEP > $out/sweep5.log 2>&1; grep -v "^\[" $out/sweep5.log | tail -80 ;;
+    refgemm) timeout -k 10 300 python tools/ref_gemm.py > $out/ref_gemm.log 2>&1; cat $out/ref_gemm.log ;;
     tcall) timeout -k 10 600 python tools/tcall_probe.py > $out/tcall.log 2>&1; cat $out/tcall.log ;;
     pyfix) timeout -k 10 900 python -m pytest tests -m gpu -q -k "$PYK" --timeout 600 -p no:cacheprovider > $out/pytest_fix.log 2>&1; tail -30 $out/pytest_fix.log ;;
     smoke) timeout -k 10 300 python -c 'import __graft_entry__ as g; g.smoke()' > $out/smoke.log 2>&1; tail -3 $out/smoke.log ;;
