@@ -697,7 +697,7 @@ int tile_seed_tiles(int64_t nq, int64_t nb, int k) {
 }
 
 int make_plan(int64_t nq, int64_t nb, int32_t d, int32_t xb_pack, int32_t xq_pack, int32_t k, Plan& p,
-              bool force_v2 = false, int64_t min_slabs = 0, int64_t max_slabs_cap = 0) {
+              bool force_v2 = false, int64_t min_slabs = 0, int64_t max_slabs_cap = 0, bool allow_l2 = true) {
     if (nq < 0 || nb < 0 || d <= 0 || k < 0) return LVS_EINVAL;
     if (xb_pack != LVS_PACK_F16 && xb_pack != LVS_PACK_SPLIT) return LVS_EINVAL;
     if (xq_pack != LVS_PACK_F16 && xq_pack != LVS_PACK_SPLIT) return LVS_EINVAL;
@@ -742,7 +742,7 @@ int make_plan(int64_t nq, int64_t nb, int32_t d, int32_t xb_pack, int32_t xq_pac
     // +9 % on the main loop, 100 k x 500 k 78.1 -> 72.6 ms, 100 k x 250 k 41.5 -> 38.5 ms, no difference at 100 k x 125 k
     // (12 slabs of 40 tiles) - so it is used whenever >= 8 narrow slabs of >= 40 tiles exist.
     int64_t slabs_l2 = 0;
-    if (p.v2 && p.gq > 8 && p.nqt >= 64 && min_slabs == 0) {
+    if (allow_l2 && p.v2 && p.gq > 8 && p.nqt >= 64 && min_slabs == 0) {
         const int64_t l2_min_slabs = lvs_tune("LVS_L2_MIN_SLABS", 8);
         const int64_t n8 = lvs_round_up(want > l2_min_slabs ? want : l2_min_slabs, 4);
         const int64_t min_tiles = lvs_tune("LVS_L2_MIN_TILES", 40);
@@ -790,12 +790,14 @@ int make_plan(int64_t nq, int64_t nb, int32_t d, int32_t xb_pack, int32_t xq_pac
         const int64_t hi_lim = slabs_l2 > 0 ? lead + p.ntiles / lvs_tune("LVS_L2_MIN_TILES", 40) : max_slabs;
         double best_cost = 1e30;
         int64_t best = s;
-        for (int64_t c = lead + gs; c <= s + s / 4 && c <= hi_lim && c <= p.ntiles; c += gs) {
-            if (10 * c < 3 * s) continue;  // stay within [0.3 s, 1.25 s]
+        const int64_t step = lvs_tune("LVS_TAIL_STEP1", 0) != 0 ? 1 : gs;
+        const double item_cost = (double)lvs_tune("LVS_ITEM_COST", 2);
+        for (int64_t c = lead + step; c <= s + s / 4 && c <= hi_lim && c <= p.ntiles; c += step) {
+            if (10 * c < lvs_tune("LVS_TAIL_LO", 3) * s) continue;  // stay within [0.3 s, 1.25 s]
             const int64_t tps = lvs_ceil_div(p.ntiles, c), ns = lvs_ceil_div(p.ntiles, tps);
             const int rounds = lvs_tile_xcd_rounds(p.nqt, (int)ns, p.gq, (int)lead);
             // an item also pays a list cold start and its candidate write-out: about two tiles' worth
-            const double cost = (double)rounds * (double)(tps + 2);
+            const double cost = (double)rounds * ((double)tps + item_cost);
             const int64_t dist = c > s ? c - s : s - c, bdist = best > s ? best - s : s - best;
             if (cost < best_cost - 1e-9 || (cost < best_cost + 1e-9 && dist < bdist)) {
                 best_cost = cost;
@@ -810,6 +812,12 @@ int make_plan(int64_t nq, int64_t nb, int32_t d, int32_t xb_pack, int32_t xq_pac
     }
     p.tiles_per_slab = (int)lvs_ceil_div(p.ntiles, s);
     p.nslab = (int)lvs_ceil_div(p.ntiles, p.tiles_per_slab);
+    // The 8 x 4 groups with a leading slab pay off on LONG slabs only.  Same box, 1 M rows (profiles/r05c_sweep.log): 30 k / 50 k
+    // queries (17 x 230 / 9 x 435 tiles) 43.6 / 70.6 ms against 45.6 / 72.9 ms with wide groups, but 20 k / 25 k queries, where the
+    // item count pushes the plan to 45 x 87 / 49 x 80 tiles, 31.6 / 37.6 ms against 29.2 / 37.0 ms: with slabs that short the lead
+    // phase and the four concurrent cold-ish lists per query cost more than the shared L2 stream returns.
+    if (slabs_l2 > 0 && p.tiles_per_slab < lvs_tune("LVS_L2_MIN_FINAL", 0) && !lvs_tune_set("LVS_GQ") && !lvs_tune_set("LVS_NSLAB"))
+        return make_plan(nq, nb, d, xb_pack, xq_pack, k, p, force_v2, min_slabs, max_slabs_cap, false);
 #ifdef LVS_TUNING
     if (lvs_tune("LVS_PLAN_PRINT", 0) != 0)
         fprintf(stderr, "lvs plan: nq %lld nb %lld k %d -> nqt %d ntiles %d gq %d lead %d slabs %d x %d tiles, items %lld, xcd rounds %d\n",

@@ -19,7 +19,7 @@ j = torch.randint(0, nb, (nmax,), generator=g, device=be.device)
 xq = torch.nn.functional.normalize(0.7 * xb[j].float() + 0.7 * torch.nn.functional.normalize(torch.randn((nmax, d), generator=g, device=be.device), dim=1), dim=1).to(torch.float16)
 cb, cq = be.pack(xb, _capi.PACK_F16), be.pack(xq, _capi.PACK_F16)
 del xb, xq
-KNOBS = ("LVS_LEAD", "LVS_GQ", "LVS_NSLAB", "LVS_L2_MIN_SLABS", "LVS_L2_MIN_TILES", "LVS_TAIL", "LVS_PLAN_PRINT")
+KNOBS = ("LVS_ITEM_COST", "LVS_TAIL_LO", "LVS_TAIL_STEP1", "LVS_L2_MIN_FINAL", "LVS_LEAD", "LVS_GQ", "LVS_NSLAB", "LVS_L2_MIN_SLABS", "LVS_L2_MIN_TILES", "LVS_TAIL", "LVS_PLAN_PRINT")
 
 
 def run(q, reps):
@@ -40,7 +40,18 @@ def run(q, reps):
     return best_k, best_w, keys
 
 
-def sweep(nq, variants, reps):
+def sweep(nq, variants, reps, rows=None):
+    global cb
+    full = cb
+    if rows is not None:
+        cb = be.slice_rows(full, 0, rows)
+    try:
+        _sweep(nq, variants, reps)
+    finally:
+        cb = full
+
+
+def _sweep(nq, variants, reps):
     q = be.slice_rows(cq, 0, nq)
     ref = None
     for tag, env in variants:
@@ -53,8 +64,8 @@ def sweep(nq, variants, reps):
         km, wm, keys = run(q, reps)
         if ref is None:
             ref = keys.clone()
-        fl = 2.0 * nq * nb * d
-        print(f"{nq:>6} q  {tag:<34} kernel {km:8.3f} ms  wall {wm:8.3f} ms  {fl / (km * 1e-3) / 1e12:7.1f} TFLOP/s  "
+        fl = 2.0 * nq * cb.n * d
+        print(f"{nq:>6} x {cb.n:>7}  {tag:<34} kernel {km:8.3f} ms  wall {wm:8.3f} ms  {fl / (km * 1e-3) / 1e12:7.1f} TFLOP/s  "
               f"{nb * d * 2 / (km * 1e-3) / 1e12:5.2f} TB/s  identical={bool((keys == ref).all())}", flush=True)
 
 
@@ -74,3 +85,14 @@ if "gq" in what:
          ("32 x 1 groups", {"LVS_GQ": "32"}), ("8 x 4, 9 slabs", {"LVS_NSLAB": "9"}), ("8 x 4, 17 slabs", {"LVS_NSLAB": "17"}),
          ("8 x 4, 25 slabs", {"LVS_NSLAB": "25"})]
     sweep(100_000, v, 2)
+
+if "plan" in what:
+    V = [("shipped", {}),
+         ("item cost 6", {"LVS_ITEM_COST": "6", "LVS_TAIL_STEP1": "1", "LVS_TAIL_LO": "2"}),
+         ("item cost 12", {"LVS_ITEM_COST": "12", "LVS_TAIL_STEP1": "1", "LVS_TAIL_LO": "2"}),
+         ("item cost 20", {"LVS_ITEM_COST": "20", "LVS_TAIL_STEP1": "1", "LVS_TAIL_LO": "2"}),
+         ("item cost 12, wide groups under 120-tile slabs", {"LVS_ITEM_COST": "12", "LVS_TAIL_STEP1": "1", "LVS_TAIL_LO": "2", "LVS_L2_MIN_FINAL": "120"}),
+         ("wide groups under 120-tile slabs", {"LVS_L2_MIN_FINAL": "120"})]
+    for nq, rows in ((100_000, 125_000), (100_000, 250_000), (50_000, 250_000), (25_000, 500_000), (12_500, None), (20_000, None),
+                     (25_000, None), (10_000, None), (4096, None), (100_000, None)):
+        sweep(nq, V, 2 if nq * (rows or nb) >= 2e10 else 4, rows)
