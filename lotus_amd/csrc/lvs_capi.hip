@@ -790,14 +790,15 @@ int make_plan(int64_t nq, int64_t nb, int32_t d, int32_t xb_pack, int32_t xq_pac
         const int64_t hi_lim = slabs_l2 > 0 ? lead + p.ntiles / lvs_tune("LVS_L2_MIN_TILES", 40) : max_slabs;
         double best_cost = 1e30;
         int64_t best = s;
-        const int64_t step = lvs_tune("LVS_TAIL_STEP1", 0) != 0 ? 1 : gs;
-        const double item_cost = (double)lvs_tune("LVS_ITEM_COST", 2);
-        for (int64_t c = lead + step; c <= s + s / 4 && c <= hi_lim && c <= p.ntiles; c += step) {
-            if (10 * c < lvs_tune("LVS_TAIL_LO", 3) * s) continue;  // stay within [0.3 s, 1.25 s]
+        for (int64_t c = lead + gs; c <= s + s / 4 && c <= hi_lim && c <= p.ntiles; c += gs) {
+            if (10 * c < 3 * s) continue;  // stay within [0.3 s, 1.25 s]
             const int64_t tps = lvs_ceil_div(p.ntiles, c), ns = lvs_ceil_div(p.ntiles, tps);
             const int rounds = lvs_tile_xcd_rounds(p.nqt, (int)ns, p.gq, (int)lead);
-            // an item also pays a list cold start and its candidate write-out: about two tiles' worth
-            const double cost = (double)rounds * ((double)tps + item_cost);
+            // an item also pays a list cold start and its candidate write-out: about two tiles' worth.  (Round 4 swept a larger
+            // fixed cost - 6, 12, 20 tiles, i.e. fewer and longer slabs - over ten shapes: slower everywhere, by up to 19 % at
+            // 100 k x 125 k with 3 x 163 instead of 9 x 55 tiles; fine items balance the XCDs better than the round count
+            // says.  profiles/r05d_plan_sweep.log)
+            const double cost = (double)rounds * (double)(tps + 2);
             const int64_t dist = c > s ? c - s : s - c, bdist = best > s ? best - s : s - best;
             if (cost < best_cost - 1e-9 || (cost < best_cost + 1e-9 && dist < bdist)) {
                 best_cost = cost;
@@ -812,11 +813,12 @@ int make_plan(int64_t nq, int64_t nb, int32_t d, int32_t xb_pack, int32_t xq_pac
     }
     p.tiles_per_slab = (int)lvs_ceil_div(p.ntiles, s);
     p.nslab = (int)lvs_ceil_div(p.ntiles, p.tiles_per_slab);
-    // The 8 x 4 groups with a leading slab pay off on LONG slabs only.  Same box, 1 M rows (profiles/r05c_sweep.log): 30 k / 50 k
-    // queries (17 x 230 / 9 x 435 tiles) 43.6 / 70.6 ms against 45.6 / 72.9 ms with wide groups, but 20 k / 25 k queries, where the
-    // item count pushes the plan to 45 x 87 / 49 x 80 tiles, 31.6 / 37.6 ms against 29.2 / 37.0 ms: with slabs that short the lead
-    // phase and the four concurrent cold-ish lists per query cost more than the shared L2 stream returns.
-    if (slabs_l2 > 0 && p.tiles_per_slab < lvs_tune("LVS_L2_MIN_FINAL", 0) && !lvs_tune_set("LVS_GQ") && !lvs_tune_set("LVS_NSLAB"))
+    // With around a hundred query tiles the item count pushes the 8 x 4 plan to 45-49 slabs of 40-90 tiles, and there the wide
+    // groups win (same box, profiles/r05d_plan_sweep.log: 20 k x 1 M 31.1 -> 28.5 ms, 25 k x 1 M 36.7 -> 35.6, 25 k x 500 k 19.4 ->
+    // 18.6); with 196 / 391 query tiles the 8 x 4 groups stay ahead even on 55-109-tile slabs (100 k x 125 k 20.0 vs 20.5 ms,
+    // 100 k x 250 k 37.4 vs 38.6), and from 118 query tiles on the slabs are long anyway.
+    if (slabs_l2 > 0 && p.nqt <= lvs_tune("LVS_L2_SHORT_NQT", 128) && p.tiles_per_slab < lvs_tune("LVS_L2_MIN_FINAL", 120) &&
+        !lvs_tune_set("LVS_GQ") && !lvs_tune_set("LVS_NSLAB"))
         return make_plan(nq, nb, d, xb_pack, xq_pack, k, p, force_v2, min_slabs, max_slabs_cap, false);
 #ifdef LVS_TUNING
     if (lvs_tune("LVS_PLAN_PRINT", 0) != 0)

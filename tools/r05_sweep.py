@@ -19,7 +19,7 @@ j = torch.randint(0, nb, (nmax,), generator=g, device=be.device)
 xq = torch.nn.functional.normalize(0.7 * xb[j].float() + 0.7 * torch.nn.functional.normalize(torch.randn((nmax, d), generator=g, device=be.device), dim=1), dim=1).to(torch.float16)
 cb, cq = be.pack(xb, _capi.PACK_F16), be.pack(xq, _capi.PACK_F16)
 del xb, xq
-KNOBS = ("LVS_ITEM_COST", "LVS_TAIL_LO", "LVS_TAIL_STEP1", "LVS_L2_MIN_FINAL", "LVS_LEAD", "LVS_GQ", "LVS_NSLAB", "LVS_L2_MIN_SLABS", "LVS_L2_MIN_TILES", "LVS_TAIL", "LVS_PLAN_PRINT")
+KNOBS = ("LVS_L2_MIN_FINAL", "LVS_L2_SHORT_NQT", "LVS_LEAD", "LVS_GQ", "LVS_NSLAB", "LVS_L2_MIN_SLABS", "LVS_L2_MIN_TILES", "LVS_TAIL", "LVS_PLAN_PRINT")
 
 
 def run(q, reps):
@@ -87,12 +87,10 @@ if "gq" in what:
     sweep(100_000, v, 2)
 
 if "plan" in what:
-    V = [("shipped", {}),
-         ("item cost 6", {"LVS_ITEM_COST": "6", "LVS_TAIL_STEP1": "1", "LVS_TAIL_LO": "2"}),
-         ("item cost 12", {"LVS_ITEM_COST": "12", "LVS_TAIL_STEP1": "1", "LVS_TAIL_LO": "2"}),
-         ("item cost 20", {"LVS_ITEM_COST": "20", "LVS_TAIL_STEP1": "1", "LVS_TAIL_LO": "2"}),
-         ("item cost 12, wide groups under 120-tile slabs", {"LVS_ITEM_COST": "12", "LVS_TAIL_STEP1": "1", "LVS_TAIL_LO": "2", "LVS_L2_MIN_FINAL": "120"}),
-         ("wide groups under 120-tile slabs", {"LVS_L2_MIN_FINAL": "120"})]
+    # (round 4 also swept a larger per-item cost in the slab-count model - fewer, longer slabs: slower everywhere,
+    # profiles/r05d_plan_sweep.log)
+    V = [("shipped", {}), ("8 x 4 groups whatever the slab length", {"LVS_L2_MIN_FINAL": "0"}),
+         ("wide groups under 120-tile slabs at any size", {"LVS_L2_SHORT_NQT": "100000"})]
     for nq, rows in ((100_000, 125_000), (100_000, 250_000), (50_000, 250_000), (25_000, 500_000), (12_500, None), (20_000, None),
                      (25_000, None), (10_000, None), (4096, None), (100_000, None)):
         sweep(nq, V, 2 if nq * (rows or nb) >= 2e10 else 4, rows)
