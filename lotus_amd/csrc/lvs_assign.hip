@@ -92,10 +92,15 @@ __global__ __launch_bounds__(512, 2) void lvs_assign_kernel(const AssignArgs a) 
     const int nkd = a.nkd;
     const bool l2 = a.metric == LVS_METRIC_L2;
 
-    if (tid < BC) {  // visible after the first K-step's barrier
+    // The accumulators START at -|y|^2 / 2 (0 under inner product), so the matrix cores deliver v = q.y - |y|^2 / 2 - the order
+    // value u / 2 of squared L2 - and the epilogue needs no multiply-add per score (four VALU operations per score instead of
+    // five; the epilogue's VALU work, not MFMA, is what separates this kernel from the list kernel's rate).  Rows past the end
+    // start at a finite sentinel: they never win, and the position tags stay meaningful.
+    if (tid < BC) {
         const long long row = c0 + tid;
-        bnl[tid] = row < a.nb ? (l2 ? a.bn[row] : 0.f) : 3.0e38f;  // rows past the end never win (finite: scores carry tags)
+        bnl[tid] = row < a.nb ? (l2 ? -0.5f * a.bn[row] : 0.f) : -1.5e38f;  // the accumulators' starting values, as stored
     }
+    __syncthreads();
 
     // staging: wave stages corpus rows [wave*32, +32) and query rows [wave*32, +32), 8 rows per load
     const int srow = lane >> 3, sp = lane & 7;
@@ -135,20 +140,32 @@ __global__ __launch_bounds__(512, 2) void lvs_assign_kernel(const AssignArgs a) 
     const int a_base = (wm * MI * 32) * ROWB;
     const int b_base = BC * ROWB + (wn * 64) * ROWB;
 
+    const int lrow_base = wm * (MI * 32) + 4 * (lane >> 5);
     f32x16 acc[MI][2];
+    // both query blocks start from the same per-row values: two LDS reads straight into the accumulator registers (asm: the
+    // compiler would read once and copy with 128 VALU moves - VALU issue slots are what this kernel is short of)
+    const unsigned bnl_addr = (unsigned)(unsigned long long)(bnl + lrow_base);
+    auto init_acc = [&]() {
+        lvs_kstep::static_for<MI * 4>([&](auto ic) {
+            constexpr int mi = decltype(ic)::value / 4, r4 = decltype(ic)::value % 4;
+            f32x4 h0, h1;
+            asm volatile("ds_read_b128 %0, %2 offset:%3\n\tds_read_b128 %1, %2 offset:%3"
+                         : "=&v"(h0), "=&v"(h1)
+                         : "v"(bnl_addr), "n"((mi * 32 + 8 * r4) * 4));
 #pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+            for (int e = 0; e < 4; ++e) {
+                acc[mi][0][r4 * 4 + e] = h0[e];
+                acc[mi][1][r4 * 4 + e] = h1[e];
+            }
+        });
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    };
+    init_acc();
 
     const int T = (tile1 - tile0) * nkd;
     int n_tile = 0, n_r = 0;  // (query tile, k-block) of the K-step being prefetched
     int ks = 0, ti = 0;
     if (wave >= 4) __builtin_amdgcn_s_setprio(1);
-    const float cs = l2 ? 2.0f : 1.0f;
-    const int lrow_base = wm * (MI * 32) + 4 * (lane >> 5);
     const int holder = wm * 2 + (lane >> 5);
     for (int t = 0; t < T; ++t) {
         const int buf = t & 1;
@@ -177,25 +194,14 @@ __global__ __launch_bounds__(512, 2) void lvs_assign_kernel(const AssignArgs a) 
         lvs_kstep::static_for<MI>([&](auto mic) {
             constexpr int mi = decltype(mic)::value;
 #pragma unroll
-            for (int r4 = 0; r4 < 4; ++r4) {
-                const f32x4 bn4 = *(const f32x4*)(bnl + lrow_base + mi * 32 + 8 * r4);
+            for (int r = 0; r < 16; ++r)
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
-#pragma unroll
-                    for (int ni = 0; ni < 2; ++ni) {
-                        const float u = __builtin_fmaf(cs, acc[mi][ni][r4 * 4 + e], -bn4[e]);
-                        const float up = __uint_as_float((__float_as_uint(u) & 0xFFFFFFC0u) | (uint32_t)(mi * 16 + r4 * 4 + e));
-                        top3_insert(up, bu[ni], su[ni], tu[ni]);
-                    }
-                __builtin_amdgcn_sched_barrier(0);  // keep the norm reads next to their uses (register footprint)
-            }
+                for (int ni = 0; ni < 2; ++ni) {
+                    const float up = __uint_as_float((__float_as_uint(acc[mi][ni][r]) & 0xFFFFFFC0u) | (uint32_t)(mi * 16 + r));
+                    top3_insert(up, bu[ni], su[ni], tu[ni]);
+                }
         });
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+        init_acc();
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni) {
             float* p = part + ((wn * 64 + ni * 32 + (lane & 31)) * 4 + holder) * 3;
@@ -209,7 +215,8 @@ __global__ __launch_bounds__(512, 2) void lvs_assign_kernel(const AssignArgs a) 
             const float* p = part + tid * 12;
             float B = -INFINITY, S = -INFINITY, Tt = -INFINITY;
             u64 k1 = 0, k2 = 0;
-            auto score_of = [&](float u) { return u > -1.0e38f ? (l2 ? -fmaxf(qn_v - u, 0.f) : u) : -INFINITY; };
+            // v = q.y - |y|^2 / 2 (tagged): squared L2 = |q|^2 - 2 v; the doubling is exact and leaves the tag bits alone
+            auto score_of = [&](float v) { return v > -1.0e38f ? (l2 ? -fmaxf(qn_v - 2.0f * v, 0.f) : v) : -INFINITY; };
 #pragma unroll
             for (int h = 0; h < 4; ++h) {
 #pragma unroll
