@@ -276,6 +276,7 @@ def legs_summary(out, legs):
         "kmeans_first_divergence_iteration": km.get("first_divergence_iteration"),
         "kmeans_all_flips_are_near_ties": km.get("all_flips_are_near_ties"),
         "fp32_10k_x_1M_ms": (legs.get("fp32_10k_x_1M") or {}).get("one_pass_ms"),
+        "fp32_join_100k_x_1M_ms": g("fp32_join_100k_x_1M", "ms_per_call"),
     }
 
 
@@ -582,11 +583,31 @@ def fp32_leg(ctx, legs):
         res32[tag + "_ms"] = (time.perf_counter() - t0) / 3 * 1e3
         if one_pass:
             res32["uncertified_fraction"] = stats["uncertified"] / max(1, stats["queries"])
+            res32["plain_search_fraction"] = stats.get("plain", 0) / max(1, stats["queries"])  # still open after the 56-deep round
     _, Ia = be.keys_to_result(got["plain_3seg"], _capi.METRIC_IP)
     _, Ib = be.keys_to_result(got["one_pass"], _capi.METRIC_IP)
     res32["one_pass_ids_equal_plain"] = float((Ia == Ib).float().mean().item())
     res32["fp16_same_shape_ms"] = (legs.get("cfg2_10k_x_1M") or {}).get("ms_per_call")
     legs["fp32_10k_x_1M"] = res32
+    # the headline join with LOTUS's default storage on both sides (faiss_vs.py:24): 100 k fp32 queries x 1 M fp32 rows
+    xq = torch.from_numpy(ctx["xq_h"]).to(dev).float()
+    xq += 1e-4 * torch.randn(xq.shape, generator=g, device=dev)
+    q32 = be.pack(torch.nn.functional.normalize(xq, dim=1), _capi.PACK_SPLIT)
+    del xq
+    stats = {}
+    be.search_keys(c32, q32, k, _capi.METRIC_IP)
+    be.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(2):
+        be.search_keys(c32, q32, k, _capi.METRIC_IP, stats=stats)
+    be.synchronize()
+    ms = (time.perf_counter() - t0) / 2 * 1e3
+    legs["fp32_join_100k_x_1M"] = {"ms_per_call": ms, "queries_per_s": q32.n / (ms * 1e-3), "bound": "mfma",
+                                   "frac": 2.0 * q32.n * c32.n * d / (ms * 1e-3) / 1e12 / PEAK_FP16_MFMA_TFLOPS,
+                                   "uncertified_fraction": stats["uncertified"] / max(1, stats["queries"]),
+                                   "plain_search_fraction": stats.get("plain", 0) / max(1, stats["queries"]),
+                                   "note": "fp32 embeddings as fp16 hi|lo rows, exact (fp32-accurate) top-k through the certified "
+                                           "one-pass search; frac counts 2 Q N d once, as for fp16 storage"}
 
 
 def t_call_leg(ctx, legs):

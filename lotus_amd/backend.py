@@ -428,7 +428,7 @@ class HipBackend:
                 self._stream())
         return keys
 
-    def _search_keys_certified(self, corpus, queries, k, metric, id_offset, stats):
+    def _search_keys_certified(self, corpus, queries, k, metric, id_offset, stats, k1=None):
         """Exact top-k of fp32-accurate operands from one MFMA pass (see ``search_keys``).
 
         The one-pass score of a pair differs from the exact one by at most ``|q| |lo_row| + |lo_q| |row| <= 2^-11 |q| R``
@@ -438,7 +438,9 @@ class HipBackend:
         exact top k is the exact top k."""
         torch = self.torch
         nq = queries.n
-        k1 = 15 if k <= 10 else min(56, k + 8)
+        first_round = k1 is None
+        if first_round:
+            k1 = 15 if k <= 10 else min(56, k + 8)
         k1 = min(k1, corpus.n)
         approx = self._search_call("lvs_flat_search_keys_hi", corpus, queries, k1, metric, id_offset)
         exact = approx.clone()
@@ -462,12 +464,25 @@ class HipBackend:
                 _ptr(idx), _ptr(cnt), self._stream())
         keys = exact[:, :k].contiguous()
         n_open = int(cnt.item())
+        n_plain = 0
         if n_open:
             sel = idx[:n_open]
-            keys[sel] = self.search_keys(corpus, self.gather(queries, sel), k, metric, id_offset=id_offset, one_pass=False)
+            sub = self.gather(queries, sel)
+            if first_round and k1 < min(56, corpus.n):
+                # second round for the few open queries: the same one-pass search with the longest lists (56 slots) - a row
+                # outside a 56-deep list is far below the k-th exact score unless the query sits in a dense tie - before
+                # anyone pays the 2-3 segment plain search (1 % of 10 k x 1 M fp32 queries: 1.2 ms of plain search -> 0.4 ms)
+                inner = {}
+                keys[sel] = self._search_keys_certified(corpus, sub, k, metric, id_offset, inner, k1=56)
+                n_plain = inner.get("plain", 0)
+            else:
+                keys[sel] = self.search_keys(corpus, sub, k, metric, id_offset=id_offset, one_pass=False)
+                n_plain = n_open
         if stats is not None:
-            stats["uncertified"] = stats.get("uncertified", 0) + n_open
-            stats["queries"] = stats.get("queries", 0) + nq
+            if first_round:
+                stats["uncertified"] = stats.get("uncertified", 0) + n_open
+                stats["queries"] = stats.get("queries", 0) + nq
+            stats["plain"] = stats.get("plain", 0) + n_plain
         return keys
 
     def nearest(self, corpus: PackedRows, queries: PackedRows, metric: int, id_offset: int = 0, stats: dict | None = None,

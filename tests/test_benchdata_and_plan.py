@@ -48,7 +48,8 @@ def test_split_planner():
     for w in (1, 2, 4, 8):
         gq, gc = plan.pick_split(w)
         assert gq * gc == w
-    assert plan.pick_split(8) == (1, 8)                       # configs[2]: a tie between the splits -> most corpus shards
+    assert plan.pick_split(8) == (8, 1)                       # configs[2] fits every GPU: the query split runs ~2 points faster
+    assert plan.pick_split(2) in ((1, 2), (2, 1))
     assert plan.pick_split(8, nq=100_000, nb=400_000_000) == (1, 8)   # 614 GB of corpus: only the row split fits
     assert plan.pick_split(8, nq=1_000_000, nb=8_000)[0] > 1  # a corpus of a few tiles: split the queries instead
     f = plan.projected_fraction
