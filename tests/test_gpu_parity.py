@@ -528,7 +528,18 @@ def test_one_pass_certificate_refuses_rows_that_differ_below_fp16_resolution(hip
     Dg, Ig = (t.cpu().numpy() for t in be.keys_to_result(be.search_keys(cb, cq, 10, IP, one_pass=True, stats=stats), IP))
     Dw, Iw = (t.cpu().numpy() for t in be.keys_to_result(be.search_keys(cb, cq, 10, IP, one_pass=False), IP))
     assert stats["uncertified"] >= 60
-    assert np.array_equal(Ig, Iw) and np.abs(Dg - Dw).max() <= 1e-6
+    # the 30 near-copies of a query's row score within ~1e-7 of each other: which of them two exact float32 evaluations (the
+    # certified path's rescoring dot products, the plain MFMA search) rank first is rounding - so the lists are compared with
+    # the float64 truth on the stored values: the right scores at every rank, every reported row scoring what is reported
+    assert np.abs(Dg - Dw).max() <= 1e-6
+    sb, sq = _stored(xb, SPLIT).astype(np.float64), _stored(xq, SPLIT).astype(np.float64)
+    truth = sq @ sb.T
+    top = -np.sort(-truth, axis=1)[:, :10]
+    rows = np.arange(len(xq))[:, None]
+    for D, I in ((Dg, Ig), (Dw, Iw)):
+        assert np.abs(D - top).max() <= 1e-6 and np.abs(truth[rows, I] - D).max() <= 1e-6
+        assert all(len(set(r)) == 10 for r in I.tolist())
+    assert (Ig[:, 0] == np.arange(64)).all() or np.abs(truth[np.arange(64), Ig[:, 0]] - top[:, 0]).max() <= 1e-6
 
 
 @pytest.mark.parametrize("nq,nb,d", [(100_000, 125_000, 32), (50_000, 250_000, 64), (16_384, 700_000, 32),
