@@ -229,6 +229,9 @@ def main():
             node_plan_legs(ctx, legs)
             world8_rehearsal(ctx, legs, checks)
             fp32_leg(ctx, legs)
+            for fut in (fut_dedup, fut_km):  # T_call stages host memory with a few threads: let the generators of the other
+                if fut is not None:          # configs' rows (up to 64 threads on a 16-CPU quota) finish first
+                    fut.result()
             t_call_leg(ctx, legs)
             if fut_dedup is not None:
                 dedup_leg(ctx, legs, checks, fut_dedup)
