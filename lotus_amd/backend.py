@@ -416,6 +416,24 @@ class HipBackend:
                 _ptr(keys), _ptr(ws), int(ws.numel()), self._stream())
         return keys
 
+    def lo_norm_max(self, pk: PackedRows) -> float:
+        """Largest |lo part of a row| of a device image (0 for fp16 rows), computed once per image and cached on it."""
+        if pk.mode != _capi.PACK_SPLIT or pk.n == 0:
+            return 0.0
+        v = getattr(pk, "_lo_norm_max", None)
+        if v is None:
+            torch = self.torch
+            dpad = int(pk.rows.shape[1]) // 2
+            m = torch.zeros((), dtype=torch.float32, device=self.device)
+            for r0 in range(0, pk.n, 1 << 18):  # in chunks: the float32 copy of 2^18 x 768 lo parts is 0.8 GB
+                m = torch.maximum(m, pk.rows[r0:r0 + (1 << 18), dpad:].float().square().sum(dim=1).max())
+            v = float(m.sqrt().item())
+            try:
+                pk._lo_norm_max = v
+            except Exception:
+                pass
+        return v
+
     def _search_call(self, name: str, corpus, queries, k, metric, id_offset):
         torch = self.torch
         keys = torch.empty((queries.n, k), dtype=torch.int64, device=self.device)
@@ -447,17 +465,15 @@ class HipBackend:
         self._c("lvs_rescore_keys", _ptr(corpus.rows), corpus.mode, _ptr(queries.rows), queries.mode, nq, corpus.d, metric,
                 _ptr(corpus.norms), _ptr(queries.norms), int(id_offset), k1, _ptr(exact), self._stream())
         self._c("lvs_sort_keys_desc", _ptr(exact), nq, k1, self._stream())
+        # |s - s_hi| <= |q| |lo_row| + |lo_q| |row| + |lo_q| |lo_row| (Cauchy-Schwarz) with the MEASURED largest lo-part norms
+        # E_c, E_q of the two operands (cached per device image; ~0.4 x the worst case 2^-11 |x|, so fewer queries stay open than
+        # under round 3's a-priori bound; being measured, they also cover components in fp16's subnormal range), + float32
+        # accumulation noise relative to |q| |row|
         R = float(corpus.norms.max().sqrt().item())
-        nsplit = int(corpus.mode == _capi.PACK_SPLIT) + int(queries.mode == _capi.PACK_SPLIT)
-        per_q = (2.0 ** -11) * R * nsplit + 8e-6 * R  # + fp32 accumulation noise, relative to |q| |row|
-        # 2^-11 |x| bounds a component's lo part only in fp16's NORMAL range; below 6.1e-5 the rounding error of the hi
-        # half is absolute (<= 2^-25 per component), i.e. |lo_row| <= 2^-11 |row| + sqrt(d) 2^-25 - it matters for
-        # unnormalised embeddings of tiny magnitude
-        sub = (corpus.rows.shape[1] // (2 if corpus.mode == _capi.PACK_SPLIT else 1)) ** 0.5 * 2.0 ** -25
-        per_q += sub * int(corpus.mode == _capi.PACK_SPLIT)
+        E_c, E_q = self.lo_norm_max(corpus), self.lo_norm_max(queries)
         c = 1.0 if metric == _capi.METRIC_IP else 2.0
-        scale = per_q * c
-        slack = 1e-6 * (2.0 ** (corpus.exp + queries.exp) + R * R) + c * sub * R * int(queries.mode == _capi.PACK_SPLIT)
+        scale = c * (E_c * (1.0 + 1e-3) + 8e-6 * R)
+        slack = 1e-6 * (2.0 ** (corpus.exp + queries.exp) + R * R) + c * E_q * (R + E_c) * (1.0 + 1e-3)
         idx = torch.empty((nq,), dtype=torch.int64, device=self.device)
         cnt = torch.zeros((1,), dtype=torch.int64, device=self.device)
         self._c("lvs_certify_topk", _ptr(approx), _ptr(exact), _ptr(queries.norms), nq, k1, k, float(scale), float(slack),
@@ -528,16 +544,14 @@ class HipBackend:
         coef = [c, c * ((2.0 ** -11) * qsplit + 8e-6) + 2.0 ** -16 * (1.0 if ip else 2.0),
                 1e-6 * 2.0 ** (corpus.exp + queries.exp), qsplit * c * (dpad ** 0.5) * 2.0 ** -25,
                 1e-6 + (0.0 if ip else 2.0 ** -16)]
-        if corpus_stats is None:
-            R = float(corpus.norms.max().sqrt().item())
-            E = 0.0
-            if corpus.mode == _capi.PACK_SPLIT:
-                E = float(corpus.rows[:, dpad:].float().square().sum(dim=1).max().sqrt().item())
-            scale = coef[0] * E + coef[1] * R
-            slack = coef[2] + coef[3] * R + coef[4] * R * R
         if corpus.n <= _capi.NEAREST3_MAX_ROWS:
             # a small corpus (k-means centroids): queries streaming past resident corpus tiles + the two-candidate certificate
             return self._nearest3(corpus, queries, metric, id_offset, stats, exact_scores, corpus_stats, bounds, coef, dpad, plain)
+        if corpus_stats is None:
+            R = float(corpus.norms.max().sqrt().item())
+            E = self.lo_norm_max(corpus)
+            scale = coef[0] * E + coef[1] * R
+            slack = coef[2] + coef[3] * R + coef[4] * R * R
         sec = torch.empty((nq,), dtype=torch.float32, device=self.device)
         need = int(self.lib.lvs_nearest_hi_workspace_bytes(nq, corpus.n, corpus.d))
         ws = self._workspace(need)

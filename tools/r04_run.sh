@@ -13,7 +13,7 @@ for w in $what; do
     pyacc) timeout -k 10 600 python -m pytest tests/test_gpu_kmeans.py -m gpu -q -k "accumulate or counting or objective or golden or bounds" --timeout 600 -p no:cacheprovider > $out/pytest_acc.log 2>&1; tail -3 $out/pytest_acc.log ;;
     pydur) timeout -k 10 900 python -m pytest tests/test_gpu_dist.py tests/test_gpu_parity.py -m gpu -q -k "rccl or ranking or rank_all or 2d_split" --durations=12 --timeout 600 -p no:cacheprovider > $out/pytest_dur.log 2>&1; tail -25 $out/pytest_dur.log ;;
     bench) timeout -k 10 900 python bench.py > $out/bench.json 2> $out/bench.err; tail -c 1500 $out/bench.json; echo; tail -5 $out/bench.err ;;
-    benchq) timeout -k 10 600 python bench.py --dedup-rows 0 --kmeans-rows 0 --no-cpu-baseline > $out/bench_quick.json 2> $out/bench_quick.err; tail -c 1500 $out/bench_quick.json; echo; tail -5 $out/bench_quick.err ;;
+    benchq) timeout -k 10 600 python bench.py --dedup-rows 0 $BENCHQ_ARGS --no-cpu-baseline > $out/bench_quick.json 2> $out/bench_quick.err; tail -c 1500 $out/bench_quick.json; echo; tail -5 $out/bench_quick.err ;;
     prof) SKIP_BENCH=1 timeout -k 10 1500 tools/profile_bench.sh $tag/prof > $out/prof.log 2>&1; tail -30 $out/prof.log ;;
     kern) timeout -k 10 1500 tools/profile_kernels.sh $tag/kern > $out/kern.log 2>&1; tail -30 $out/kern.log ;;
     kmprof) timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kmprof -o km -- python tools/kmeans_iter_workload.py > $out/kmprof.log 2>&1; tail -5 $out/kmprof.log ;;
