@@ -348,6 +348,7 @@ class HipBackend:
     # ---- search ----
     CERT_MIN_PAIRS = 1 << 26  # below this many (query, row) pairs the extra launches cost more than the two passes saved
     CERT_MAX_K = 48
+    CERT_SPARE_SMALL_K = 5  # spare list slots of the one-pass search for k <= 10 (k1 = k + spare <= 15)
 
     SEED_EXCHANGE_MIN_QUERIES = 2048  # below this a sharded call is too short for an extra collective (see seed_tiles)
 
@@ -458,7 +459,7 @@ class HipBackend:
         nq = queries.n
         first_round = k1 is None
         if first_round:
-            k1 = 15 if k <= 10 else min(56, k + 8)
+            k1 = min(15, k + self.CERT_SPARE_SMALL_K) if k <= 10 else min(56, k + 8)
         k1 = min(k1, corpus.n)
         approx = self._search_call("lvs_flat_search_keys_hi", corpus, queries, k1, metric, id_offset)
         exact = approx.clone()

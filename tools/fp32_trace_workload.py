@@ -25,3 +25,14 @@ for tag, c, q in (("fp16", c16, q16), ("fp32 one-pass", c32, q32)):
         be.search_keys(c, q, k, 0, stats=st)
     be.synchronize()
     print(f"{tag}: {(time.perf_counter() - t0) / 5 * 1e3:.2f} ms per call  {st}", flush=True)
+for spare in (1, 2, 3, 5):
+    be.CERT_SPARE_SMALL_K = spare
+    for _ in range(2):
+        be.search_keys(c32, q32, k, 0)
+    be.synchronize()
+    st = {}
+    t0 = time.perf_counter()
+    for _ in range(5):
+        be.search_keys(c32, q32, k, 0, stats=st)
+    be.synchronize()
+    print(f"fp32 one-pass, k1 = k + {spare}: {(time.perf_counter() - t0) / 5 * 1e3:.2f} ms per call  {st}", flush=True)
