@@ -86,6 +86,8 @@ scenario("stream_32q_x_2M_d384", MAIN, lambda: be.search_keys(p384, q384, 10, IP
 shard = be.slice_rows(p4m, 0, 125_000)
 scenario("topk_100k_x_125k_shard", "lvs_tile_kernel<0, 4>", lambda: be.search_keys(shard, q100k, 10, IP), 5, bound="mfma",
          flops_per_call=2.0 * 100_000 * 125_000 * D, note="8-GPU shard shape of BASELINE configs[2]")
+scenario("topk_12500_x_1M_split8x1", "lvs_tile_kernel<0, 4>", lambda: be.search_keys(p1m, be.slice_rows(q100k, 0, 12_500), 10, IP), 5,
+         bound="mfma", flops_per_call=2.0 * 12_500 * 1_000_000 * D, note="per-GPU shape of the 8 x 1 query split: 49 query tiles")
 scenario("topk_10k_x_1M_cfg2", "lvs_tile_kernel<0, 4>", lambda: be.search_keys(p1m, be.slice_rows(q100k, 0, 10_000), 10, IP), 5,
          bound="mfma", flops_per_call=2.0 * 10_000 * 1_000_000 * D, note="BASELINE configs[1]")
 scenario("topk_100k_x_1M_cfg3", "lvs_tile_kernel<0, 4>", lambda: be.search_keys(p1m, q100k, 10, IP), 3, warm=1,
@@ -100,7 +102,7 @@ scenario("top1_kmeans_2M_x_1024_hilo", "lvs_tile_kernel<2, 4>", lambda: be.searc
          note="k-means assignment, fp16 points x fp32-accurate (hi|lo) centroids: 2 K segments = 2x the MFMA work")
 scenario("top1_kmeans_2M_x_1024_fp16c", "lvs_tile_kernel<2, 4>", lambda: be.search_keys(pc16, pts, 1, L2), 3, warm=1,
          bound="mfma", flops_per_call=2.0 * 2_000_000 * 1024 * D, note="same with fp16 centroids (1 K segment)")
-scenario("nearest_hi_2M_x_1024", "lvs_tile_kernel<5, 4>", lambda: be.nearest(pc, pts, L2), 3, warm=1,
+scenario("nearest3_2M_x_1024", "lvs_assign_kernel", lambda: be.nearest(pc, pts, L2), 3, warm=1,
          bound="mfma", flops_per_call=2.0 * 2_000_000 * 1024 * D,
          note="certified k-means assignment: ONE pass over the hi parts + margin certificate (same winners as the hi|lo search)")
 x32m = x16[:1_000_000].float()

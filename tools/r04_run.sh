@@ -15,7 +15,7 @@ for w in $what; do
     bench) timeout -k 10 900 python bench.py > $out/bench.json 2> $out/bench.err; tail -c 1500 $out/bench.json; echo; tail -5 $out/bench.err ;;
     benchq) timeout -k 10 600 python bench.py --dedup-rows 0 $BENCHQ_ARGS --no-cpu-baseline > $out/bench_quick.json 2> $out/bench_quick.err; tail -c 1500 $out/bench_quick.json; echo; tail -5 $out/bench_quick.err ;;
     prof) SKIP_BENCH=1 timeout -k 10 1500 tools/profile_bench.sh $tag/prof > $out/prof.log 2>&1; tail -30 $out/prof.log ;;
-    kern) timeout -k 10 1500 tools/profile_kernels.sh $tag/kern > $out/kern.log 2>&1; tail -30 $out/kern.log ;;
+    kern) timeout -k 10 1500 tools/profile_kernels.sh $tag/kern $KERN_SCEN > $out/kern.log 2>&1; tail -30 $out/kern.log ;;
     kmprof) timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kmprof -o km -- python tools/kmeans_iter_workload.py > $out/kmprof.log 2>&1; tail -5 $out/kmprof.log ;;
     kmprofb) timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kmprofb -o km -- python tools/kmeans_iter_workload.py 10000000 blobs > $out/kmprofb.log 2>&1; tail -5 $out/kmprofb.log ;;
     sweep) make -C lotus_amd/csrc tuning -j8 > $out/tuning_build.log 2>&1; timeout -k 10 600 python tools/small_batch_sweep.py > $out/small_batch_sweep.log 2>&1; cat $out/small_batch_sweep.log ;;
