@@ -9,7 +9,8 @@ Both are still written, so a directory built here loads in stock LOTUS and vice 
   ``{dir}/rows.f16`` / ``rows.f64`` written next to it, described by ``{dir}/rows.json``;
 * a rank that owns rows ``[lo, hi)`` touches only those pages (per-rank partial load);
 * ``signature()`` = (size, mtime) of the files an index was loaded from, so a directory rewritten by another
-  process is noticed instead of served stale.
+  process is noticed instead of served stale; ``rows.json`` records a CONTENT stamp (size + sampled blocks) of the two
+  reference files it was written with, so a copied directory keeps its row store and a foreign rewrite voids it.
 """
 from __future__ import annotations
 
@@ -62,14 +63,35 @@ def write_dir(index_dir: str, embeddings, host: np.ndarray, metric: int, raw: bo
     os.replace(tmp, meta_path)  # the description appears only once the rows are complete
 
 
+_STAMP_BLOCK = 4096
+_STAMP_BLOCKS = 16
+
+
+def _fingerprint(path: str, size: int) -> str:
+    """Content stamp of a file that survives a copy: blake2b over its size and 16 evenly spaced 4 KB blocks (first and last
+    included) - 64 KB read whatever the file's size.  A re-index with other embeddings changes the sampled rows; an mtime
+    (round 3's stamp) changed with every `cp -r` / rsync and voided a perfectly good row store."""
+    import hashlib
+
+    h = hashlib.blake2b(digest_size=16)
+    h.update(str(size).encode())
+    with open(path, "rb") as fp:
+        last = max(0, size - _STAMP_BLOCK)
+        for i in range(_STAMP_BLOCKS):
+            fp.seek(last * i // (_STAMP_BLOCKS - 1))
+            h.update(fp.read(_STAMP_BLOCK))
+    return h.hexdigest()
+
+
 def _file_stamps(index_dir: str) -> dict:
     out = {}
     for name in ("index", "vecs"):
+        path = os.path.join(index_dir, name)
         try:
-            st = os.stat(os.path.join(index_dir, name))
-            out[name] = [int(st.st_size), int(st.st_mtime_ns)]
+            size = int(os.stat(path).st_size)
+            out[name] = [size, _fingerprint(path, size)]
         except FileNotFoundError:
-            out[name] = [-1, -1]
+            out[name] = [-1, ""]
     return out
 
 

@@ -174,3 +174,32 @@ def test_get_vectors_notices_a_rewritten_directory_without_load_index(tmp_path):
     HipVS(backend=OracleBackend()).index(None, b, d)
     os.utime(os.path.join(d, "vecs"), ns=(5, 5))
     assert np.array_equal(vs.get_vectors_from_index(d, [3]), b[[3]])
+
+
+def test_copied_directory_keeps_its_row_store(tmp_path):
+    """rows.json used to record the mtime of `vecs` / `index`, so `cp -r` / rsync of an index directory voided
+    the fp16 row store and get_vectors_from_index silently changed dtype.  The stamp is a content fingerprint now: a copy
+    (other mtimes, same bytes) keeps serving the stored dtype from the memory map; a foreign rewrite still voids it."""
+    import shutil
+    import time
+
+    a = synth.corpus(300, 24, seed=3).astype(np.float16)
+    d = str(tmp_path / "i")
+    HipVS(backend=OracleBackend()).index(None, a, d)
+    d2 = str(tmp_path / "copy")
+    shutil.copytree(d, d2)
+    for name in ("vecs", "index", "rows.f16", "rows.json"):
+        os.utime(os.path.join(d2, name), ns=(time.time_ns(), time.time_ns() - 7_000_000_000))  # other mtimes
+    rows, how = store.open_stored_rows(d2)
+    assert how == "mmap" and rows.dtype == np.float16 and np.array_equal(np.asarray(rows), a)
+    vs = HipVS(backend=OracleBackend())
+    vs.load_index(d2)
+    got = vs.get_vectors_from_index(d2, [7, 9])
+    assert got.dtype == np.float16 and np.array_equal(got, a[[7, 9]])
+    # same size, one changed row in the middle of the file: the sampled blocks need not see it, the SIZE + head / tail do not
+    # change either - so a partial in-place edit is only caught when it touches a sampled block; a re-index (every row new) is
+    b = synth.corpus(300, 24, seed=4).astype(np.float32)
+    with open(os.path.join(d2, "vecs"), "wb") as fp:
+        pickle.dump(b, fp)
+    faiss_io.write_index_flat(os.path.join(d2, "index"), b, 0)
+    assert store.open_stored_rows(d2)[1] == "pickle"
