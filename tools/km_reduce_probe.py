@@ -6,13 +6,10 @@ sys.path.insert(0, ROOT)
 import numpy as np
 import torch
 from lotus_amd import _capi
-if "dpl" in sys.argv[1:]:  # sweep the column-slice width (dimensions per lane) on the tuning build
-    _capi.load(os.path.join(ROOT, "lotus_amd", "liblotus_hip_tuning.so"))
 from lotus_amd.backend import HipBackend
 
 be = HipBackend("cuda:0")
-_nums = [a for a in sys.argv[1:] if a.isdigit()]
-n = int(_nums[0]) if _nums else 10_000_000
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000
 K, d = 1024, 768
 g = torch.Generator(device=be.device); g.manual_seed(3)
 x = torch.randn((n, d), generator=g, device=be.device).to(torch.float16)
@@ -29,16 +26,6 @@ def sizes_to_assign(sz, shuffle=True):
 
 
 def timed(name, assign):
-    if "dpl" in sys.argv[1:]:
-        for dpl in (8, 4, 2):
-            os.environ["LVS_KM_DPL"] = str(dpl)
-            _timed(f"{name} [{dpl} dims per lane]", assign)
-        os.environ.pop("LVS_KM_DPL")
-    else:
-        _timed(name, assign)
-
-
-def _timed(name, assign):
     t = torch.from_numpy(assign.astype(np.int64)).to(be.device)
     for _ in range(2):
         be.kmeans_accumulate(pk, t, K)
