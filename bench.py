@@ -60,7 +60,7 @@ def sig(x, digits=5):
     return x
 
 
-DETAIL_KEYS = ("note", "objective", "searched_row_fraction_per_iteration", "comparators_timed", "algorithmic_flops",
+DETAIL_KEYS = ("note", "objective", "iteration_ms", "searched_row_fraction_per_iteration", "comparators_timed", "algorithmic_flops",
                "algorithmic_flops_per_iteration", "mfma_frac_secondary")
 
 
@@ -747,13 +747,20 @@ def kmeans_legs(ctx, legs, checks, fut):
     kw = dict(backend=be, packed=pk, max_points_per_centroid=None, final_assign=False)
     ts = {}
     stats = {}
-    for niter in (2, 10, 2, 10, 2, 10):  # the fastest of three runs each: an iteration is ~40 launches and one host round trip,
-        be.synchronize()                 # so a busy host shows up in it
-        t0 = time.perf_counter()
-        rf = kmeans(None, K, niter=niter, stats=stats, bounds=False, **kw)
+    # every iteration timed on its own (events on the launch stream, incl. the one host round trip an iteration has); three
+    # runs of 10 iterations, per iteration the fastest of the three, `ms_per_iteration` = their mean.  (Round 3 took the slope
+    # between a 2- and a 6-iteration run: a 2-iteration run's set-up varies by tens of ms between runs, and so did the slope.)
+    its = None
+    for _ in range(3):
+        st_run = {"time_iterations": True}
         be.synchronize()
-        ts[niter] = min(ts.get(niter, 1e9), time.perf_counter() - t0)
-    per_iter = (ts[10] - ts[2]) / 8
+        t0 = time.perf_counter()
+        rf = kmeans(None, K, niter=10, stats=st_run, bounds=False, **kw)
+        be.synchronize()
+        ts[10] = min(ts.get(10, 1e9), time.perf_counter() - t0)
+        its = st_run["iteration_ms"] if its is None else [min(a, b) for a, b in zip(its, st_run["iteration_ms"])]
+        stats = st_run
+    per_iter = sum(its) / len(its) * 1e-3
     fl = 2.0 * n * K * d
     legs["kmeans_full_iter_10M_x_1024"] = {
         "rows": n, "k": K, "ms_per_iteration": per_iter * 1e3, "bound": "mfma", "algorithmic_flops_per_iteration": fl,
@@ -761,11 +768,11 @@ def kmeans_legs(ctx, legs, checks, fut):
         "uncertified_fraction": stats.get("uncertified", 0) / max(1, stats.get("queries", 0)),
         "objective_decreasing": bool(np.all(np.diff(rf.obj) <= 1e-6 * np.abs(rf.obj[:-1]))),
         "pair_fraction": stats.get("pairs", 0) / max(1, stats.get("queries", 0)),
-        "seconds_2_iterations": ts[2], "seconds_10_iterations": ts[10], "ms_per_iteration_of_the_10_run": ts[10] / 10 * 1e3,
+        "iteration_ms": [round(v, 2) for v in its], "seconds_10_iterations_incl_setup": ts[10],
         "objective": [float(v) for v in rf.obj],
         "note": "EXHAUSTIVE: all rows searched every iteration (bounds off): certified one-pass assignment (fp16 points x "
                 "fp32-accurate centroids, lvs_nearest3) + two exact dot products for the rows only two centroids can win + exact "
-                "re-search of the rest + in-row-order centroid sums + update; slope between 2 and 10 iterations"}
+                "re-search of the rest + in-row-order centroid sums + update; mean of ten iterations, each timed by device events"}
     # (i') the same 20 iterations with exact distance bounds (Hamerly): rows whose nearest centroid provably did not change
     # are not searched again - identical objectives (checked against the exhaustive run above), far less work once the
     # centroids settle.  NOT comparable with a roofline (work is skipped): reported as wall time and searched rows

@@ -159,7 +159,14 @@ def kmeans(x, k: int, niter: int = 20, seed: int = 1234, max_points_per_centroid
             b_ub = torch.zeros((train.n,), dtype=torch.float32, device=dev)
             b_lb = torch.zeros((train.n,), dtype=torch.float32, device=dev)
             keys = None
+        # stats["time_iterations"] = True: device time of every iteration from events on the launch stream -> stats["iteration_ms"]
+        timed = stats is not None and bool(stats.get("time_iterations")) and dev.type == "cuda"
+        marks = []
         for it in range(niter):
+            if timed:
+                ev = torch.cuda.Event(enable_timing=True)
+                ev.record(torch.cuda.current_stream(dev))
+                marks.append(ev)
             if not use_bounds:
                 keys = be.nearest(cpk, train, _capi.METRIC_L2, exact_scores=False, corpus_stats=cstats, stats=stats)  # ids only ...
             else:
@@ -192,6 +199,12 @@ def kmeans(x, k: int, niter: int = 20, seed: int = 1234, max_points_per_centroid
             cpk, cstats = be.kmeans_finish(sums, counts, centroids, nt, cmode, nsplit_dev[it:it + 1], exp=pexp)
             if use_bounds:
                 shift, top2 = be.kmeans_centroid_shift(c_old, centroids)
+        if timed and marks:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record(torch.cuda.current_stream(dev))
+            ev.synchronize()
+            marks.append(ev)
+            stats["iteration_ms"] = [float(a.elapsed_time(b)) for a, b in zip(marks[:-1], marks[1:])]
         obj[:] = (obj_dev[:niter].cpu().numpy() * 2.0 ** (-2 * pexp)).astype(np.float32)
         nsplit[:] = nsplit_dev[:niter].cpu().numpy()
     assign = np.zeros(0, np.int64)
