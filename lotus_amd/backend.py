@@ -48,6 +48,9 @@ class HipBackend:
         import threading
 
         self._h2d_lock = threading.Lock()
+        # one device workspace and one set of side streams per backend: stores that share a backend take this lock around
+        # every plugin call (HipVS), so two threads never interleave the launches of two operations
+        self._call_lock = threading.RLock()
 
     # ---- plumbing ----
     def _stream(self) -> int:
@@ -109,7 +112,8 @@ class HipBackend:
         nbytes = int(c.nbytes)
         ring = None
         if nbytes >= (4 << 20) and c.ndim == 2 and int(c.shape[1]) * c.itemsize <= self.H2D_SLICE_BYTES:
-            ring = self._h2d_ring()
+            with self._h2d_lock:
+                ring = self._h2d_ring()
         if ring is None:
             import warnings
 

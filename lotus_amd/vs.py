@@ -55,7 +55,11 @@ def _serialised(fn):
     @functools.wraps(fn)
     def run(self, *a, **k):
         with self._lock:
-            return fn(self, *a, **k)
+            shared = getattr(self._backend, "_call_lock", None)  # stores sharing one backend share its workspace too
+            if shared is None:
+                return fn(self, *a, **k)
+            with shared:
+                return fn(self, *a, **k)
 
     return run
 
