@@ -64,10 +64,22 @@ DETAIL_KEYS = ("note", "objective", "iteration_ms", "searched_row_fraction_per_i
                "algorithmic_flops_per_iteration", "mfma_frac_secondary")
 
 
-def compact(x):
-    """The stdout form of a leg: verbose keys dropped (they go to stderr)."""
+LEG_DETAIL_KEYS = ("rows", "k", "niter", "train_rows", "threshold", "kernel_launches", "expected_in_band", "unplanted_pairs",
+                   "shards", "shard_rows", "ids_from_every_shard", "short_lists_slots", "objective_first_last", "blob_purity",
+                   "oracle_iterations", "bound", "seconds_10_iterations_incl_setup", "oracle_seconds",
+                   "mfma_floor_node_qps", "best_node_qps", "fp16_same_shape_ms")
+
+
+def compact(x, in_legs=False):
+    """The stdout form of the line: verbose keys dropped (they go to stderr); inside `legs` also the keys that restate a leg's
+    configuration (its name says it) and a call's wall time where the kernel time is given."""
     if isinstance(x, dict):
-        return {k: compact(v) for k, v in x.items() if k not in DETAIL_KEYS}
+        out = {}
+        for k, v in x.items():
+            if k in DETAIL_KEYS or (in_legs and (k in LEG_DETAIL_KEYS or (k == "ms_per_call" and "kernel_ms" in x))):
+                continue
+            out[k] = compact(v, in_legs or k == "legs")
+        return out
     return x
 
 
