@@ -254,10 +254,13 @@ int32_t lvs_margin_select_stats(const uint64_t* keys, const float* second, const
                                 const float* corpus_stats, const float* coef5, int64_t* out_idx, uint64_t* out_count,
                                 void* stream);
 int64_t lvs_kmeans_accumulate_workspace_bytes(int64_t n, int32_t k);
-/* sums [k][d] float32 += packed rows of x grouped by assign[i] (int64, values outside [0,k) are skipped);
- * counts [k] float32 += group sizes.  Both must be initialised by the caller.  Rows of one centroid are added
- * in row order (faiss compute_centroids order), so the result is deterministic.  (Rows are bucketed by a stable counting
- * sort on the centroid ids: per-chunk histograms, a scan, an in-order scatter.) */
+/* sums [k][d] float32: the packed rows of x, grouped by assign[i] (int64, values outside [0,k) are skipped), are added to
+ * what is there, one after the other in row order per centroid (faiss compute_centroids order) - the chain of float32
+ * additions CONTINUES from the caller's values, so handing the rows over in consecutive ranges (one call each, sums carried
+ * along, zeros before the first) gives bit for bit the sums of one call over all rows: a caller may run the sums of one range
+ * on a side stream under the assignment search of the next (lotus_amd/cluster.py).  counts [k] float32 += group sizes.  Both
+ * must be initialised by the caller.  (Rows are bucketed by a stable counting sort on the centroid ids: per-chunk histograms,
+ * a scan, an in-order scatter; one wave per (centroid, 128 columns) walks its bucket.) */
 int32_t lvs_kmeans_accumulate(const void* x, int64_t n, int32_t d, int32_t pack_mode, const int64_t* assign,
                               int32_t k, float* sums, float* counts, void* workspace, int64_t workspace_bytes,
                               void* stream);

@@ -815,6 +815,18 @@ class HipBackend:
                 _ptr(counts), _ptr(ws), int(ws.numel()), self._stream())
         return sums, counts
 
+    def kmeans_accumulate_keys_into(self, x: PackedRows, keys, k: int, sums, counts, id_offset: int = 0, workspace=None) -> None:
+        """Add the rows of ``x`` to ``sums`` / ``counts`` CONTINUING the in-row-order sums that are there (zeros before the first
+        rows): handing the rows over in consecutive ranges gives bit for bit what one call over all rows gives.  ``workspace``: a
+        uint8 device tensor of ``lvs_kmeans_accumulate_workspace_bytes`` for a call that runs on a side stream next to launches
+        using the backend's own workspace."""
+        need = int(self.lib.lvs_kmeans_accumulate_workspace_bytes(x.n, k))
+        ws = workspace if workspace is not None else self._workspace(need)
+        if int(ws.numel()) < need:
+            raise ValueError("workspace too small")
+        self._c("lvs_kmeans_accumulate_keys", _ptr(x.rows), x.n, x.d, x.mode, _ptr(keys), int(id_offset), k, _ptr(sums),
+                _ptr(counts), _ptr(ws), int(ws.numel()), self._stream())
+
     def kmeans_objective(self, centroids, sums, counts, x2, out) -> None:
         """out[0] (device float64) = x2[0] - 2 sum_j <c_j, S_j> + sum_j n_j |c_j|^2: faiss's objective of the iteration
         (sum of the assignment distances) from the sums, with the centroids BEFORE the update; float64 on the device."""

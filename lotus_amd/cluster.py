@@ -34,7 +34,7 @@ def kmeans(x, k: int, niter: int = 20, seed: int = 1234, max_points_per_centroid
            pack_mode: int | None = None, packed=None, shard: bool = False, process_group=None,
            final_assign: bool = True, centroid_precision: str = "fp32", n_total: int | None = None,
            local_pos=None, stats: dict | None = None, bounds: bool | None = None,
-           trace: list | None = None) -> KMeansResult:
+           trace: list | None = None, parts: int | None = None) -> KMeansResult:
     """faiss-parity k-means (``faiss.Kmeans(d, k, niter).train(x)`` + ``index.search(x, 1)``, ``lotus/utils.py:61-65``).
 
     ``x``: host matrix [n,d] (float16/32/64) and/or ``packed``: its device image.  Everything after the packing runs
@@ -59,6 +59,12 @@ def kmeans(x, k: int, niter: int = 20, seed: int = 1234, max_points_per_centroid
         assigns the rows it holds.
       Either way one all-reduce of the ``[k,d]`` sums, ``[k]`` counts and the objective per iteration, and one
       all-gather of the final cluster ids; nothing else crosses the ranks.
+
+    ``parts`` (default: 4 from 2^21 training rows on, exhaustive iterations only): the training rows go through an iteration in
+    that many consecutive ranges, and the in-row-order sums of one range run on a side stream UNDER the assignment search of the
+    next (the sums kernel needs 82 VGPRs: one of its waves fits on a SIMD beside the two waves of the assignment kernel).  The
+    sums continue across the ranges in row order, so results are bit-identical to ``parts=1``; at 10 M x 1 024 x 768 an iteration
+    drops from 21.0 to 19.2 ms (tools/overlap_probe.py).
 
     ``trace`` (a list, optional; parity tooling): one dict per iteration with device copies of the centroids the iteration
     assigned against (``centroids``, float32 [k,d], the rows' scaled domain) and of the assignment's result keys (``keys``).
@@ -162,12 +168,38 @@ def kmeans(x, k: int, niter: int = 20, seed: int = 1234, max_points_per_centroid
         # stats["time_iterations"] = True: device time of every iteration from events on the launch stream -> stats["iteration_ms"]
         timed = stats is not None and bool(stats.get("time_iterations")) and dev.type == "cuda"
         marks = []
+        nparts = int(parts) if parts is not None else (4 if train.n >= (1 << 21) else 1)
+        nparts = max(1, min(nparts, train.n // 65536)) if (not use_bounds and hasattr(be, "kmeans_accumulate_keys_into")
+                                                           and dev.type == "cuda") else 1
+        if nparts > 1:
+            side = torch.cuda.Stream(device=dev)
+            side_ws = torch.empty(int(be.lib.lvs_kmeans_accumulate_workspace_bytes(train.n, k)) + 256, dtype=torch.uint8, device=dev)
+            cuts = [(train.n * i // nparts) // 4096 * 4096 for i in range(nparts)] + [train.n]
         for it in range(niter):
             if timed:
                 ev = torch.cuda.Event(enable_timing=True)
                 ev.record(torch.cuda.current_stream(dev))
                 marks.append(ev)
-            if not use_bounds:
+            if nparts > 1:
+                # ranges of rows: search range i, then its sums on the side stream while range i + 1 is searched
+                main = torch.cuda.current_stream(dev)
+                sums = torch.zeros((k, d), dtype=torch.float32, device=dev)
+                counts = torch.zeros((k,), dtype=torch.float32, device=dev)
+                held, last = [], None
+                for i in range(nparts):
+                    sub = be.slice_rows(train, cuts[i], cuts[i + 1])
+                    kp = be.nearest(cpk, sub, _capi.METRIC_L2, exact_scores=False, corpus_stats=cstats, stats=stats)
+                    searched_ev = main.record_event()
+                    with torch.cuda.stream(side):
+                        side.wait_event(searched_ev)
+                        be.kmeans_accumulate_keys_into(sub, kp, k, sums, counts, workspace=side_ws)
+                        last = side.record_event()
+                    held.append(kp)  # alive until the side stream is done with it (the wait below)
+                main.wait_event(last)
+                if trace is not None:
+                    trace.append({"centroids": centroids.clone(), "keys": torch.cat(held)})
+                del held
+            elif not use_bounds:
                 keys = be.nearest(cpk, train, _capi.METRIC_L2, exact_scores=False, corpus_stats=cstats, stats=stats)  # ids only ...
             else:
                 act = None
@@ -187,9 +219,10 @@ def kmeans(x, k: int, niter: int = 20, seed: int = 1234, max_points_per_centroid
                 if stats is not None:
                     stats.setdefault("searched_rows", []).append(searched)
                 c_old = centroids.clone()
-            if trace is not None:
-                trace.append({"centroids": centroids.clone(), "keys": keys.clone()})
-            sums, counts = be.kmeans_accumulate_keys(train, keys, k)
+            if nparts == 1:
+                if trace is not None:
+                    trace.append({"centroids": centroids.clone(), "keys": keys.clone()})
+                sums, counts = be.kmeans_accumulate_keys(train, keys, k)
             # ... because the objective (faiss: sum of the assignment distances) follows from the sums the update needs
             # anyway:  sum_i |x_i - c_a(i)|^2 = sum_i |x_i|^2 - 2 sum_j c_j . S_j + sum_j n_j |c_j|^2   (float64, [k,d])
             be.kmeans_objective(centroids, sums, counts, x2, obj_dev[it:it + 1])

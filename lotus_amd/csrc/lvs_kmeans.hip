@@ -183,30 +183,49 @@ __global__ __launch_bounds__(256) void km_scatter_kernel(const KeyT* __restrict_
     }
 }
 
-typedef _Float16 km_half8 __attribute__((ext_vector_type(8)));
+// grid = (k, ceil(dpad / (64 * DPL))), one wave per workgroup: a lane owns DPL consecutive dimensions (8, 4 or 2: 16-, 8- or
+// 4-byte loads) of centroid blockIdx.x and walks the bucket in row order, U rows in flight at a time.  Per dimension the
+// additions happen in exactly the bucket (= ascending row) order, so the sums do not depend on DPL, U or the launch shape -
+// faiss's accumulation order (compute_centroids), bit for bit.
+// A bucket is one dependent chain of additions per wave, and what a row costs a wave is mostly fixed (row number, 64-bit address,
+// load issue) - so the LONGEST bucket sets the kernel's time when the sizes are skewed (configs[4]'s blob rows: up to 3-4 x the
+// mean).  Narrower column slices put more waves on every bucket without touching the order of any column's sum.
+template <int DPL>
+struct KmVec;
+template <>
+struct KmVec<8> {
+    typedef _Float16 type __attribute__((ext_vector_type(8)));
+};
+template <>
+struct KmVec<4> {
+    typedef _Float16 type __attribute__((ext_vector_type(4)));
+};
+template <>
+struct KmVec<2> {
+    typedef _Float16 type __attribute__((ext_vector_type(2)));
+};
 
-// grid = (k, ceil(dpad / 512)), one wave per workgroup: lane owns 8 consecutive dimensions of centroid blockIdx.x
-// and walks the bucket in row order, U rows (16-byte loads) in flight at a time.  Per dimension the additions
-// happen in exactly the bucket (= ascending row) order, so the sums do not depend on U or on the launch shape.
-template <int SPLIT>
+template <int SPLIT, int DPL>
 __global__ __launch_bounds__(64) void km_reduce_kernel(const _Float16* __restrict__ x, long long ld, int d, int dpad,
                                                        const uint32_t* __restrict__ rows,
                                                        const uint32_t* __restrict__ offsets,
                                                        float* __restrict__ sums, float* __restrict__ cnt_out) {
+    typedef typename KmVec<DPL>::type vec_t;
     const int c = blockIdx.x, lane = threadIdx.x;
-    const int j0 = (blockIdx.y * 64 + lane) * 8;
+    const int j0 = (blockIdx.y * 64 + lane) * DPL;
     const uint32_t b = offsets[c], e = offsets[c + 1];
     if (blockIdx.y == 0 && lane == 0) cnt_out[c] += (float)(e - b);
     if (j0 >= dpad) return;
-    constexpr int U = SPLIT ? 16 : 32;
-    float acc[8];
+    // rows in flight: 128 data VGPRs' worth (hi parts; half as many rows when the lo parts ride along), at most 64
+    constexpr int U = (DPL == 8 ? 32 : 64) / (SPLIT ? 2 : 1);
+    // the sums CONTINUE from what is there (zeros before the first rows): a caller may hand the rows over in consecutive ranges
+    // - (s + x1) + x2 ... is the same chain of float32 additions whether it is cut into launches or not
+    float acc[DPL];
 #pragma unroll
-    for (int t = 0; t < 8; ++t) acc[t] = 0.f;
+    for (int t = 0; t < DPL; ++t) acc[t] = j0 + t < d ? sums[(long long)c * d + j0 + t] : 0.f;
     const _Float16* xc = x + j0;
-    // A bucket is one dependent chain of additions, and a batch of U rows costs what it cannot overlap: a memory latency.
-    // So: many rows per batch (U x 16 B in flight per lane), and the row NUMBERS of the next batch are fetched while this
-    // batch is added (they are wave-uniform: scalar loads), so that a batch waits for one latency, not two.  On configs[4]'s
-    // blob rows, where bucket sizes differ by 4 x in the first iterations, the longest bucket sets the kernel's time.
+    // many rows per batch, and the row NUMBERS of the next batch are fetched while this batch is added (they are wave-uniform:
+    // scalar loads), so that a batch waits for one latency, not two
     const uint32_t nfull = (e - b) / U;
     uint32_t p = b;
     if (nfull) {
@@ -214,12 +233,12 @@ __global__ __launch_bounds__(64) void km_reduce_kernel(const _Float16* __restric
 #pragma unroll
         for (int i = 0; i < U; ++i) idx[i] = rows[p + i];
         for (uint32_t kb = 0; kb < nfull; ++kb) {
-            km_half8 hi[U], lo[U];
+            vec_t hi[U], lo[U];
 #pragma unroll
             for (int i = 0; i < U; ++i) {
                 const _Float16* row = xc + (long long)idx[i] * ld;
-                hi[i] = *(const km_half8*)row;
-                if (SPLIT) lo[i] = *(const km_half8*)(row + dpad);
+                hi[i] = *(const vec_t*)row;
+                if (SPLIT) lo[i] = *(const vec_t*)(row + dpad);
             }
             if (kb + 1 < nfull) {
 #pragma unroll
@@ -228,20 +247,20 @@ __global__ __launch_bounds__(64) void km_reduce_kernel(const _Float16* __restric
 #pragma unroll
             for (int i = 0; i < U; ++i)
 #pragma unroll
-                for (int t = 0; t < 8; ++t) acc[t] += SPLIT ? (float)hi[i][t] + (float)lo[i][t] : (float)hi[i][t];
+                for (int t = 0; t < DPL; ++t) acc[t] += SPLIT ? (float)hi[i][t] + (float)lo[i][t] : (float)hi[i][t];
             p += U;
         }
     }
     for (; p < e; ++p) {
         const _Float16* row = xc + (long long)rows[p] * ld;
-        km_half8 h = *(const km_half8*)row, l;
-        if (SPLIT) l = *(const km_half8*)(row + dpad);
+        vec_t h = *(const vec_t*)row, l;
+        if (SPLIT) l = *(const vec_t*)(row + dpad);
 #pragma unroll
-        for (int t = 0; t < 8; ++t) acc[t] += SPLIT ? (float)h[t] + (float)l[t] : (float)h[t];
+        for (int t = 0; t < DPL; ++t) acc[t] += SPLIT ? (float)h[t] + (float)l[t] : (float)h[t];
     }
 #pragma unroll
-    for (int t = 0; t < 8; ++t)
-        if (j0 + t < d) sums[(long long)c * d + j0 + t] += acc[t];
+    for (int t = 0; t < DPL; ++t)
+        if (j0 + t < d) sums[(long long)c * d + j0 + t] = acc[t];
 }
 
 // centroid update of faiss compute_centroids: c = sum * (1 / count) where the cluster is not empty, unchanged otherwise
@@ -896,13 +915,29 @@ int32_t km_accumulate(const void* x, int64_t n, int32_t d, int32_t pack_mode, co
     if (rc != LVS_OK) return rc;
     const int dpad = (int)lvs_round_up(d, LVS_BK);
     const long long ld = pack_mode == LVS_PACK_SPLIT ? 2 * dpad : dpad;
-    const dim3 grid((unsigned)k, (unsigned)lvs_ceil_div(dpad, 512));
-    if (pack_mode == LVS_PACK_SPLIT)
-        hipLaunchKernelGGL(km_reduce_kernel<1>, grid, dim3(64), 0, st, (const _Float16*)x, ld, d, dpad, rows, offs, sums,
-                           counts);
-    else
-        hipLaunchKernelGGL(km_reduce_kernel<0>, grid, dim3(64), 0, st, (const _Float16*)x, ld, d, dpad, rows, offs, sums,
-                           counts);
+    // column slices per bucket: two dimensions per lane (128 columns per wave; d = 768: six waves per bucket).  Measured neutral
+    // against eight dimensions per lane on its own (profiles/r05s_km_reduce_dpl_sweep.log), but at 82 instead of 148 VGPRs a
+    // wave of this kernel fits on a SIMD NEXT TO the two waves of the assignment kernel (2 x 199 + 82 <= 512), which is what lets
+    // the sums of one half of the rows run under the assignment of the other half (lotus_amd/cluster.py)
+    int dpl = 2;
+    if (lvs_tune_set("LVS_KM_DPL")) {
+        const int v = (int)lvs_tune("LVS_KM_DPL", 0);
+        if (v == 2 || v == 4 || v == 8) dpl = v;
+    }
+    const dim3 grid((unsigned)k, (unsigned)lvs_ceil_div(dpad, 64 * dpl));
+#define LVS_KM_REDUCE(SP, DP)                                                                                              \
+    hipLaunchKernelGGL((km_reduce_kernel<SP, DP>), grid, dim3(64), 0, st, (const _Float16*)x, ld, d, dpad, rows, offs, sums, \
+                       counts)
+    if (pack_mode == LVS_PACK_SPLIT) {
+        if (dpl == 2) LVS_KM_REDUCE(1, 2);
+        else if (dpl == 4) LVS_KM_REDUCE(1, 4);
+        else LVS_KM_REDUCE(1, 8);
+    } else {
+        if (dpl == 2) LVS_KM_REDUCE(0, 2);
+        else if (dpl == 4) LVS_KM_REDUCE(0, 4);
+        else LVS_KM_REDUCE(0, 8);
+    }
+#undef LVS_KM_REDUCE
     LVS_HIP_CHECK(hipGetLastError());
     return LVS_OK;
 }

@@ -577,3 +577,38 @@ def test_two_candidate_certificate_settles_split_twins_with_two_dot_products(hip
     assert (Ig[:, 0] != truth.argmax(1)).sum() <= (Iw[:, 0] != truth.argmax(1)).sum() + 0.002 * nq
     assert (Ig != Iw).mean() <= 0.05
     assert stats["pairs"] >= 0.3 * nq and stats["uncertified"] - stats["pairs"] <= 0.01 * nq, stats
+
+
+@pytest.mark.parametrize("mode", [F16, SPLIT])
+def test_ranges_with_overlapped_sums_equal_the_single_pass(hip_backend, mode):
+    """From 2^21 training rows on an iteration hands the rows over in four consecutive ranges and runs the in-row-order sums
+    of one range on a side stream under the assignment search of the next (lotus_amd/cluster.py `parts`): the sums continue
+    across the ranges (lvs_kmeans_accumulate_keys carries them along), so objectives, centroids, split counts, the traced
+    assignments and the final assignment are bit-identical to the single pass - also with an uneven last range."""
+    import benchdata
+    from lotus_amd.cluster import kmeans
+
+    K, n, d = 64, 300_001, 96
+    x16, _ = benchdata.blobs(benchdata.CFG_KMEANS, n, d, K)
+    x = x16 if mode == F16 else (x16.astype(np.float32) * np.float32(1.0 + 2.0 ** -13))
+    kw = dict(niter=6, backend=hip_backend, max_points_per_centroid=None, bounds=False)
+    t1, t4 = [], []
+    one = kmeans(x, K, parts=1, trace=t1, **kw)
+    four = kmeans(x, K, parts=4, trace=t4, **kw)
+    assert np.array_equal(one.obj, four.obj) and np.array_equal(one.centroids, four.centroids)
+    assert np.array_equal(one.nsplit, four.nsplit) and np.array_equal(one.assign, four.assign)
+    for a, b in zip(t1, t4):
+        assert bool((a["keys"].reshape(-1) == b["keys"].reshape(-1)).all()) and bool((a["centroids"] == b["centroids"]).all())
+    # the C ABI's contract on its own: two calls over consecutive ranges == one call, bit for bit
+    import torch
+
+    be = hip_backend
+    p = be.pack(x, mode)
+    keys = be.search_keys(be.pack(one.centroids, SPLIT), p, 1, L2)
+    s1, c1 = be.kmeans_accumulate_keys(p, keys, K)
+    s2 = torch.zeros_like(s1)
+    c2 = torch.zeros_like(c1)
+    h = 123_456
+    be.kmeans_accumulate_keys_into(be.slice_rows(p, 0, h), keys[:h].contiguous(), K, s2, c2)
+    be.kmeans_accumulate_keys_into(be.slice_rows(p, h, n), keys[h:].contiguous(), K, s2, c2)
+    assert bool(torch.equal(s1, s2)) and bool(torch.equal(c1, c2))
