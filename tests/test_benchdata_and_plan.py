@@ -74,3 +74,36 @@ def test_bench_cpu_baseline_reports_a_parity_sample_of_the_timed_run():
     wrong[7, 0] = (wrong[7, 0] + 12345) % len(xb)  # a planted neighbour replaced by an unrelated row: must be counted
     bad = bench.cpu_baseline(np, xb, xq, 300, 10, Dg, wrong)["gpu_parity_on_the_timed_sample"]
     assert bad["id_mismatches_outside_near_ties"] >= 1 and bad["recall_at_k"] < 1.0
+
+
+def test_bench_line_keeps_the_contract_keys_and_fits_the_record():
+    """bench.py prints a compacted line (5 significant digits, leg configuration keys and notes to stderr): the contract's keys
+    must survive the compaction, the legs' figures too, and the line must stay below 6 KB so that the driver's 8 KB tail of
+    stdout holds all of it.  Replayed on the verbose form of a real run (profiles/r05x_bench_details.txt)."""
+    import json
+    import os
+    import re
+
+    import bench
+
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r05x_bench_details.txt")
+    full = json.loads(re.search(r"BENCH_DETAILS (\{.*\})", open(path).read()).group(1))["line"]
+    line = json.dumps(bench.sig(bench.compact(full)))
+    assert len(line) < 6000, len(line)
+    out = json.loads(line)
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline", "cpu_baseline", "legs", "legs_summary"):
+        assert key in out, key
+    assert "workload" in out["config"]
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert key in out["roofline"], key
+    for key in ("value", "unit", "cores", "kind", "sample"):
+        assert key in out["cpu_baseline"], key
+    assert isinstance(out["cpu_baseline"]["cores"], int)
+    assert list(out)[-1] == "legs_summary"  # printed last: a truncated record still ends with the figures that matter
+    legs = out["legs"]
+    assert {"cfg2_10k_x_1M", "q1", "q128", "q1024", "node_plan_8gpu", "world8_rehearsal", "t_call_host_to_host",
+            "range_selfjoin_cfg4", "kmeans_parity_mode", "kmeans_full_iter_10M_x_1024", "fp32_join_100k_x_1M"} <= set(legs)
+    assert "frac" in legs["q128"] and "kernel_ms" in legs["q128"] and "note" not in legs["world8_rehearsal"]
+    assert legs["kmeans_parity_mode"]["all_flips_are_near_ties"] in (True, False) and "seconds" in legs["kmeans_parity_mode"]
+    assert bench.sig(0.123456789) == 0.12346 and bench.sig({"a": [1.0000001, 2]}) == {"a": [1.0, 2]}
