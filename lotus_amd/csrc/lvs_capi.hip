@@ -1385,7 +1385,16 @@ extern "C" int32_t lvs_flat_search_keys_seeded(const void* xb, int32_t xb_pack, 
 
 extern "C" int32_t lvs_flat_search_seed_tiles(int64_t nq, int64_t nb, int32_t k) {
     if (nq < 0 || nb < 0 || k < 1) return LVS_EINVAL;
-    return tile_seed_tiles(nq, nb, k);
+    int tiles = tile_seed_tiles(nq, nb, k);
+    // A shard of a sharded join pools its sample with the other shards', so a larger sample per shard pays: 100 k x 8 x 125 k
+    // rows, same box, sample pass + search per shard (profiles/r05y_seed_pool_sweep.log): 10 tiles 0.42 + 19.94 ms, 20 tiles
+    // 0.76 + 19.06, 40 tiles 1.51 + 18.22, 61 tiles 2.29 + 17.71 - a twenty-fourth of the shard, at most 24 tiles.
+    if (tiles > 0 && lvs_ceil_div(nq, LVS2_BQ) > 64) {
+        int64_t t = nb / LVS_BC / 24;
+        t = t > 24 ? 24 : t;
+        if (t > tiles) tiles = (int)t;
+    }
+    return tiles;
 }
 
 extern "C" int32_t lvs_flat_search_seed_scores(const void* xb, int32_t xb_pack, int64_t nb, const void* xq, int32_t xq_pack,

@@ -29,6 +29,7 @@ for w in $what; do
     fp32k1) timeout -k 10 300 python tools/fp32_trace_workload.py > $out/fp32k1.log 2>&1; grep "per call" $out/fp32k1.log ;;
     kmdpl) make -C lotus_amd/csrc tuning -j8 > $out/tuning_build.log 2>&1; timeout -k 10 600 python tools/km_reduce_probe.py dpl > $out/kmdpl.log 2>&1; grep "ms per call" $out/kmdpl.log ;;
     overlap) timeout -k 10 600 python tools/overlap_probe.py > $out/overlap.log 2>&1; grep " ms" $out/overlap.log ;;
+    seedpool) make -C lotus_amd/csrc tuning -j8 > $out/tuning_build.log 2>&1; timeout -k 10 600 python tools/seed_pool_sweep.py > $out/seedpool.log 2>&1; grep "tiles per shard" $out/seedpool.log ;;
     tcall) timeout -k 10 600 python tools/tcall_probe.py > $out/tcall.log 2>&1; cat $out/tcall.log ;;
     pyfix) timeout -k 10 900 python -m pytest tests -m gpu -q -k "$PYK" --timeout 600 --durations=12 -p no:cacheprovider > $out/pytest_fix.log 2>&1; tail -30 $out/pytest_fix.log ;;
     smoke) timeout -k 10 300 python -c 'import __graft_entry__ as g; g.smoke()' > $out/smoke.log 2>&1; tail -3 $out/smoke.log ;;
