@@ -132,11 +132,13 @@ int32_t lvs_flat_search_keys(const void* xb, int32_t xb_pack, int64_t nb, const 
  * computes it, and the k-th largest of a subset never exceeds the k-th largest of all rows; a shard may return fewer than k
  * keys (empty slots = key 0) when fewer of its rows reach the threshold - lvs_merge_keys of all shards' lists is complete.
  * ---- */
-/* sample tiles a shard of nb rows contributes for nq queries (0: this shape is not seeded; k <= 56 only) */
+/* sample tiles a shard of nb rows contributes for nq queries (0: this shape is not seeded; k <= 56 only).  Beyond 64 query
+ * tiles: the call's own sample size or a twenty-fourth of the shard, whichever is larger, at most 24 tiles. */
 int32_t lvs_flat_search_seed_tiles(int64_t nq, int64_t nb, int32_t k);
 /* out_scores [tiles][nq] float32: the best score (larger = better domain, the values lvs_flat_search_keys ranks, operands'
  * pack scales included) of every query over tile t = rows [256 t, 256 t + 256) of xb; tiles past the shard's last whole
- * tile are filled with -inf ("no row seen"). */
+ * tile are filled with -inf ("no row seen"); a shard shorter than one tile (nb < 256, NULL buffers allowed) fills its whole
+ * block that way. */
 int32_t lvs_flat_search_seed_scores(const void* xb, int32_t xb_pack, int64_t nb, const void* xq, int32_t xq_pack, int64_t nq,
                                     int32_t d, int32_t metric, const float* xb_norms_sq, const float* xq_norms_sq,
                                     int32_t tiles, float* out_scores, void* stream);

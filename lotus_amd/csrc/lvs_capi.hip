@@ -1407,7 +1407,6 @@ extern "C" int32_t lvs_flat_search_seed_scores(const void* xb, int32_t xb_pack, 
     LVS_REQUIRE(tiles >= 0, "bad tile count %d", tiles);
     if (nq == 0 || tiles == 0) return LVS_OK;
     LVS_REQUIRE(out_scores, "out_scores is NULL");
-    LVS_REQUIRE(metric != LVS_METRIC_L2 || (xb_norms_sq && xq_norms_sq), "L2 needs both norm vectors");
     LVS_DEVICE_GUARD(stream);
     hipStream_t st = (hipStream_t)stream;
     const int have = (int)(nb / LVS_BC < tiles ? nb / LVS_BC : tiles);  // whole tiles of real rows only
@@ -1417,8 +1416,9 @@ extern "C" int32_t lvs_flat_search_seed_scores(const void* xb, int32_t xb_pack, 
         hipLaunchKernelGGL(fill_f32_kernel, dim3((unsigned)lvs_ceil_div(cnt, 256)), dim3(256), 0, st, dst, cnt, -INFINITY);
         LVS_HIP_CHECK(hipGetLastError());
     }
-    if (have == 0) return LVS_OK;
+    if (have == 0) return LVS_OK;  // an empty or shorter-than-a-tile shard (its buffers may be NULL) still fills its block
     LVS_REQUIRE(xb && xq, "NULL rows");
+    LVS_REQUIRE(metric != LVS_METRIC_L2 || (xb_norms_sq && xq_norms_sq), "L2 needs both norm vectors");
     LvsTileArgs a;
     memset(&a, 0, sizeof(a));
     a.xb = xb;

@@ -480,6 +480,48 @@ def test_seeded_list_kernel(hip_backend, nq, nb, d, k, mode, metric):
         assert set(I[0, :2]) == {3, nb // 2 + 3} and I[0, 0] == 3
 
 
+@pytest.mark.parametrize("metric,k,nq,d", [(IP, 10, 2304, 64), (L2, 5, 3000, 96), (IP, 15, 2100, 32)])
+def test_pooled_thresholds_of_shards_keep_the_merged_result_exact(hip_backend, metric, k, nq, d):
+    """The exchange behind a row-sharded join (lvs_flat_search_seed_scores -> all-gather -> lvs_flat_search_keys_seeded) through
+    the C ABI on one GPU: uneven shards - one of 100 000 rows, one of 45 000, one SHORTER than a sample tile (its block is all
+    -inf), one empty - searched with the pooled sample scores and merged == the oracle's search over all rows; lists may come
+    back short, never wrong.  Also: sample blocks holding fewer than k real values (no threshold), duplicated rows whose
+    score IS the threshold (ties pass), and the stream-kernel path (few queries) taking the same seeds."""
+    import torch
+
+    be = hip_backend
+    nb = 100_000 + 45_000 + 200
+    xb = synth.corpus(nb, d, seed=77) * (1.2 if metric == L2 else 1.0)
+    xb[100_000:100_050] = xb[:50]          # rows of shard 0's sample duplicated in shard 1: equal scores across shards
+    xq, _ = synth.queries(xb, nq, seed=78)
+    xq[:50] = xb[:50]
+    cq = be.pack(xq.astype(np.float16), F16)
+    bounds = [(0, 100_000), (100_000, 145_000), (145_000, 145_200), (145_200, 145_200)]
+    shards = [be.pack(xb[lo:hi].astype(np.float16), F16) for lo, hi in bounds]
+    tiles = 12
+    blocks = [be.seed_scores(sh, cq, metric, tiles) for sh in shards]
+    assert bool(torch.isneginf(blocks[2]).all()) and bool(torch.isneginf(blocks[3]).all())  # shorter than a tile / empty
+    assert bool(torch.isfinite(blocks[0]).all())
+    pooled = torch.cat(blocks)
+    Dr, Ir = oracle.flat_search(_stored(xb, F16), _stored(xq, F16), k, metric)
+    atol = 1e-5 if metric == IP else 4e-5
+    for seeds in (pooled, pooled[:k - 1], torch.cat([blocks[2], blocks[0][:k - 2]])):   # full; fewer rows than k; < k finite
+        parts = torch.stack([be.search_keys(sh, cq, k, metric, id_offset=lo, seed_scores=seeds) for sh, (lo, _) in zip(shards, bounds)])
+        D, I = (t.cpu().numpy() for t in be.keys_to_result(be.merge_keys(parts), metric))
+        err, hard, recall = synth.compare_topk(Dr, Ir, D, I, atol=atol)
+        assert err <= atol and hard == 0 and recall >= 0.9999, (err, hard, recall)
+        assert np.array_equal(I[:50, 0], np.arange(50)) and np.array_equal(I[:50, 1], 100_000 + np.arange(50))  # ties: lowest id first
+    short = int((parts == 0).sum().item())
+    assert short >= 0  # (a shard may return fewer than k keys; the merge above was complete regardless)
+    # few queries: the small-batch streaming kernel takes the same pooled seeds
+    few = be.slice_rows(cq, 0, 40)
+    parts = torch.stack([be.search_keys(sh, few, k, metric, id_offset=lo, seed_scores=pooled[:, :40].contiguous())
+                         for sh, (lo, _) in zip(shards, bounds)])
+    D, I = (t.cpu().numpy() for t in be.keys_to_result(be.merge_keys(parts), metric))
+    err, hard, recall = synth.compare_topk(Dr[:40], Ir[:40], D, I, atol=atol)
+    assert err <= atol and hard == 0 and recall >= 0.9999, (err, hard, recall)
+
+
 @pytest.mark.parametrize("cmode,qmode,metric,nq,nb,d,k", [
     (SPLIT, SPLIT, IP, 3000, 60_000, 384, 10),   # LOTUS's default: fp32 embeddings on both sides (3 passes -> 1)
     (SPLIT, F16, L2, 2000, 50_000, 200, 5),
