@@ -132,10 +132,17 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # LOTUS_BENCH_REHEARSAL=1 (development only, never a reported number): the ranks share cuda:0 and talk over gloo, so that
+    # the N > 1 code path of this file can be exercised on a one-GPU box (RCCL refuses two ranks on one device)
+    rehearsal = world > 1 and os.environ.get("LOTUS_BENCH_REHEARSAL") == "1"
+    dev_index = 0 if rehearsal else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1:
-        dist.init_process_group("nccl", device_id=device)  # RCCL
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)  # RCCL
 
     from lotus_amd import _capi, _dist
     from lotus_amd.backend import HipBackend
@@ -192,7 +199,7 @@ def main():
     ktot_ms, klaunches = be.timing_read()
     be.timing_enable(False)
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearsal else device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
@@ -217,7 +224,7 @@ def main():
             "scaling": "strong",
             "vs_baseline": None,
             "dtype": "f16",
-            "data": "synthetic",
+            "data": "synthetic" if not rehearsal else "synthetic; REHEARSAL: all ranks on one GPU over gloo - not a measurement",
             "config": {"workload": f"sem_sim_join {nq} x {n} rows, d={d} fp16, k={k}, IP; corpus row-sharded over {world} "
                                    f"GPU(s) ({hi - lo} rows each), pooled sample thresholds + RCCL all-gather top-k merge; "
                                    "device-resident in/out",

@@ -20,6 +20,12 @@ import numpy as np
 
 from . import _capi, _dist
 
+# row ranges of an exhaustive iteration from 2^21 training rows on (an int, or a tuple of fractions).  Nothing hides the sums of
+# the LAST range, so it is the shortest: 10 M x 1 024 x 768, same box, ms per iteration (profiles/r06c_km_parts_probe.log):
+# one range 21.5, 3 / 4 / 6 equal ranges 20.5 / 20.2-20.3 / 20.5, 30 / 30 / 25 / 15 % 19.8
+PARTS_DEFAULT = (0.30, 0.30, 0.25, 0.15)
+SIDE_STREAM_PRIORITY = 0    # of the stream the sums of a range run on
+
 
 @dataclass
 class KMeansResult:
@@ -60,11 +66,11 @@ def kmeans(x, k: int, niter: int = 20, seed: int = 1234, max_points_per_centroid
       Either way one all-reduce of the ``[k,d]`` sums, ``[k]`` counts and the objective per iteration, and one
       all-gather of the final cluster ids; nothing else crosses the ranks.
 
-    ``parts`` (default: 4 from 2^21 training rows on, exhaustive iterations only): the training rows go through an iteration in
-    that many consecutive ranges, and the in-row-order sums of one range run on a side stream UNDER the assignment search of the
+    ``parts`` (an int or a sequence of fractions; default: ``PARTS_DEFAULT`` from 2^21 training rows on, exhaustive iterations
+    only): the training rows go through an iteration in that many consecutive ranges, and the in-row-order sums of one range run on a side stream UNDER the assignment search of the
     next (the sums kernel needs 82 VGPRs: one of its waves fits on a SIMD beside the two waves of the assignment kernel).  The
     sums continue across the ranges in row order, so results are bit-identical to ``parts=1``; at 10 M x 1 024 x 768 an iteration
-    drops from 21.0 to 19.2 ms (tools/overlap_probe.py).
+    drops from 21.5 to 19.8 ms (tools/km_parts_probe.py; search + sums alone 21.0 -> 19.2 ms, tools/overlap_probe.py).
 
     ``trace`` (a list, optional; parity tooling): one dict per iteration with device copies of the centroids the iteration
     assigned against (``centroids``, float32 [k,d], the rows' scaled domain) and of the assignment's result keys (``keys``).
@@ -168,13 +174,19 @@ def kmeans(x, k: int, niter: int = 20, seed: int = 1234, max_points_per_centroid
         # stats["time_iterations"] = True: device time of every iteration from events on the launch stream -> stats["iteration_ms"]
         timed = stats is not None and bool(stats.get("time_iterations")) and dev.type == "cuda"
         marks = []
-        nparts = int(parts) if parts is not None else (4 if train.n >= (1 << 21) else 1)
-        nparts = max(1, min(nparts, train.n // 65536)) if (not use_bounds and hasattr(be, "kmeans_accumulate_keys_into")
-                                                           and dev.type == "cuda") else 1
+        if parts is None:
+            parts = PARTS_DEFAULT if train.n >= (1 << 21) else 1
+        fracs = [1.0 / int(parts)] * int(parts) if isinstance(parts, int) else [float(f) for f in parts]
+        can_overlap = not use_bounds and hasattr(be, "kmeans_accumulate_keys_into") and dev.type == "cuda"
+        nparts = len(fracs) if (can_overlap and min(fracs) * train.n >= 65536) else 1
         if nparts > 1:
-            side = torch.cuda.Stream(device=dev)
+            side = torch.cuda.Stream(device=dev, priority=SIDE_STREAM_PRIORITY)
             side_ws = torch.empty(int(be.lib.lvs_kmeans_accumulate_workspace_bytes(train.n, k)) + 256, dtype=torch.uint8, device=dev)
-            cuts = [(train.n * i // nparts) // 4096 * 4096 for i in range(nparts)] + [train.n]
+            acc, cuts = 0.0, [0]
+            for f in fracs[:-1]:
+                acc += f / sum(fracs)
+                cuts.append(int(train.n * acc) // 4096 * 4096)
+            cuts.append(train.n)
         for it in range(niter):
             if timed:
                 ev = torch.cuda.Event(enable_timing=True)

@@ -581,7 +581,7 @@ def test_two_candidate_certificate_settles_split_twins_with_two_dot_products(hip
 
 @pytest.mark.parametrize("mode", [F16, SPLIT])
 def test_ranges_with_overlapped_sums_equal_the_single_pass(hip_backend, mode):
-    """From 2^21 training rows on an iteration hands the rows over in four consecutive ranges and runs the in-row-order sums
+    """From 2^21 training rows on an iteration hands the rows over in four consecutive ranges (30 / 30 / 25 / 15 %) and runs the in-row-order sums
     of one range on a side stream under the assignment search of the next (lotus_amd/cluster.py `parts`): the sums continue
     across the ranges (lvs_kmeans_accumulate_keys carries them along), so objectives, centroids, split counts, the traced
     assignments and the final assignment are bit-identical to the single pass - also with an uneven last range."""
@@ -599,6 +599,13 @@ def test_ranges_with_overlapped_sums_equal_the_single_pass(hip_backend, mode):
     assert np.array_equal(one.nsplit, four.nsplit) and np.array_equal(one.assign, four.assign)
     for a, b in zip(t1, t4):
         assert bool((a["keys"].reshape(-1) == b["keys"].reshape(-1)).all()) and bool((a["centroids"] == b["centroids"]).all())
+    # ranges of unequal length (the default from 2^21 rows on: the last, whose sums nothing hides, is the shortest)
+    from lotus_amd import cluster as cl
+
+    assert not isinstance(cl.PARTS_DEFAULT, int) and abs(sum(cl.PARTS_DEFAULT) - 1.0) < 1e-9
+    frac = kmeans(x, K, parts=cl.PARTS_DEFAULT, **kw)
+    assert np.array_equal(one.obj, frac.obj) and np.array_equal(one.centroids, frac.centroids)
+    assert np.array_equal(one.nsplit, frac.nsplit) and np.array_equal(one.assign, frac.assign)
     # the C ABI's contract on its own: two calls over consecutive ranges == one call, bit for bit
     import torch
 
