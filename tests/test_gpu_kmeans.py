@@ -170,6 +170,8 @@ def test_kmeans_scale_smoke(hip_backend):
     (SPLIT, SPLIT, L2, 9_000, 300, 384),    # LOTUS's default fp32 embeddings on both sides (3 passes -> 1)
     (F16, SPLIT, IP, 5_000, 2048, 128),
     (SPLIT, F16, IP, 3_000, 70_000, 64),    # long corpus: several slabs -> merge_top2
+    (SPLIT, F16, L2, 4_000, 16_384, 64),    # the longest corpus the query-streaming kernel takes (64 resident tiles) ...
+    (SPLIT, F16, L2, 4_000, 16_385, 64),    # ... and one row more: the slab kernel (lvs_nearest_hi)
 ])
 def test_certified_nearest_equals_the_exact_search(hip_backend, cmode, qmode, metric, nq, nb, d):
     """`nearest` = one MFMA pass over the hi parts + margin certificate + exact re-search of the uncertified queries;
@@ -499,7 +501,7 @@ def _hi_scores(xb, xq, metric):
 
 @pytest.mark.parametrize("metric", [L2, IP])
 @pytest.mark.parametrize("nq,nb,d", [(700, 1, 64), (300, 2, 64), (1000, 3, 96), (513, 255, 64), (2049, 257, 128),
-                                     (5000, 1024, 768), (70_000, 1000, 64), (300, 5000, 32)])
+                                     (5000, 1024, 768), (70_000, 1000, 64), (300, 5000, 32), (1500, 16_384, 32)])
 def test_query_streaming_nearest_returns_the_top_three(hip_backend, metric, nq, nb, d):
     """lvs_nearest3 (lvs_assign.hip): queries stream past resident corpus tiles; per query the best and second-best ROWS and
     the third-best SCORE of the one-pass (hi parts) scores, every value perturbed by < 2^-17 relative (position tags).  Ragged
