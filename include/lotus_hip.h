@@ -29,13 +29,15 @@
 extern "C" {
 #endif
 
-#define LVS_ABI_VERSION 4 /* 2: pack modes in lvs_flat_search_workspace_bytes, lvs_build_flags, k-means device update;
+#define LVS_ABI_VERSION 5 /* 2: pack modes in lvs_flat_search_workspace_bytes, lvs_build_flags, k-means device update;
                              3: k-means iteration entirely on the device (objective, split, repack, accumulate from keys),
                                 lvs_pack_rows_checked (validation + power-of-two scale), lvs_absmax, lvs_margin_select_stats;
                                 scale exponents in lvs_unpack_rows / lvs_keys_to_result / lvs_scores / lvs_range_join;
                              4: pooled sample thresholds of a sharded join (lvs_flat_search_seed_tiles / _seed_scores /
                                 lvs_flat_search_keys_seeded); query-streaming nearest-row search with a two-candidate
-                                certificate (lvs_nearest3 / _select / lvs_resolve_pairs) */
+                                certificate (lvs_nearest3 / _select / lvs_resolve_pairs);
+                             5: banded candidate lists for the certified one-pass search (lvs_flat_search_keys_hi_banded,
+                                lvs_certify_topk_banded) */
 
 #define LVS_OK 0
 #define LVS_EINVAL (-1)   /* bad argument */
@@ -157,6 +159,17 @@ int32_t lvs_flat_search_keys_hi(const void* xb, int32_t xb_pack, int64_t nb, con
                                 int32_t d, int32_t metric, int32_t k, const float* xb_norms_sq, const float* xq_norms_sq,
                                 int64_t id_offset, const uint32_t* row_ids, uint64_t* out_keys, void* workspace,
                                 int64_t workspace_bytes, void* stream);
+/* lvs_flat_search_keys_hi with BANDED lists: k list slots per query, but a row is admitted only while its one-pass score is
+ * >= max(last slot, kc-th slot - (band_scale * sqrt(xq_norms_sq[q]) + band_slack)) - both rise monotonically during the search.
+ * A row further than the certificate's band below the kc-th best can never matter to lvs_certify_topk_banded, so the lists
+ * cost the insertions of kc-deep ones and slots beyond the band stay EMPTY (key 0, sorted last) unless the band is crowded.
+ * kc <= k; needs xq_norms_sq under either metric.  Launches that do not go through the tiled list kernel (small batches on
+ * the streaming kernel) return plain k-deep lists - which lvs_certify_topk_banded accepts just the same. */
+int32_t lvs_flat_search_keys_hi_banded(const void* xb, int32_t xb_pack, int64_t nb, const void* xq, int32_t xq_pack, int64_t nq,
+                                       int32_t d, int32_t metric, int32_t k, int32_t kc, float band_scale, float band_slack,
+                                       const float* xb_norms_sq, const float* xq_norms_sq, int64_t id_offset,
+                                       const uint32_t* row_ids, uint64_t* out_keys, void* workspace, int64_t workspace_bytes,
+                                       void* stream);
 /* keys [nq][k] sorted best-first in place (k <= 64). */
 int32_t lvs_sort_keys_desc(uint64_t* keys, int64_t nq, int32_t k, void* stream);
 /* approx_keys [nq][k1] from lvs_flat_search_keys_hi (best first), exact_keys [nq][k1] the same candidates after
@@ -165,6 +178,13 @@ int32_t lvs_sort_keys_desc(uint64_t* keys, int64_t nq, int32_t k, void* stream);
  * Uncertified queries are appended to out_idx (order unspecified), *out_count (device uint64, zeroed by the caller) += n. */
 int32_t lvs_certify_topk(const uint64_t* approx_keys, const uint64_t* exact_keys, const float* q_norms_sq, int64_t nq,
                          int32_t k1, int32_t k, float scale, float slack, int64_t* out_idx, uint64_t* out_count, void* stream);
+/* The same for lists from lvs_flat_search_keys_hi_banded: with bound = scale * sqrt(q_norms_sq) + slack, a row outside the list
+ * scored at most max(last slot, k-th one-pass score - band * bound), `band` no larger than the search's (band_scale / scale); the
+ * query is certified when its k-th exact score is strictly above that + bound - always, once band > 2 and the band was not
+ * crowded beyond the list's slots.  band = 0: lvs_certify_topk. */
+int32_t lvs_certify_topk_banded(const uint64_t* approx_keys, const uint64_t* exact_keys, const float* q_norms_sq, int64_t nq,
+                                int32_t k1, int32_t k, float scale, float slack, float band, int64_t* out_idx,
+                                uint64_t* out_count, void* stream);
 /* Merge `nparts` candidate lists (e.g. the all-gathered per-shard lists): parts [nparts][nq][k] -> out [nq][k].
  * Any nparts >= 1 and k <= LVS_MAX_K (long lists are folded in rounds of at most 4096 keys per query). */
 int32_t lvs_merge_keys(const uint64_t* parts, int32_t nparts, int64_t nq, int32_t k, uint64_t* out_keys,

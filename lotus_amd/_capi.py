@@ -18,7 +18,7 @@ METRIC_IP, METRIC_L2 = 0, 1
 PACK_F16, PACK_SPLIT = 0, 1
 MAX_K = 2048
 NEAREST3_MAX_ROWS = 16384
-ABI_VERSION = 4
+ABI_VERSION = 5
 BUILD_TUNING, BUILD_COUNT_EVENTS = 1, 2
 PACK_FLAG_NONFINITE, PACK_FLAG_RANGE = 1, 2
 
@@ -61,8 +61,12 @@ SIGNATURES = {
     "lvs_rescore_keys": (_i32, [_vp, _i32, _vp, _i32, _i64, _i32, _i32, _vp, _vp, _i64, _i32, _vp, _vp]),
     "lvs_flat_search_keys_hi": (_i32, [_vp, _i32, _i64, _vp, _i32, _i64, _i32, _i32, _i32, _vp, _vp, _i64, _vp, _vp,
                                        _vp, _i64, _vp]),
+    "lvs_flat_search_keys_hi_banded": (_i32, [_vp, _i32, _i64, _vp, _i32, _i64, _i32, _i32, _i32, _i32, ctypes.c_float,
+                                              ctypes.c_float, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp]),
     "lvs_sort_keys_desc": (_i32, [_vp, _i64, _i32, _vp]),
     "lvs_certify_topk": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, ctypes.c_float, ctypes.c_float, _vp, _vp, _vp]),
+    "lvs_certify_topk_banded": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, ctypes.c_float, ctypes.c_float, ctypes.c_float, _vp,
+                                       _vp, _vp]),
     "lvs_margin_select": (_i32, [_vp, _vp, _vp, _i64, ctypes.c_float, ctypes.c_float, _vp, _vp, _vp]),
     "lvs_margin_select_stats": (_i32, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
     "lvs_kmeans_accumulate_workspace_bytes": (_i64, [_i64, _i32]),

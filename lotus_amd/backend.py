@@ -353,6 +353,8 @@ class HipBackend:
     CERT_MIN_PAIRS = 1 << 26  # below this many (query, row) pairs the extra launches cost more than the two passes saved
     CERT_MAX_K = 48
     CERT_SPARE_SMALL_K = 5  # spare list slots of the one-pass search for k <= 10 (k1 = k + spare <= 15)
+    CERT_BAND_SEARCH = 2.05   # banded lists: rows further than this many error bounds below the k-th one-pass score are not
+    CERT_BAND_CERTIFY = 2.02  # listed; the certificate assumes a slightly narrower band (> 2 is what its proof needs)
 
     SEED_EXCHANGE_MIN_QUERIES = 2048  # below this a sharded call is too short for an extra collective (see seed_tiles)
 
@@ -439,6 +441,19 @@ class HipBackend:
                 pass
         return v
 
+    def row_norm_max(self, pk: PackedRows) -> float:
+        """Largest |row| of a device image, computed once per image and cached on it."""
+        if pk.n == 0:
+            return 0.0
+        v = getattr(pk, "_row_norm_max", None)
+        if v is None:
+            v = float(pk.norms.max().sqrt().item())
+            try:
+                pk._row_norm_max = v
+            except Exception:
+                pass
+        return v
+
     def _search_call(self, name: str, corpus, queries, k, metric, id_offset):
         torch = self.torch
         keys = torch.empty((queries.n, k), dtype=torch.int64, device=self.device)
@@ -465,24 +480,42 @@ class HipBackend:
         if first_round:
             k1 = min(15, k + self.CERT_SPARE_SMALL_K) if k <= 10 else min(56, k + 8)
         k1 = min(k1, corpus.n)
-        approx = self._search_call("lvs_flat_search_keys_hi", corpus, queries, k1, metric, id_offset)
-        exact = approx.clone()
-        self._c("lvs_rescore_keys", _ptr(corpus.rows), corpus.mode, _ptr(queries.rows), queries.mode, nq, corpus.d, metric,
-                _ptr(corpus.norms), _ptr(queries.norms), int(id_offset), k1, _ptr(exact), self._stream())
-        self._c("lvs_sort_keys_desc", _ptr(exact), nq, k1, self._stream())
         # |s - s_hi| <= |q| |lo_row| + |lo_q| |row| + |lo_q| |lo_row| (Cauchy-Schwarz) with the MEASURED largest lo-part norms
         # E_c, E_q of the two operands (cached per device image; ~0.4 x the worst case 2^-11 |x|, so fewer queries stay open than
         # under round 3's a-priori bound; being measured, they also cover components in fp16's subnormal range), + float32
         # accumulation noise relative to |q| |row|
-        R = float(corpus.norms.max().sqrt().item())
+        R = self.row_norm_max(corpus)
         E_c, E_q = self.lo_norm_max(corpus), self.lo_norm_max(queries)
         c = 1.0 if metric == _capi.METRIC_IP else 2.0
         scale = c * (E_c * (1.0 + 1e-3) + 8e-6 * R)
         slack = 1e-6 * (2.0 ** (corpus.exp + queries.exp) + R * R) + c * E_q * (R + E_c) * (1.0 + 1e-3)
+        # BANDED lists: with bound = scale |q| + slack, a row whose one-pass score is more than 2 bound below the k-th best
+        # one-pass score cannot reach the exact top k (k-th exact >= k-th one-pass - bound).  So the kernel admits a row only
+        # above max(last slot, k-th slot - CERT_BAND_SEARCH x bound): the k1-deep lists then cost the insertions of k-deep
+        # ones, and a query stays open only when more than k1 - k rows crowd that band.  The certificate assumes the slightly
+        # narrower CERT_BAND_CERTIFY (rounding of the two evaluations of the band can never make it claim too much).
+        keys = torch.empty((nq, k1), dtype=torch.int64, device=self.device)
+        need = int(self.lib.lvs_flat_search_workspace_bytes(nq, corpus.n, corpus.d, k1, corpus.mode, queries.mode))
+        if need < 0:
+            raise LotusHipError("lvs_flat_search_workspace_bytes rejected the shape")
+        ws = self._workspace(need)
+        banded = k1 > k
+        if banded:
+            self._c("lvs_flat_search_keys_hi_banded", _ptr(corpus.rows), corpus.mode, corpus.n, _ptr(queries.rows), queries.mode,
+                    nq, corpus.d, metric, k1, k, float(self.CERT_BAND_SEARCH * scale), float(self.CERT_BAND_SEARCH * slack),
+                    _ptr(corpus.norms), _ptr(queries.norms), int(id_offset), None, _ptr(keys), _ptr(ws), int(ws.numel()),
+                    self._stream())
+            approx = keys
+        else:
+            approx = self._search_call("lvs_flat_search_keys_hi", corpus, queries, k1, metric, id_offset)
+        exact = approx.clone()
+        self._c("lvs_rescore_keys", _ptr(corpus.rows), corpus.mode, _ptr(queries.rows), queries.mode, nq, corpus.d, metric,
+                _ptr(corpus.norms), _ptr(queries.norms), int(id_offset), k1, _ptr(exact), self._stream())
+        self._c("lvs_sort_keys_desc", _ptr(exact), nq, k1, self._stream())
         idx = torch.empty((nq,), dtype=torch.int64, device=self.device)
         cnt = torch.zeros((1,), dtype=torch.int64, device=self.device)
-        self._c("lvs_certify_topk", _ptr(approx), _ptr(exact), _ptr(queries.norms), nq, k1, k, float(scale), float(slack),
-                _ptr(idx), _ptr(cnt), self._stream())
+        self._c("lvs_certify_topk_banded", _ptr(approx), _ptr(exact), _ptr(queries.norms), nq, k1, k, float(scale), float(slack),
+                float(self.CERT_BAND_CERTIFY if banded else 0.0), _ptr(idx), _ptr(cnt), self._stream())
         keys = exact[:, :k].contiguous()
         n_open = int(cnt.item())
         n_plain = 0

@@ -480,17 +480,27 @@ __global__ __launch_bounds__(256) void sort_keys_kernel(u64* __restrict__ keys, 
 // exact top k.  Queries that fail the test are appended to out_idx.  An unfilled list (fewer than k1 rows) holds every row.
 __global__ __launch_bounds__(256) void certify_topk_kernel(const u64* __restrict__ approx, const u64* __restrict__ exact,
                                                            const float* __restrict__ qn, long long nq, int k1, int k,
-                                                           float scale, float slack, long long* __restrict__ out_idx,
+                                                           float scale, float slack, float band,
+                                                           long long* __restrict__ out_idx,
                                                            unsigned long long* __restrict__ out_count) {
     const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     bool open = false;
     if (q < nq) {
         const u64 last = approx[q * k1 + k1 - 1];
         const u64 kth = exact[q * k1 + k - 1];
-        if (last != 0 && kth != 0) {
+        const float bound = scale * sqrtf(qn ? qn[q] : 1.0f) + slack;
+        if (band > 0.f) {
+            // banded list: a row outside it scored below max(last slot, k-th one-pass score - band * bound) when it was
+            // turned away (both only rise during the search); an unfilled list no longer means "every row is here"
+            const u64 akth = approx[q * k1 + k - 1];
+            if (kth != 0 && akth != 0) {
+                float s_min = lvs_unord32((uint32_t)(akth >> 32)) - band * bound;
+                if (last != 0) s_min = fmaxf(s_min, lvs_unord32((uint32_t)(last >> 32)));
+                open = !(lvs_unord32((uint32_t)(kth >> 32)) > s_min + bound);
+            }
+        } else if (last != 0 && kth != 0) {
             const float s_min = lvs_unord32((uint32_t)(last >> 32));
             const float s_k = lvs_unord32((uint32_t)(kth >> 32));
-            const float bound = scale * sqrtf(qn ? qn[q] : 1.0f) + slack;
             open = !(s_k > s_min + bound);
         }
     }
@@ -648,6 +658,16 @@ thread_local bool g_hi_only = false;
 struct HiOnlyScope {
     HiOnlyScope() { g_hi_only = true; }
     ~HiOnlyScope() { g_hi_only = false; }
+};
+// lvs_flat_search_keys_hi_banded: list slots beyond a per-query band below the kc-th best stay empty (LvsTileArgs::kc)
+struct BandSpec {
+    int kc;
+    float bscale, bslack;
+};
+thread_local BandSpec g_band = {0, 0.f, 0.f};
+struct BandScope {
+    BandScope(int kc, float bscale, float bslack) { g_band = BandSpec{kc, bscale, bslack}; }
+    ~BandScope() { g_band = BandSpec{0, 0.f, 0.f}; }
 };
 
 // bytes reserved for the small-batch kernel's candidate lists [ranges][nq][k]
@@ -1012,8 +1032,11 @@ bool make_two_phase_plan(int64_t nq, int64_t nb, int32_t d, int32_t xb_pack, int
 // than k ranges saw a row.  One wave per query: 64 values at a time are sorted across the lanes and folded into the running
 // top 64 (k <= 56).  Every value is a real row's score, and the k-th largest of a subset never exceeds the k-th largest of
 // all rows: a valid lower bound of the final k-th best score, so the seeded search stays exact.
+// Banded lists (kc > 0, qn given): the larger of that and (kc-th largest - the query's band) - equally a lower bound of what
+// the kernel's own admission rule ends at.
 __global__ __launch_bounds__(256) void seed_kth_kernel(const float* __restrict__ seeds, int nparts, long long nq, int k,
-                                                       uint32_t* __restrict__ gtau) {
+                                                       uint32_t* __restrict__ gtau, int kc = 0, const float* __restrict__ qn = nullptr,
+                                                       float bscale = 0.f, float bslack = 0.f) {
     const int lane = threadIdx.x & 63;
     const long long q = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (q >= nq) return;
@@ -1034,7 +1057,14 @@ __global__ __launch_bounds__(256) void seed_kth_kernel(const float* __restrict__
             best = lvs_wave_bitonic_merge_desc(best, lane);
         }
     }
-    const uint32_t kth = (uint32_t)(lvs_shfl_u64(best, k - 1) >> 32);
+    uint32_t kth = (uint32_t)(lvs_shfl_u64(best, k - 1) >> 32);
+    if (kc > 0 && qn) {
+        const uint32_t kcth = (uint32_t)(lvs_shfl_u64(best, kc - 1) >> 32);
+        if (kcth) {
+            const uint32_t ob = lvs_ord32(lvs_unord32(kcth) - (bscale * sqrtf(qn[q]) + bslack));
+            kth = ob > kth ? ob : kth;
+        }
+    }
     if (lane == 0) gtau[q] = kth;
 }
 
@@ -1296,11 +1326,15 @@ static int32_t flat_search_impl(const void* xb, int32_t xb_pack, int64_t nb, con
         // pass > 0: only keys strictly below the last key of the previous pass take part
         a.ub = pass == 0 ? nullptr : (const u64*)out_keys + (col0 - 1);
         a.ub_stride = k;
+        const bool banded = g_band.kc > 0 && g_band.kc < kp && p.npass == 1 && !pred && !use_top1 && xq_norms_sq;
+        a.kc = banded ? g_band.kc : 0;
+        a.bscale = banded ? g_band.bscale : 0.f;
+        a.bslack = banded ? g_band.bslack : 0.f;
         const bool seedable = pass == 0 && p.npass == 1 && !pred && !use_top1;
         const int seed_tiles = seedable ? tile_seed_tiles(nq, nb, kp) : 0;
         if (seedable && ext_seeds && ext_rows >= kp) {  // the caller's pooled sample scores (every shard's sample)
             hipLaunchKernelGGL(seed_kth_kernel, dim3((unsigned)lvs_ceil_div(nq, 4)), dim3(256), 0, st, ext_seeds, (int)ext_rows,
-                               (long long)nq, kp, gtau);  // writes every gtau[q]
+                               (long long)nq, kp, gtau, a.kc, xq_norms_sq, a.bscale, a.bslack);  // writes every gtau[q]
             LVS_HIP_CHECK(hipGetLastError());
         } else if (seed_tiles > 0) {  // thresholds seeded from a sample instead of cold starts (tile_seed_tiles)
             float* seeds = (float*)(ws + p.off_seed);
@@ -1313,11 +1347,12 @@ static int32_t flat_search_impl(const void* xb, int32_t xb_pack, int64_t nb, con
             sd.gq = 1;
             sd.lead_slabs = 0;
             sd.k = 1;
+            sd.kc = 0;
             sd.ub = nullptr;
             sd.seed_out = seeds;
             LVS_HIP_CHECK(lvs_tile_launch(LVS_MODE_SEED, sd, st));
             hipLaunchKernelGGL(seed_kth_kernel, dim3((unsigned)lvs_ceil_div(nq, 4)), dim3(256), 0, st, (const float*)seeds,
-                               sd.nslab, (long long)nq, kp, gtau);  // writes every gtau[q]
+                               sd.nslab, (long long)nq, kp, gtau, a.kc, xq_norms_sq, a.bscale, a.bslack);  // writes every gtau[q]
             LVS_HIP_CHECK(hipGetLastError());
         } else {
             LVS_HIP_CHECK(hipMemsetAsync(gtau, 0, (size_t)nq * 4, st));
@@ -1551,6 +1586,21 @@ extern "C" int32_t lvs_flat_search_keys_hi(const void* xb, int32_t xb_pack, int6
                                 out_keys, workspace, workspace_bytes, stream);
 }
 
+extern "C" int32_t lvs_flat_search_keys_hi_banded(const void* xb, int32_t xb_pack, int64_t nb, const void* xq, int32_t xq_pack,
+                                                  int64_t nq, int32_t d, int32_t metric, int32_t k, int32_t kc,
+                                                  float band_scale, float band_slack, const float* xb_norms_sq,
+                                                  const float* xq_norms_sq, int64_t id_offset, const uint32_t* row_ids,
+                                                  uint64_t* out_keys, void* workspace, int64_t workspace_bytes,
+                                                  void* stream) {
+    LVS_REQUIRE(kc >= 1 && kc <= k, "banded search: 1 <= kc <= k (got kc=%d, k=%d)", kc, k);
+    LVS_REQUIRE(band_scale >= 0.f && band_slack >= 0.f, "negative band");
+    LVS_REQUIRE(nq == 0 || xq_norms_sq, "banded search needs the query norms");
+    HiOnlyScope hi;
+    BandScope band(kc, band_scale, band_slack);
+    return lvs_flat_search_keys(xb, xb_pack, nb, xq, xq_pack, nq, d, metric, k, xb_norms_sq, xq_norms_sq, id_offset, row_ids,
+                                out_keys, workspace, workspace_bytes, stream);
+}
+
 extern "C" int32_t lvs_sort_keys_desc(uint64_t* keys, int64_t nq, int32_t k, void* stream) {
     LVS_REQUIRE(nq >= 0 && k >= 0 && k <= 64, "lvs_sort_keys_desc: k must be at most 64 (got %d)", k);
     if (nq == 0 || k <= 1) return LVS_OK;
@@ -1562,18 +1612,24 @@ extern "C" int32_t lvs_sort_keys_desc(uint64_t* keys, int64_t nq, int32_t k, voi
     return LVS_OK;
 }
 
-extern "C" int32_t lvs_certify_topk(const uint64_t* approx_keys, const uint64_t* exact_keys, const float* q_norms_sq,
-                                    int64_t nq, int32_t k1, int32_t k, float scale, float slack, int64_t* out_idx,
-                                    uint64_t* out_count, void* stream) {
-    LVS_REQUIRE(nq >= 0 && k >= 1 && k1 >= k && scale >= 0.f && slack >= 0.f, "bad arguments");
+extern "C" int32_t lvs_certify_topk_banded(const uint64_t* approx_keys, const uint64_t* exact_keys, const float* q_norms_sq,
+                                           int64_t nq, int32_t k1, int32_t k, float scale, float slack, float band,
+                                           int64_t* out_idx, uint64_t* out_count, void* stream) {
+    LVS_REQUIRE(nq >= 0 && k >= 1 && k1 >= k && scale >= 0.f && slack >= 0.f && band >= 0.f, "bad arguments");
     if (nq == 0) return LVS_OK;
     LVS_REQUIRE(approx_keys && exact_keys && out_idx && out_count, "NULL buffer");
     LVS_DEVICE_GUARD(stream);
     hipLaunchKernelGGL(certify_topk_kernel, dim3((unsigned)lvs_ceil_div(nq, 256)), dim3(256), 0, (hipStream_t)stream,
                        (const u64*)approx_keys, (const u64*)exact_keys, q_norms_sq, (long long)nq, (int)k1, (int)k, scale, slack,
-                       (long long*)out_idx, (unsigned long long*)out_count);
+                       band, (long long*)out_idx, (unsigned long long*)out_count);
     LVS_HIP_CHECK(hipGetLastError());
     return LVS_OK;
+}
+
+extern "C" int32_t lvs_certify_topk(const uint64_t* approx_keys, const uint64_t* exact_keys, const float* q_norms_sq,
+                                    int64_t nq, int32_t k1, int32_t k, float scale, float slack, int64_t* out_idx,
+                                    uint64_t* out_count, void* stream) {
+    return lvs_certify_topk_banded(approx_keys, exact_keys, q_norms_sq, nq, k1, k, scale, slack, 0.f, out_idx, out_count, stream);
 }
 
 static int32_t margin_select_launch(const uint64_t* keys, const float* second, const float* q_norms_sq, int64_t nq, float scale,

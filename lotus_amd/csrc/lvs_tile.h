@@ -61,6 +61,10 @@ struct LvsTileArgs {
     int gq;                   // query tiles per XCD group (1,2,4,8,16,32); slabs per group = 32 / gq
     int lead_slabs;           // slabs walked first in 32-wide groups (see item_of_block); 0 or 1
     int no_share;             // 1: slabs do not exchange thresholds - every slab's list is its own exact top-k
+    // LVS_MODE_TOPK, banded lists (kc > 0, kc < k; needs qn): a row is admitted only while its score is >= max(last slot,
+    // kc-th slot - (bscale * |q| + bslack)); slots beyond the band stay empty (lvs_flat_search_keys_hi_banded)
+    int kc;
+    float bscale, bslack;
     // LVS_MODE_COLLECT: keys >= thr_key[q] go to bucket[q][*] (unordered, at most bucket_capacity are kept; bucket_count
     // keeps counting so that the caller sees an overflow)
     const u64* thr_key;       // [nq]

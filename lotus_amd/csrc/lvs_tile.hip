@@ -46,7 +46,8 @@ struct Geo {
     static constexpr int KCAP = MI == 4 ? LVS2_KCAP : LVS3_KCAP;
     static constexpr int OFF_LIST = 2 * STAGE_BYTES;             // u64 [BQ][KCAP] sorted descending, first k used
     static constexpr int OFF_LOCK = OFF_LIST + BQ * KCAP * 8;    // u32 [BQ] list locks
-    static constexpr int LDS_TOTAL = OFF_LOCK + BQ * 4;
+    static constexpr int OFF_EFF = OFF_LOCK + BQ * 4;            // u32 [BQ] banded lists (a.kc > 0): admission threshold per query
+    static constexpr int LDS_TOTAL = OFF_EFF + BQ * 4;
     static_assert(LDS_TOTAL <= 160 * 1024, "LDS budget");
     static_assert(KCAP <= 64, "one lane per list slot");
 };
@@ -135,6 +136,7 @@ __global__ __launch_bounds__(512, 2) void lvs_tile_kernel(const LvsTileArgs a) {
 
     u64* lists = (u64*)(smem + OFF_LIST);
     uint32_t* locks = (uint32_t*)(smem + OFF_LOCK);
+    uint32_t* eff = (uint32_t*)(smem + Geo<MI>::OFF_EFF);
     float* bnl = (float*)(smem + OFF_LIST);           // TOP1: |y|^2 of the current corpus tile [BC]
     u64* part = (u64*)(smem + OFF_LIST + BC * 4);     // TOP1: [BQ][4] per-lane partial best keys
     float* psec = (float*)(smem + OFF_LIST + BC * 4 + BQ * 4 * 8);  // TOP2: [BQ][4] per-lane second-best scores
@@ -219,6 +221,7 @@ __global__ __launch_bounds__(512, 2) void lvs_tile_kernel(const LvsTileArgs a) {
     if (MODE == LVS_MODE_TOPK) {
         for (int i = tid; i < BQ * KCAP; i += 512) lists[i] = 0;
         for (int i = tid; i < BQ; i += 512) locks[i] = 0;
+        for (int i = tid; i < BQ; i += 512) eff[i] = 0;
     }
     float bestv[2] = {-INFINITY, -INFINITY};
     float secv[2] = {-INFINITY, -INFINITY};  // TOP2: second-best score seen by this lane
@@ -284,7 +287,8 @@ __global__ __launch_bounds__(512, 2) void lvs_tile_kernel(const LvsTileArgs a) {
             for (int ni = 0; ni < 2; ++ni) {
                 if (qvalid[ni] && !a.no_share) gpre[ni] = a.gtau[q0 + qloc[ni]];
                 // every wave passed this K-step's barrier, so every insertion of the previous epilogue is in the list
-                lpre[ni] = ((const uint32_t*)(lists + qloc[ni] * KCAP + k - 1))[1];  // score half of the k-th key
+                // score half of the k-th key; banded lists: the admission threshold the last insertion left (>= that score)
+                lpre[ni] = *(a.kc ? (const uint32_t*)(eff + qloc[ni]) : (const uint32_t*)(lists + qloc[ni] * KCAP + k - 1) + 1);
             }
         }
         // ---- one K-step, software-pipelined by hand: 4*MI steps f = kk*MI + mi of {A-fragment read two steps ahead,
@@ -545,7 +549,20 @@ __global__ __launch_bounds__(512, 2) void lvs_tile_kernel(const LvsTileArgs a) {
                     if (lane < k) newv = mine > ukey ? mine : (prev > ukey ? ukey : prev);
                     __builtin_amdgcn_wave_barrier();
                     if (lane < k) UL[lane] = newv;
-                    const uint32_t ntau = __builtin_amdgcn_readlane((uint32_t)(newv >> 32), k - 1);
+                    uint32_t ntau = __builtin_amdgcn_readlane((uint32_t)(newv >> 32), k - 1);
+                    if (a.kc) {
+                        // Banded list (the certified one-pass search, lvs_flat_search_keys_hi_banded): a row further than the
+                        // query's band below the CURRENT kc-th best can never be needed by the certificate, so the admission
+                        // threshold is max(last slot, kc-th slot - band) - a list of k slots then costs the insertions of a
+                        // list of kc, and slots stay empty unless the band is crowded.  The threshold only ever rises.
+                        const uint32_t nkc = __builtin_amdgcn_readlane((uint32_t)(newv >> 32), a.kc - 1);
+                        if (nkc) {
+                            const float band = a.bscale * __builtin_sqrtf(a.qn[q0 + uq]) + a.bslack;  // uniform: a scalar load
+                            const uint32_t ob = lvs_ord32(lvs_unord32(nkc) - band);
+                            ntau = ob > ntau ? ob : ntau;
+                        }
+                        if (lane == 0) eff[uq] = ntau;  // under the lock, before the unlock store below
+                    }
                     // unlock: the LDS executes one wave's DS instructions in issue order, so a plain (relaxed)
                     // store issued after the slot writes is observed after them - no wait for the writes needed
                     asm volatile("" ::: "memory");
@@ -645,7 +662,7 @@ __global__ __launch_bounds__(512, 2) void lvs_tile_kernel(const LvsTileArgs a) {
         if (!a.no_share && (ti <= 8 || ((ti & 7) == 0) || t + 1 == T)) {  // every tile while the lists fill, then every 8
 #pragma unroll
             for (int ni = 0; ni < 2; ++ni) {
-                const uint32_t lo = (uint32_t)(lists[qloc[ni] * KCAP + k - 1] >> 32);
+                const uint32_t lo = a.kc ? eff[qloc[ni]] : (uint32_t)(lists[qloc[ni] * KCAP + k - 1] >> 32);
                 if (qvalid[ni] && lane < 32 && wm == 0 && lo > gord[ni]) atomicMax(&a.gtau[q0 + qloc[ni]], lo);
             }
         }

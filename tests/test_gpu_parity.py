@@ -552,6 +552,71 @@ def test_one_pass_certified_search_equals_the_plain_search(hip_backend, cmode, q
     assert err <= atol and hard == 0 and recall >= 0.9999
 
 
+@pytest.mark.parametrize("metric,nq,nb,d,k,k1", [(IP, 3000, 120_000, 96, 10, 15), (L2, 1500, 80_000, 64, 5, 10),
+                                                 (IP, 700, 90_000, 128, 20, 28)])
+def test_banded_lists_keep_every_row_inside_the_band(hip_backend, metric, nq, nb, d, k, k1):
+    """lvs_flat_search_keys_hi_banded through the C ABI against the plain k1-deep one-pass lists of the same launch shape:
+    inside the band (one-pass score >= k-th best - band) a banded list IS the plain list, key for key; below it it holds
+    whatever rows were admitted before the band rose past them (never a row that could matter).  With a band wider than the
+    spread it is the plain list.  lvs_certify_topk_banded then certifies exactly the queries whose band was not
+    crowded, and lvs_certify_topk == band 0."""
+    import torch
+
+    be = hip_backend
+    xb = synth.corpus(nb, d, seed=31) * (1.3 if metric == L2 else 1.0)
+    xq, _ = synth.queries(xb, nq, seed=32)
+    xb[5000:5000 + k1 + 4] = xb[77]         # more copies of one row than a list has slots: a query that hits it has a crowded band
+    xq[:40] = xb[77] + 0.01 * synth.corpus(40, d, seed=33)
+    cb, cq = be.pack(xb, SPLIT), be.pack(xq, SPLIT)
+    P = lambda t: 0 if t is None else int(t.data_ptr())
+    need = int(be.lib.lvs_flat_search_workspace_bytes(nq, nb, d, k1, cb.mode, cq.mode))
+    ws = be._workspace(need)
+
+    def banded(scale, slack):
+        keys = torch.empty((nq, k1), dtype=torch.int64, device=be.device)
+        be._c("lvs_flat_search_keys_hi_banded", P(cb.rows), cb.mode, nb, P(cq.rows), cq.mode, nq, d, metric, k1, k, float(scale),
+              float(slack), P(cb.norms), P(cq.norms), 0, None, P(keys), P(ws), int(ws.numel()), be._stream())
+        return keys
+
+    plain = be._search_call("lvs_flat_search_keys_hi", cb, cq, k1, metric, 0)
+    pl = plain.cpu().numpy().view(np.uint64)
+    s_pl, _, e_pl = oracle.unpack_keys(pl)
+    assert not e_pl.any()
+    qn = np.sqrt(cq.norms.cpu().numpy().astype(np.float64))
+    spread = float(np.median(s_pl[:, k - 1] - s_pl[:, k1 - 1]))
+    scale = 0.05 * spread / float(np.median(qn))      # a band of ~5 % of the distance from the k-th to the k1-th score
+    bd = banded(scale, 0.0).cpu().numpy().view(np.uint64)
+    s_bd, _, e_bd = oracle.unpack_keys(bd)
+    filled = (~e_bd).sum(1)
+    assert (filled >= k).all()
+    band = np.float32(scale) * np.sqrt(cq.norms.cpu().numpy())                      # float32, as the kernel evaluates it
+    inside = s_pl >= (s_pl[:, k - 1] - band)[:, None] + 1e-6 * np.abs(s_pl[:, :1])  # rows the band must keep (ulp slack)
+    n_in = inside.sum(1)                              # (a prefix of the plain list: it is sorted)
+    assert (n_in >= k).all() and (n_in <= filled).all()
+    for q in range(nq):
+        # inside the band: the plain list, key for key.  Below it a list may keep rows admitted before the band rose past
+        # them (and miss better ones that came later - nobody needs either); sorted best first, empty slots last
+        assert np.array_equal(bd[q, :n_in[q]], pl[q, :n_in[q]]), q
+        assert (np.diff(bd[q].astype(np.float64)) <= 0).all() and e_bd[q, filled[q]:].all() and not e_bd[q, :filled[q]].any(), q
+    # (the list returned is the MERGE of the slabs' lists, each of which fills its own first k slots before its band means
+    # anything - so the merged list is full again, its tail a mix of rows below the band; what the band saves is insertions)
+    wide = banded(1e6, 0.0).cpu().numpy().view(np.uint64)                          # a band wider than any spread: the plain lists
+    assert np.array_equal(wide, pl)
+    # certificates: band 0 == lvs_certify_topk; banded: open exactly where the band is crowded beyond the list
+    exact = torch.from_numpy(bd.view(np.int64)).to(be.device)
+    approx = exact.clone()
+
+    def certify(name, *extra):
+        idx = torch.empty((nq,), dtype=torch.int64, device=be.device)
+        cnt = torch.zeros((1,), dtype=torch.int64, device=be.device)
+        be._c(name, P(approx), P(exact), P(cq.norms), nq, k1, k, float(scale / 2.05), 0.0, *extra, P(idx), P(cnt), be._stream())
+        return set(idx[:int(cnt.item())].cpu().numpy().tolist())
+
+    open_banded = certify("lvs_certify_topk_banded", 2.02)
+    assert set(range(40)) <= open_banded and len(open_banded) <= 40 + 0.01 * nq       # (approx == exact here: a pure list test)
+    assert certify("lvs_certify_topk_banded", 0.0) == certify("lvs_certify_topk")
+
+
 def test_one_pass_certificate_refuses_rows_that_differ_below_fp16_resolution(hip_backend):
     """Twins with identical hi parts and different lo parts around rank k: the one-pass scores cannot order them, the
     certificate must send those queries to the plain search - results stay exact."""
