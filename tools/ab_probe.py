@@ -1,4 +1,7 @@
 """Same-box A/B of two builds of the library (development aid): python tools/ab_probe.py <path of liblotus_hip*.so>
+(the other build: compile another checkout's lotus_amd/csrc - same ABI version - and copy its library into lotus_amd/ under
+another name, e.g. liblotus_hip_prevtile.so, which `tools/r04_run.sh <tag> ab` alternates with the shipped one; boxes of the
+pool differ by more than most kernel changes, so only runs of one gpurun call compare)
 fp16 join 100 k x 1 M, fp16 / fp32 10 k x 1 M, fp32 join 100 k x 1 M (d = 768, k = 10, IP), ms per call by device events."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
