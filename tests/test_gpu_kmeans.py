@@ -78,9 +78,10 @@ def test_accumulate_is_exact_and_in_row_order(hip_backend, mode):
 
 @pytest.mark.parametrize("mode", [F16, SPLIT])
 def test_accumulate_bucket_sizes_around_the_half_batches(hip_backend, mode):
-    """The sums kernel alternates two half batches of 32 (fp16 rows) / 16 (hi|lo rows) rows with hand-counted waits: buckets
-    of every size around 0 .. 5 half batches (incl. the last bucket of the array, where the row-number prefetch is clamped),
-    d with a partly filled last lane block - bit-identical to in-order float32 sums."""
+    """The sums kernel walks a bucket in batches of 64 (fp16 rows) / 32 (hi|lo rows) rows, the row numbers of the next batch
+    prefetched while one is added, then a row-by-row tail: buckets of every size around 0 .. 3 batches and their halves (incl.
+    the last bucket of the array, whose prefetch ends at the array's end), d with a partly filled last lane block -
+    bit-identical to in-order float32 sums."""
     be = hip_backend
     rng = np.random.default_rng(21)
     H = 32 if mode == F16 else 16
