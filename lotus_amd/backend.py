@@ -353,6 +353,10 @@ class HipBackend:
     CERT_MIN_PAIRS = 1 << 26  # below this many (query, row) pairs the extra launches cost more than the two passes saved
     CERT_MAX_K = 48
     CERT_SPARE_SMALL_K = 5  # spare list slots of the one-pass search for k <= 10 (k1 = k + spare <= 15)
+    # largest k served by the 15-slot lists of the 256-query geometry.  fp32 10 k x 1 M, same box (profiles/r06l_fp32_k12_probe.log):
+    # k = 11: 15.9 ms (0.4 % of the queries open) against 20.5 ms with k + 8 slots on the 128-query geometry; k = 12: 17.0 (3.8 % open)
+    # against 20.6; k = 13: 21.7 (17 % open) against 20.7
+    CERT_MAX_K_SMALL_LISTS = 12
     CERT_BAND_SEARCH = 2.05   # banded lists: rows further than this many error bounds below the k-th one-pass score are not
     CERT_BAND_CERTIFY = 2.02  # listed; the certificate assumes a slightly narrower band (> 2 is what its proof needs)
 
@@ -478,7 +482,9 @@ class HipBackend:
         nq = queries.n
         first_round = k1 is None
         if first_round:
-            k1 = min(15, k + self.CERT_SPARE_SMALL_K) if k <= 10 else min(56, k + 8)
+            # k <= 12 stays on the 256-query geometry (15 slots): banded lists make spare slots cheap, and the 128-query geometry
+            # of deeper lists is 25-45 % slower - a few more open queries for the second round are the smaller price
+            k1 = min(15, k + self.CERT_SPARE_SMALL_K) if k <= 10 else (15 if k <= self.CERT_MAX_K_SMALL_LISTS else min(56, k + 8))
         k1 = min(k1, corpus.n)
         # |s - s_hi| <= |q| |lo_row| + |lo_q| |row| + |lo_q| |lo_row| (Cauchy-Schwarz) with the MEASURED largest lo-part norms
         # E_c, E_q of the two operands (cached per device image; ~0.4 x the worst case 2^-11 |x|, so fewer queries stay open than

@@ -525,6 +525,8 @@ def test_pooled_thresholds_of_shards_keep_the_merged_result_exact(hip_backend, m
 @pytest.mark.parametrize("cmode,qmode,metric,nq,nb,d,k", [
     (SPLIT, SPLIT, IP, 3000, 60_000, 384, 10),   # LOTUS's default: fp32 embeddings on both sides (3 passes -> 1)
     (SPLIT, F16, L2, 2000, 50_000, 200, 5),
+    (SPLIT, SPLIT, IP, 2500, 60_000, 256, 12),   # k = 11, 12 keep the 15-slot lists (three spare slots here)
+    (SPLIT, F16, L2, 1200, 45_000, 96, 13),      # k + 8 = 21 slots: the 128-query geometry
     (F16, SPLIT, IP, 1000, 40_000, 768, 20),     # k1 = 28: the 128-query geometry
     (SPLIT, SPLIT, L2, 300, 30_000, 128, 48),    # largest certified k (56 list slots)
     (SPLIT, SPLIT, IP, 20, 100_000, 256, 10),    # few queries: the one-pass search is the streaming kernel

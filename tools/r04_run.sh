@@ -33,6 +33,7 @@ for w in $what; do
     kmparts) timeout -k 10 600 python tools/km_parts_probe.py > $out/kmparts.log 2>&1; grep -v "^\[" $out/kmparts.log | tail -20 ;;
     bench2) LOTUS_BENCH_REHEARSAL=1 timeout -k 10 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 3 --warmup 1 > $out/bench2.json 2> $out/bench2.err; tail -c 1800 $out/bench2.json; echo; tail -5 $out/bench2.err ;;
     ab) for i in 1 2; do for l in lotus_amd/liblotus_hip.so lotus_amd/liblotus_hip_prevtile.so; do timeout -k 10 300 python tools/ab_probe.py $l 2>&1 | grep "fp16 100k" >> $out/ab.log; done; done; cat $out/ab.log ;;
+    k12) timeout -k 10 200 python tools/fp32_k12_probe.py > $out/k12.log 2>&1; grep "per call" $out/k12.log ;;
     tcall) timeout -k 10 600 python tools/tcall_probe.py > $out/tcall.log 2>&1; cat $out/tcall.log ;;
     pyfix) timeout -k 10 900 python -m pytest tests -m gpu -q -k "$PYK" --timeout 600 --durations=12 -p no:cacheprovider > $out/pytest_fix.log 2>&1; tail -30 $out/pytest_fix.log ;;
     smoke) timeout -k 10 300 python -c 'import __graft_entry__ as g; g.smoke()' > $out/smoke.log 2>&1; tail -3 $out/smoke.log ;;
