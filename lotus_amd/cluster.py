@@ -24,6 +24,18 @@ from . import _capi, _dist
 # the LAST range, so it is the shortest: 10 M x 1 024 x 768, same box, ms per iteration (profiles/r06c_km_parts_probe.log):
 # one range 21.5, 3 / 4 / 6 equal ranges 20.5 / 20.2-20.3 / 20.5, 30 / 30 / 25 / 15 % 19.8
 PARTS_DEFAULT = (0.30, 0.30, 0.25, 0.15)
+
+
+def range_cuts(n: int, fracs) -> list[int]:
+    """Row ranges [cuts[i], cuts[i + 1]) of ``n`` rows in the proportions ``fracs``: cut points on multiples of 4 096 rows (whole
+    tiles of every kernel involved), the last range takes the remainder."""
+    total = float(sum(fracs))
+    acc, cuts = 0.0, [0]
+    for f in list(fracs)[:-1]:
+        acc += float(f) / total
+        cuts.append(max(cuts[-1], min(n, int(n * acc) // 4096 * 4096)))
+    cuts.append(n)
+    return cuts
 SIDE_STREAM_PRIORITY = 0    # of the stream the sums of a range run on
 
 
@@ -182,11 +194,7 @@ def kmeans(x, k: int, niter: int = 20, seed: int = 1234, max_points_per_centroid
         if nparts > 1:
             side = torch.cuda.Stream(device=dev, priority=SIDE_STREAM_PRIORITY)
             side_ws = torch.empty(int(be.lib.lvs_kmeans_accumulate_workspace_bytes(train.n, k)) + 256, dtype=torch.uint8, device=dev)
-            acc, cuts = 0.0, [0]
-            for f in fracs[:-1]:
-                acc += f / sum(fracs)
-                cuts.append(int(train.n * acc) // 4096 * 4096)
-            cuts.append(train.n)
+            cuts = range_cuts(train.n, fracs)
         for it in range(niter):
             if timed:
                 ev = torch.cuda.Event(enable_timing=True)

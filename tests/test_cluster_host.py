@@ -107,3 +107,19 @@ def test_step_by_step_harness_on_the_cpu_double():
     assert km_steps.teacher_forced(be, c) <= 2
     rep = km_steps.free_run(be, c)
     assert rep["iterations_compared"] == 5 and rep["all_flips_are_near_ties"]
+
+
+def test_row_ranges_of_an_iteration_cover_the_rows_in_order():
+    """`cluster.range_cuts`: the ranges an exhaustive k-means iteration hands the rows over in (sums of one range under the
+    search of the next) - consecutive, complete, cut on multiples of 4 096 rows, in the requested proportions."""
+    from lotus_amd import cluster
+
+    for n in (65536 * 4, 2_097_152, 10_000_000, 3_000_001):
+        for fracs in ((0.25,) * 4, cluster.PARTS_DEFAULT, (3, 3, 2.5, 1.5), (1.0,), (0.5, 0.5)):
+            cuts = cluster.range_cuts(n, fracs)
+            assert cuts[0] == 0 and cuts[-1] == n and len(cuts) == len(fracs) + 1
+            assert all(b >= a for a, b in zip(cuts, cuts[1:])) and all(c % 4096 == 0 for c in cuts[1:-1])
+            total = float(sum(fracs))
+            for i, f in enumerate(fracs[:-1]):
+                assert abs((cuts[i + 1] - cuts[i]) - n * f / total) <= 2 * 4096
+    assert abs(sum(cluster.PARTS_DEFAULT) - 1.0) < 1e-9 and min(cluster.PARTS_DEFAULT) == cluster.PARTS_DEFAULT[-1]
