@@ -1,4 +1,5 @@
-"""A host-side MODEL of the banded candidate lists behind the certified one-pass search (lvs_flat_search_keys_hi_banded +
+"""Host-side MODELS of the three rules the exactness of the device path rests on - not the kernels, the RULES they implement -
+run against brute force on random inputs.  First: the banded candidate lists behind the certified one-pass search (lvs_flat_search_keys_hi_banded +
 lvs_certify_topk_banded) - not the kernel, the RULE it implements - run against brute force on random inputs:
 whatever the order the rows arrive in, however they are cut into slabs with lists of their own, and whenever the slabs
 publish their thresholds to each other, a query the certificate passes has its exact top k among the listed candidates."""
@@ -99,3 +100,63 @@ def test_band_zero_is_the_plain_certificate_and_a_wide_band_the_plain_list():
     assert banded_search(hi, slabs, k, k1, 1e9, rng) == plain            # a band wider than any spread admits what a plain list admits
     cand = banded_search(hi, slabs, k, k1, 0.0, rng)                      # no band: only rows above the running k-th best
     assert cand[:k] == plain[:k]
+
+
+# ---- the other two rules the exactness of the device path rests on, modelled the same way ---------------------------------
+@pytest.mark.parametrize("seed", range(4))
+def test_pooled_sample_thresholds_keep_the_merged_top_k_exact(seed):
+    """lvs_flat_search_seed_scores -> all-gather -> lvs_flat_search_keys_seeded: every shard starts from the k-th
+    largest of ALL shards' per-tile sample maxima.  Each of those values is the score of a real row of the searched set, so the
+    threshold never exceeds the global k-th best: shards may return short lists, their merge is the brute-force top k."""
+    rng = np.random.default_rng(100 + seed)
+    for trial in range(60):
+        world = int(rng.integers(1, 9))
+        k = int(rng.integers(1, 12))
+        tile = int(rng.choice([4, 16, 64]))
+        sizes = rng.integers(0, 600, world)                      # uneven shards, some empty or shorter than a tile
+        scores = [rng.normal(0, 1, int(s)) for s in sizes]
+        if rng.random() < 0.3:                                   # duplicated rows across shards: ties AT the threshold
+            for s in scores:
+                if len(s) > 3:
+                    s[:3] = 1.5
+        tiles = int(rng.integers(1, 6))
+        maxima = []
+        for s in scores:                                         # a shard samples its first `tiles` whole tiles
+            for t in range(tiles):
+                blk = s[t * tile:(t + 1) * tile]
+                maxima.append(blk.max() if len(blk) == tile else -np.inf)
+        finite = sorted((m for m in maxima if np.isfinite(m)), reverse=True)
+        thr = finite[k - 1] if len(finite) >= k else -np.inf     # seed_kth_kernel: no threshold without k sampled values
+        parts = [np.sort(s[s >= thr])[::-1][:k] for s in scores]
+        merged = np.sort(np.concatenate(parts))[::-1][:k]
+        truth = np.sort(np.concatenate(scores))[::-1][:k]
+        assert np.array_equal(merged, truth), (seed, trial)
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_two_candidate_certificate_returns_the_exact_nearest_row(seed):
+    """lvs_nearest3 + lvs_nearest3_select + lvs_resolve_pairs: from the one-pass scores the kernel keeps best,
+    second and third; best - second > 2 bound certifies the winner, else best - third > 2 bound leaves exactly two candidates
+    (two exact dot products decide), else the row goes to the exact search.  Whatever the branch, the answer is the exact
+    argmax (any of the equals on an exact tie)."""
+    rng = np.random.default_rng(200 + seed)
+    taken = {"certified": 0, "pair": 0, "open": 0}
+    for trial in range(400):
+        n = int(rng.integers(1, 40))
+        bound = float(rng.choice([1e-3, 3e-2]))
+        exact = rng.normal(0, float(rng.choice([0.02, 0.3])), n)
+        if n > 2 and rng.random() < 0.3:
+            exact[1] = exact[0] * (1 + 1e-9)                     # split twins
+        hi = exact + rng.uniform(-bound, bound, n)
+        order = np.argsort(-hi, kind="stable")
+        best, second, third = (hi[order[i]] if i < n else -np.inf for i in range(3))
+        if best - second > 2 * bound:
+            winner, branch = order[0], "certified"
+        elif best - third > 2 * bound:
+            pair = order[:2]
+            winner, branch = pair[np.argmax(exact[pair])], "pair"
+        else:
+            winner, branch = int(np.argmax(exact)), "open"       # the exact search over every row
+        taken[branch] += 1
+        assert exact[winner] == exact.max(), (seed, trial, branch)
+    assert min(taken.values()) >= 10
