@@ -113,9 +113,41 @@ def csrc_hash() -> str:
     return h.hexdigest()[:16]
 
 
+def self_launch(args) -> int:
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks ourselves - the same
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py ...`
+    command the torchrun form of the contract spells out, on a free port - and hand its exit code back.  Rank r runs on
+    cuda:r over RCCL; rank 0 prints the one JSON line to the inherited stdout."""
+    import socket
+    import subprocess
+
+    rehearsal = os.environ.get("LOTUS_BENCH_REHEARSAL") == "1"
+    if not rehearsal:
+        import torch
+
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            print(f"bench.py: --gpus {args.gpus} but this host shows {have} GPU(s); nothing was measured "
+                  "(LOTUS_BENCH_REHEARSAL=1 runs the N-rank code path on one GPU over gloo - a rehearsal, not a number)",
+                  file=sys.stderr)
+            return 1
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    # torchrun pins OMP_NUM_THREADS=1 per rank when it is unset; rank 0 runs the CPU oracle check - give every rank its share
+    env.setdefault("OMP_NUM_THREADS", str(max(1, min(32, (os.cpu_count() or 1) // args.gpus))))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     args = parse()
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on this driver; before any HIP call
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args))
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -126,10 +158,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
-                             "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
-        args.gpus = world
+        args.gpus = world  # started under torch.distributed.run: the launcher's world size is the truth
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU")
     # LOTUS_BENCH_REHEARSAL=1 (development only, never a reported number): the ranks share cuda:0 and talk over gloo, so that
@@ -160,8 +189,7 @@ def main():
         fut_dedup = pool.submit(benchdata.dedup_rows, benchdata.CFG_DEDUP, args.dedup_rows, d)
     if legs_on and args.kmeans_rows > 0:
         fut_km = pool.submit(benchdata.blobs, benchdata.CFG_KMEANS, args.kmeans_rows, d, args.kmeans_k)
-    xb_h = benchdata.corpus(benchdata.CFG_JOIN, n, d)            # every rank draws the whole corpus: the queries are
-    xq_h, planted_h = benchdata.queries(benchdata.CFG_JOIN, xb_h, nq)  # planted on rows of all shards
+    xb_h, xq_h, planted_h, shm_dir = shared_inputs(np, dist, benchdata, world, rank, n, d, nq)
     gen_s = time.perf_counter() - t_gen0
     per = -(-n // world)
     lo, hi = min(n, rank * per), min(n, (rank + 1) * per)
@@ -273,7 +301,47 @@ def main():
     pool.shutdown(wait=False, cancel_futures=True)
     if world > 1:
         dist.barrier()
+        if rank == 0 and shm_dir:
+            import shutil
+
+            shutil.rmtree(shm_dir, ignore_errors=True)
         dist.destroy_process_group()
+
+
+def shared_inputs(np, dist, benchdata, world, rank, n, d, nq):
+    """-> (corpus [n, d], queries [nq, d], planted [nq], shm dir or None), all host arrays.  The queries are planted on rows
+    of every shard and a block's numpy stream cannot be entered in the middle, so SOMEBODY has to draw the whole corpus: at
+    N > 1 rank 0 draws it once into /dev/shm and the other ranks map it (each touches only its own shard's pages and the
+    queries) instead of N ranks repeating the same host work side by side.  Falls back to every rank drawing when /dev/shm
+    cannot hold it."""
+    def draw():
+        xb = benchdata.corpus(benchdata.CFG_JOIN, n, d)
+        xq, planted = benchdata.queries(benchdata.CFG_JOIN, xb, nq)
+        return xb, xq, planted
+
+    if world == 1:
+        return (*draw(), None)
+    shm = os.path.join("/dev/shm", f"lotus_bench_{os.environ.get('MASTER_PORT', '0')}_{os.getppid()}")
+    flag = [0]
+    got = None
+    if rank == 0:
+        try:
+            os.makedirs(shm, exist_ok=True)
+            if os.statvfs(shm).f_bavail * os.statvfs(shm).f_frsize < (n + nq) * d * 2 * 1.1:
+                raise OSError("no room in /dev/shm")
+            got = draw()
+            for name, a in zip(("xb", "xq", "planted"), got):
+                np.save(os.path.join(shm, name + ".npy"), a)
+            flag[0] = 1
+        except OSError:
+            flag[0] = 0
+    dist.broadcast_object_list(flag, src=0)  # also the barrier the readers wait at
+    if not flag[0]:
+        return (*(got if got is not None else draw()), None)
+    if rank != 0:
+        got = tuple(np.load(os.path.join(shm, name + ".npy"), mmap_mode="r") for name in ("xb", "xq", "planted"))
+        got = (got[0], np.ascontiguousarray(got[1]), np.ascontiguousarray(got[2]))
+    return (*got, shm)
 
 
 def legs_summary(out, legs):

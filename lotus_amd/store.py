@@ -9,8 +9,9 @@ Both are still written, so a directory built here loads in stock LOTUS and vice 
   ``{dir}/rows.f16`` / ``rows.f64`` written next to it, described by ``{dir}/rows.json``;
 * a rank that owns rows ``[lo, hi)`` touches only those pages (per-rank partial load);
 * ``signature()`` = (size, mtime) of the files an index was loaded from, so a directory rewritten by another
-  process is noticed instead of served stale; ``rows.json`` records a CONTENT stamp (size + sampled blocks) of the two
-  reference files it was written with, so a copied directory keeps its row store and a foreign rewrite voids it.
+  process is noticed instead of served stale; ``rows.json`` records size, mtime and a sampled content stamp of the two
+  reference files it was written with: untouched files are accepted at once, a copied directory keeps its row store after
+  ONE exact comparison with the faiss file, and a foreign rewrite - even of a few rows of the same shape - voids it.
 """
 from __future__ import annotations
 
@@ -84,15 +85,77 @@ def _fingerprint(path: str, size: int) -> str:
 
 
 def _file_stamps(index_dir: str) -> dict:
+    """[size, sampled fingerprint, mtime_ns] of the reference's two files."""
     out = {}
     for name in ("index", "vecs"):
         path = os.path.join(index_dir, name)
         try:
-            size = int(os.stat(path).st_size)
-            out[name] = [size, _fingerprint(path, size)]
+            st = os.stat(path)
+            out[name] = [int(st.st_size), _fingerprint(path, int(st.st_size)), int(st.st_mtime_ns)]
         except FileNotFoundError:
-            out[name] = [-1, ""]
+            out[name] = [-1, "", -1]
     return out
+
+
+def _row_store_matches_index(index_dir: str, meta: dict) -> bool:
+    """EXACT check that ``rows.f16|f64`` still holds the embeddings ``{dir}/index`` was written from: the faiss file's code
+    section is the float32 cast of the embeddings (``faiss_vs.py:24``), so the row store cast to float32 must equal it value
+    for value.  One sequential pass over both files, only taken when the cheap (size, mtime) test could not decide."""
+    codes = _mmap_flat_or_none(os.path.join(index_dir, "index"))
+    n, d, tag = int(meta["n"]), int(meta["d"]), meta["dtype"]
+    if codes is None or codes.shape != (n, d):
+        return False
+    path = os.path.join(index_dir, meta["file"])
+    if not os.path.exists(path) or os.path.getsize(path) != n * d * np.dtype(_DTYPES[tag]).itemsize:
+        return False
+    if n == 0:
+        return True
+    rows = np.memmap(path, dtype=_DTYPES[tag], mode="r", shape=(n, d))
+    step = max(1, (64 << 20) // (4 * d))
+    for r0 in range(0, n, step):
+        a = np.asarray(rows[r0:r0 + step]).astype(np.float32)
+        if not np.array_equal(a.view(np.uint32), np.asarray(codes[r0:r0 + step]).view(np.uint32)):
+            return False
+    return True
+
+
+def _stamps_still_valid(index_dir: str, meta: dict) -> bool:
+    """Is the row store ``rows.json`` describes still the one the reference's two files were written with?
+
+    * size of ``index`` / ``vecs`` changed                     -> no;
+    * size and mtime both as recorded                          -> yes (nobody touched the files);
+    * same size, other mtime (``cp -r`` / rsync / a re-index of the same shape by a writer that does not know rows.json):
+      the sampled fingerprint must match - 64 KB of a file of gigabytes cannot rule out a rewrite of a few rows, so it only
+      screens - and then the row store is compared with the faiss file's code section EXACTLY.  A float32 store is the faiss
+      file itself (mapped in place): whatever it holds now is what a search must see, the fingerprint screen is enough.
+    After a full comparison the new mtimes are recorded (best effort) so that the next open is cheap again."""
+    stamps = meta.get("written_with")
+    if stamps is None:
+        return True
+    now = _file_stamps(index_dir)
+    same_time = True
+    for name in ("index", "vecs"):
+        was = list(stamps.get(name, [-2, ""]))
+        if was[0] != now[name][0]:
+            return False
+        same_time &= len(was) >= 3 and was[2] == now[name][2]
+    if same_time:
+        return True
+    if any(list(stamps[name])[1] != now[name][1] for name in ("index", "vecs")):
+        return False
+    if meta.get("file") == "index":
+        return True
+    if not _row_store_matches_index(index_dir, meta):
+        return False
+    try:
+        meta = dict(meta, written_with=now)
+        tmp = os.path.join(index_dir, "rows.json.tmp")
+        with open(tmp, "w") as fp:
+            json.dump(meta, fp)
+        os.replace(tmp, os.path.join(index_dir, "rows.json"))
+    except OSError:
+        pass
+    return True
 
 
 def _mmap_flat_or_none(path: str):
@@ -129,8 +192,7 @@ def _described_rows(index_dir: str):
         return None
     if meta.get("version") != RAW_VERSION or tag not in _DTYPES:
         return None
-    stamps = meta.get("written_with")
-    if stamps is not None and stamps != _file_stamps(index_dir):
+    if not _stamps_still_valid(index_dir, meta):
         return None  # `index` / `vecs` were rewritten by a writer that left this description (and rows.f16|f64) behind
     if meta["file"] == "index":
         rows = _mmap_flat_or_none(os.path.join(index_dir, "index"))

@@ -107,3 +107,32 @@ def test_bench_line_keeps_the_contract_keys_and_fits_the_record():
     assert "frac" in legs["q128"] and "kernel_ms" in legs["q128"] and "note" not in legs["world8_rehearsal"]
     assert legs["kmeans_parity_mode"]["all_flips_are_near_ties"] in (True, False) and "seconds" in legs["kmeans_parity_mode"]
     assert bench.sig(0.123456789) == 0.12346 and bench.sig({"a": [1.0000001, 2]}) == {"a": [1.0, 2]}
+
+
+def test_bench_builds_the_torchrun_command_for_its_own_ranks(monkeypatch):
+    """`python bench.py --gpus 4` without a launcher re-executes itself under torch.distributed.run (one rank per GPU,
+    127.0.0.1, a free port) with the same arguments; under a launcher (WORLD_SIZE set) it does not."""
+    import subprocess
+    import sys
+    import types
+
+    import bench
+
+    seen = {}
+
+    def fake_run(cmd, env=None, **kw):
+        seen["cmd"], seen["env"] = cmd, env
+        return types.SimpleNamespace(returncode=0)
+
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    monkeypatch.setenv("LOTUS_BENCH_REHEARSAL", "1")  # no GPU count check on this CPU-only box
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3", "--warmup", "1"])
+    rc = bench.self_launch(bench.parse())
+    assert rc == 0
+    cmd = seen["cmd"]
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nproc-per-node=4" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert 1024 < int(cmd[cmd.index("--master-port") + 1]) < 65536
+    assert cmd[-6:] == ["--gpus", "4", "--steps", "3", "--warmup", "1"] and cmd[-7].endswith("bench.py")
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" and int(seen["env"]["OMP_NUM_THREADS"]) >= 1

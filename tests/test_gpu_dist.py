@@ -75,3 +75,32 @@ def test_rccl_transport_branch_runs_on_device_tensors():
     assert p.exitcode == 0
     assert shape == (1, 4, 3) and same and on_gpu and direct
     assert s == 35.0 and c == 10.0 and o == 3.5
+
+
+def test_bench_self_launches_its_ranks_and_prints_one_line():
+    """`python bench.py --gpus 2 ...` with no launcher around it (the form of the driver's N = 1 command): bench.py starts its
+    own two ranks under torch.distributed.run, rank 0 prints the one JSON line.  Rehearsal mode (both ranks on cuda:0 over
+    gloo) because this box has one GPU - the code path is the N > 1 path of the real run: shared inputs through /dev/shm,
+    pooled sample thresholds, seeded shard search, key all-gather, merge, max-over-ranks timing, oracle check on rank 0."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, LOTUS_BENCH_REHEARSAL="1")
+    for var in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR"):
+        env.pop(var, None)
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--queries", "4096", "--corpus", "262144", "--check-sample", "128"],
+                       env=env, cwd=root, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 2 and out["unit"] == "queries/s"
+    assert out["roofline"]["bound"] == "mfma" and out["roofline"]["frac"] > 0
+    assert out["recall_at_k"] == 1.0 and out["id_mismatches_outside_near_ties"] == 0
+    assert out["planted_neighbour_at_rank1"] > 0.99
+    assert "REHEARSAL" in out["data"]
+    assert not [f for f in os.listdir("/dev/shm") if f.startswith("lotus_bench_")]

@@ -196,10 +196,53 @@ def test_copied_directory_keeps_its_row_store(tmp_path):
     vs.load_index(d2)
     got = vs.get_vectors_from_index(d2, [7, 9])
     assert got.dtype == np.float16 and np.array_equal(got, a[[7, 9]])
-    # same size, one changed row in the middle of the file: the sampled blocks need not see it, the SIZE + head / tail do not
-    # change either - so a partial in-place edit is only caught when it touches a sampled block; a re-index (every row new) is
+    # the one exact comparison re-stamped the copy: the next open is decided by (size, mtime) alone
+    import json
+
+    with open(os.path.join(d2, "rows.json")) as fp:
+        assert json.load(fp)["written_with"]["index"][2] == os.stat(os.path.join(d2, "index")).st_mtime_ns
     b = synth.corpus(300, 24, seed=4).astype(np.float32)
     with open(os.path.join(d2, "vecs"), "wb") as fp:
         pickle.dump(b, fp)
     faiss_io.write_index_flat(os.path.join(d2, "index"), b, 0)
     assert store.open_stored_rows(d2)[1] == "pickle"
+
+
+def test_same_shape_rewrite_of_a_few_middle_rows_voids_the_row_store(tmp_path):
+    """a re-index by stock FaissVS that keeps n x d and changes only some rows leaves the file sizes and - almost
+    surely - the 16 sampled 4 KB blocks as they were.  The row store must not be served on the strength of 64 KB of samples:
+    untouched files are accepted by (size, mtime); anything else is compared with the faiss file exactly."""
+    n, dim = 20_000, 64  # index file 5 MB: 16 sampled blocks cover 1.3 % of it
+    a = synth.corpus(n, dim, seed=21).astype(np.float16)
+    d = str(tmp_path / "i")
+    vs = HipVS(backend=OracleBackend())
+    vs.index(None, a, d)
+    assert store.open_stored_rows(d)[1] == "mmap"
+    # pick rows whose bytes lie in none of the sampled blocks of `index` (float32 codes from byte 45) or of `vecs` (the fp16
+    # pickle: a header of < 256 bytes, then the matrix)
+    def sampled(name):
+        last = os.path.getsize(os.path.join(d, name)) - store._STAMP_BLOCK
+        return [(last * i // (store._STAMP_BLOCKS - 1), last * i // (store._STAMP_BLOCKS - 1) + store._STAMP_BLOCK)
+                for i in range(store._STAMP_BLOCKS)]
+
+    def clear(r, name, head, item):
+        return not any(lo - item * dim - 256 <= head + r * item * dim < hi + 256 for lo, hi in sampled(name))
+
+    rows = [r for r in range(n // 2 - 200, n // 2 + 200) if clear(r, "index", 45, 4) and clear(r, "vecs", 0, 2)][:5]
+    assert len(rows) == 5
+    b = a.copy()
+    b[rows] = synth.corpus(5, dim, seed=22).astype(np.float16)
+    before = store._file_stamps(d)
+    with open(os.path.join(d, "vecs"), "wb") as fp:  # FaissVS.index (faiss_vs.py:27-30): its two files, same shape and dtype
+        pickle.dump(b, fp)
+    faiss_io.write_index_flat(os.path.join(d, "index"), b.astype(np.float32), 0)
+    after = store._file_stamps(d)
+    for name in ("index", "vecs"):  # sizes and sampled fingerprints did not see the rewrite; only the mtimes moved
+        assert after[name][:2] == before[name][:2] and after[name][2] != before[name][2]
+    stored, how = store.open_stored_rows(d)
+    assert how == "pickle" and np.array_equal(stored, b)
+    dev_rows, how = store.open_device_rows(d)
+    assert how == "index-mmap" and np.array_equal(np.asarray(dev_rows), b.astype(np.float32))
+    vs.load_index(d)
+    assert np.array_equal(vs.get_vectors_from_index(d, rows), b[rows])
+    assert vs(b[rows[2]:rows[2] + 1].astype(np.float32), 1).indices[0, 0] == rows[2]
