@@ -267,6 +267,9 @@ def main():
         details = {"gen_s": gen_s, "hbm_frac_secondary": alg_bytes / (kernel_ms * 1e-3) / 1e9 / PEAK_HBM_GBS}
         n_chk = max(args.check_sample, args.cpu_sample if (world == 1 and not args.no_cpu_baseline) else 0, 1)
         D_h, I_h = D[:n_chk].cpu().numpy(), I[:n_chk].cpu().numpy()
+        chk_rows = check_rows(np, nq, args.check_sample)
+        chk_dev = torch.from_numpy(chk_rows).to(device)
+        D_chk, I_chk = D[chk_dev].cpu().numpy(), I[chk_dev].cpu().numpy()
         checks = []  # CPU-side work deferred until every GPU leg has run
         legs = {}
         if legs_on:
@@ -280,6 +283,7 @@ def main():
                 if fut is not None:          # configs' rows (up to 64 threads on a 16-CPU quota) finish first
                     fut.result()
             t_call_leg(ctx, legs)
+            t_op_leg(ctx, legs)
             if fut_dedup is not None:
                 dedup_leg(ctx, legs, checks, fut_dedup)
             if fut_km is not None:
@@ -287,7 +291,7 @@ def main():
         be.synchronize()
         # ---- CPU side ----
         if args.check_sample > 0:
-            out.update(oracle_check(np, xb_h, xq_h, D_h, I_h, args.check_sample, k))
+            out.update(oracle_check(np, xb_h, xq_h, D_chk, I_chk, chk_rows, k))
         for fn in checks:
             fn()
         if world == 1 and not args.no_cpu_baseline:
@@ -360,6 +364,7 @@ def legs_summary(out, legs):
         "world8_pooled_seeds_ms_per_shard": w8.get("kernel_ms_per_shard"),
         "world8_projected_node_qps": w8.get("projected_node_qps"),
         "t_call_ms": g("t_call_host_to_host", "ms_per_call"), "t_call_qps": g("t_call_host_to_host", "queries_per_s"),
+        "t_op_ms": g("t_op_sem_sim_join_100k_x_1M", "ms_per_call"), "t_op_qps": g("t_op_sem_sim_join_100k_x_1M", "queries_per_s"),
         "cfg4_dedup_5M_mfma_frac": g("range_selfjoin_cfg4"),
         "cfg5_kmeans_iter_ms": g("kmeans_full_iter_10M_x_1024", "ms_per_iteration"),
         "cfg5_kmeans_iter_mfma_frac": g("kmeans_full_iter_10M_x_1024"),
@@ -409,14 +414,23 @@ def _topk_vs_oracle(np, xb_h, xq_h, Dg, Ig, k, metric=0):
             "id_mismatches_outside_near_ties": _near_tie_mismatches(np, Dr, Ir, Ig, k)}
 
 
-def oracle_check(np, xb_h, xq_h, Dg, Ig, sample, k):
+def oracle_check(np, xb_h, xq_h, Dg, Ig, rows, k):
     """The GPU result of the last timed step against the CPU oracle (oracle/flat.py: 4096 x 1024 sgemm blocks + k-best
-    collector with faiss's tie rule) on the first `sample` queries x the WHOLE corpus (the same fp16 values, upcast -
-    SURVEY.md 8(c)).  Runs at every N on rank 0."""
-    sample = min(sample, xq_h.shape[0])
-    res = _topk_vs_oracle(np, xb_h, xq_h[:sample], Dg[:sample], Ig[:sample], k)
-    res["oracle_check_queries"] = sample
+    collector with faiss's tie rule) on the queries `rows` x the WHOLE corpus (the same fp16 values, upcast - SURVEY.md 8(c)).
+    `rows`: the first queries of the batch AND one query of every 256-query tile of the launch, at a position that walks
+    through the tile (tile t: row 256 t + 37 t mod 256) - every workgroup row of the launch, every wave and lane position is
+    sampled, not just the head of the batch.  Dg / Ig hold the GPU rows in that order.  Runs at every N on rank 0."""
+    res = _topk_vs_oracle(np, xb_h, xq_h[rows], Dg, Ig, k)
+    res["oracle_check_queries"] = int(len(rows))
+    res["oracle_check_rows"] = "first rows + one per 256-query tile (row 256 t + 37 t mod 256)"
     return res
+
+
+def check_rows(np, nq, head):
+    """Query rows of the oracle check: the first `head` rows, then one per 256-query tile (stratified, see oracle_check)."""
+    t = np.arange(-(-nq // 256))
+    strat = np.minimum(256 * t + (37 * t) % 256, nq - 1)
+    return np.unique(np.concatenate([np.arange(min(head, nq)), strat]))
 
 
 def _cpu_quota():
@@ -725,6 +739,45 @@ def t_call_leg(ctx, legs):
                                    "same_ids_as_the_timed_step": same,
                                    "note": "HipVS.__call__(numpy fp16 [Q,d]) -> numpy (D, I); PCIe and packing included; "
                                            "median of 5"}
+
+
+def t_op_leg(ctx, legs):
+    """T_op (the third timing boundary): the whole operator, frames in, frame out -
+    `lotus_amd.ops.sem_sim_join(left, right, ...)` = what `df1.sem_sim_join(df2, ...)` (sem_sim_join.py:84-166) does around the
+    search: query vectors from the retriever model, VS.__call__ with the right frame's index labels as ids, the post-filter and
+    the joined frame with its `_scores` column (1 M result rows).  The retriever model hands the precomputed embeddings over
+    (the embedding model itself is outside the path)."""
+    import pandas as pd
+
+    from lotus_amd import ops
+    from lotus_amd.vs import HipVS, _Resident
+
+    np, be, corpus, xq_h, k, d = ctx["np"], ctx["be"], ctx["corpus"], ctx["xq_h"], ctx["k"], ctx["d"]
+
+    class PassRM:  # RM.convert_query_to_query_vector (models/rm.py:77-78) passes ndarrays through; so does this stand-in
+        def convert_query_to_query_vector(self, q):
+            return xq_h
+
+    vs = HipVS(backend=be, storage="fp16")
+    vs._resident["bench"] = _Resident(vecs=None, packed=corpus, n=corpus.n, d=d, lo=0, hi=corpus.n)
+    vs.index_dir = "bench"
+    right = pd.DataFrame({"R": np.arange(corpus.n)})
+    right.attrs["index_dirs"] = {"R": "bench"}
+    left = pd.DataFrame({"L": np.arange(xq_h.shape[0])})
+    run = lambda: ops.sem_sim_join(left, right, "L", "R", k, rm=PassRM(), vs=vs)
+    out = run()
+    ts = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        out = run()
+        ts.append(time.perf_counter() - t0)
+    t_op = sorted(ts)[1]
+    want_I = be.keys_to_result(ctx["keys"][:4096], ctx["_capi"].METRIC_IP)[1].cpu().numpy()
+    got_I = out["R"].to_numpy()[:4096 * k].reshape(4096, k)
+    legs["t_op_sem_sim_join_100k_x_1M"] = {
+        "ms_per_call": t_op * 1e3, "queries_per_s": xq_h.shape[0] / t_op, "result_rows": int(len(out)),
+        "columns": list(out.columns), "same_ids_as_the_timed_step": bool(np.array_equal(want_I, got_I)),
+        "note": "lotus_amd.ops.sem_sim_join(left frame, right frame) -> joined frame, host in / host out; median of 3"}
 
 
 def dedup_leg(ctx, legs, checks, fut):

@@ -30,6 +30,7 @@ def _ptr(t) -> int:
 
 class HipBackend:
     PACK_CHUNK_ROWS = 262144
+    NEAREST3_WS_BUDGET = 2 << 30  # bytes of scratch one lvs_nearest3 call may ask for; more queries go through in chunks
 
     def __init__(self, device=None):
         import torch
@@ -63,9 +64,15 @@ class HipBackend:
             _capi.check(getattr(self.lib, name)(*args), name)
 
     def _workspace(self, nbytes: int):
-        if self._ws is None or self._ws.numel() < nbytes:
-            self._ws = self.torch.empty(max(nbytes, 1 << 20), dtype=self.torch.uint8, device=self.device)
-        return self._ws
+        """The scratch buffer of the CURRENT stream (one per stream: launches queued on a side stream - the k-means sums and
+        certificates of one row range under the assignment search of the next - never share scratch memory with the main one)."""
+        if self._ws is None:
+            self._ws = {}
+        key = self._stream()
+        ws = self._ws.get(key)
+        if ws is None or ws.numel() < nbytes:
+            ws = self._ws[key] = self.torch.empty(max(nbytes, 1 << 20), dtype=self.torch.uint8, device=self.device)
+        return ws
 
     def synchronize(self) -> None:
         self.torch.cuda.synchronize(self.device)
@@ -547,7 +554,10 @@ class HipBackend:
 
     def nearest(self, corpus: PackedRows, queries: PackedRows, metric: int, id_offset: int = 0, stats: dict | None = None,
                 exact_scores: bool = True, corpus_stats=None, bounds=None):
-        """Nearest corpus row of every query (k = 1) -> int64 key tensor [nq, 1], same winner as ``search_keys(.., 1, ..)``.
+        """Nearest corpus row of every query (k = 1) -> int64 key tensor [nq, 1], same winner as ``search_keys(.., 1, ..)``
+        (two rows whose exact scores agree to within float32 rounding may come out in either order: a certified winner needs no
+        second look, a PAIR is settled by ``lvs_resolve_pairs``' scalar float32 dot products, an OPEN query by the multi-segment
+        MFMA search - three summation orders; ``stats`` counts ``pairs`` and ``open`` separately, ``uncertified`` is their sum).
 
         fp32-accurate operands (fp16 hi|lo rows) cost two or three MFMA passes in the exact search.  Here ONE pass over
         the hi parts (``lvs_nearest_hi``) gives every query a winner and its margin over the runner-up; the true score
@@ -581,16 +591,25 @@ class HipBackend:
         # lvs_nearest_hi tags every running score in its low six mantissa bits (relative perturbation < 2^-17 of u = q.y or
         # 2 q.y - |y|^2, for the winner and for the runner-up): the 2^-16 terms.  |lo_q| <= 2^-11 |q| + sqrt(d) 2^-25: the
         # second term covers components in fp16's subnormal range.
-        dpad = int(corpus.rows.shape[1]) // (2 if corpus.mode == _capi.PACK_SPLIT else 1)
-        qsplit = 1.0 if queries.mode == _capi.PACK_SPLIT else 0.0
-        ip = metric == _capi.METRIC_IP
-        c = 2.0 if ip else 4.0
-        coef = [c, c * ((2.0 ** -11) * qsplit + 8e-6) + 2.0 ** -16 * (1.0 if ip else 2.0),
-                1e-6 * 2.0 ** (corpus.exp + queries.exp), qsplit * c * (dpad ** 0.5) * 2.0 ** -25,
-                1e-6 + (0.0 if ip else 2.0 ** -16)]
+        coef, dpad = self._nearest_coef(corpus, queries, metric)
         if corpus.n <= _capi.NEAREST3_MAX_ROWS:
-            # a small corpus (k-means centroids): queries streaming past resident corpus tiles + the two-candidate certificate
-            return self._nearest3(corpus, queries, metric, id_offset, stats, exact_scores, corpus_stats, bounds, coef, dpad, plain)
+            # a small corpus (k-means centroids): queries streaming past resident corpus tiles + the two-candidate certificate.
+            # Its scratch is 20 B per (corpus tile, query): the queries go through in chunks that keep it below a fixed budget
+            # (10 M rows x 16 384 centroids would ask for 12.8 GB in one call - ADVICE r04); results are per query, so
+            # chunking changes nothing
+            per_q = max(1, int(self.lib.lvs_nearest3_workspace_bytes(1 << 20, corpus.n, corpus.d)) >> 20)
+            step = max(1 << 16, (self.NEAREST3_WS_BUDGET // per_q) >> 16 << 16)
+            if nq <= step:
+                return self._nearest3(corpus, queries, metric, id_offset, stats, exact_scores, corpus_stats, bounds, coef, dpad, plain)
+            for q0 in range(0, nq, step):
+                q1 = min(nq, q0 + step)
+                bsub = bounds
+                if bounds is not None:
+                    pos = bounds[3][q0:q1] if bounds[3] is not None else torch.arange(q0, q1, dtype=torch.int64, device=self.device)
+                    bsub = (bounds[0], bounds[1], bounds[2], pos)
+                keys[q0:q1] = self._nearest3(corpus, self.slice_rows(queries, q0, q1), metric, id_offset, stats, exact_scores,
+                                             corpus_stats, bsub, coef, dpad, plain)
+            return keys
         if corpus_stats is None:
             R = float(corpus.norms.max().sqrt().item())
             E = self.lo_norm_max(corpus)
@@ -642,12 +661,30 @@ class HipBackend:
             stats["queries"] = stats.get("queries", 0) + nq
         return keys
 
+    @staticmethod
+    def _nearest_coef(corpus, queries, metric):
+        """-> (the five coefficients of the one-pass error bound - see the comment in ``nearest`` -, dpad)."""
+        dpad = int(corpus.rows.shape[1]) // (2 if corpus.mode == _capi.PACK_SPLIT else 1)
+        qsplit = 1.0 if queries.mode == _capi.PACK_SPLIT else 0.0
+        ip = metric == _capi.METRIC_IP
+        c = 2.0 if ip else 4.0
+        coef = [c, c * ((2.0 ** -11) * qsplit + 8e-6) + 2.0 ** -16 * (1.0 if ip else 2.0),
+                1e-6 * 2.0 ** (corpus.exp + queries.exp), qsplit * c * (dpad ** 0.5) * 2.0 ** -25,
+                1e-6 + (0.0 if ip else 2.0 ** -16)]
+        return coef, dpad
+
     def _nearest3(self, corpus, queries, metric, id_offset, stats, exact_scores, corpus_stats, bounds, coef, dpad, plain):
         """``nearest`` for a corpus of at most 16 384 rows (``lvs_nearest3``): the one-pass search also returns the runner-up's
         id and the THIRD score, so a query whose best-second margin is inside the error bound but whose best-third margin is
         not has only two possible winners - two exact dot products (``lvs_resolve_pairs``) decide it instead of an exact
         search over every row; only queries with three or more rows inside the bound take that search.  The three-way split
         depends on a query's own scores and the corpus alone, never on which other queries share the call."""
+        h = self._nearest3_begin(corpus, queries, metric, id_offset, exact_scores, corpus_stats, bounds, coef, dpad, plain)
+        return self._nearest3_finish(h, stats)
+
+    def _nearest3_begin(self, corpus, queries, metric, id_offset, exact_scores, corpus_stats, bounds, coef, dpad, plain):
+        """Launches only: the one-pass search and the three-way split; nothing is read back.  -> handle for ``_nearest3_finish``
+        (which may run on another stream once these launches are done - ``nearest_begin`` / ``nearest_finish``)."""
         torch = self.torch
         nq = queries.n
         if corpus_stats is None:  # (largest |row|^2, largest |lo part|^2) of the corpus, left on the device
@@ -676,12 +713,25 @@ class HipBackend:
             self._c("lvs_kmeans_bounds_set", _ptr(keys), 1, _ptr(sec), _ptr(queries.norms), _ptr(b_pos), nq,
                     _ptr(corpus_stats), ctypes.addressof(coef5), int(id_offset), _ptr(b_assign), _ptr(b_ub), _ptr(b_lb),
                     self._stream())
+        return dict(corpus=corpus, queries=queries, metric=metric, id_offset=id_offset, exact_scores=exact_scores,
+                    corpus_stats=corpus_stats, bounds=bounds, coef5=coef5, plain=plain, keys=keys, keys2=keys2, sec=sec,
+                    third=third, pair_idx=pair_idx, open_idx=open_idx, counts=counts)
+
+    def _nearest3_finish(self, h, stats):
+        """The call's one host round trip (how many queries are pairs / open) and what follows from it: two exact dot products
+        for the pairs, the exact search for the open queries.  -> keys [nq, 1]."""
+        corpus, queries, metric, id_offset = h["corpus"], h["queries"], h["metric"], h["id_offset"]
+        corpus_stats, bounds, coef5, plain = h["corpus_stats"], h["bounds"], h["coef5"], h["plain"]
+        keys, keys2, pair_idx, open_idx, counts = h["keys"], h["keys2"], h["pair_idx"], h["open_idx"], h["counts"]
+        nq = queries.n
+        if bounds is not None:
+            b_assign, b_ub, b_lb, b_pos = bounds
         n_pair, n_open = (int(v) for v in counts.tolist())  # the call's one host round trip
         psel = pair_idx[:n_pair]
         # the one-pass keys of the rows decided below, as lvs_kmeans_bounds_fix needs them (taken before any exact score goes in)
         approx_pair = keys[psel].contiguous() if (bounds is not None and n_pair) else None
         approx_open = keys[open_idx[:n_open]].contiguous() if (bounds is not None and n_open) else None
-        if exact_scores:
+        if h["exact_scores"]:
             self._c("lvs_rescore_keys", _ptr(corpus.rows), corpus.mode, _ptr(queries.rows), queries.mode, nq, corpus.d,
                     metric, _ptr(corpus.norms), _ptr(queries.norms), int(id_offset), 1, _ptr(keys), self._stream())
         exact2 = (ctypes.c_float * 2)(8e-6, 4e-6)  # float32 rounding of an exact distance, see nearest()
@@ -707,8 +757,31 @@ class HipBackend:
         if stats is not None:
             stats["uncertified"] = stats.get("uncertified", 0) + n_open + n_pair
             stats["pairs"] = stats.get("pairs", 0) + n_pair
+            stats["open"] = stats.get("open", 0) + n_open
             stats["queries"] = stats.get("queries", 0) + nq
         return keys
+
+    def nearest_begin(self, corpus: PackedRows, queries: PackedRows, metric: int, id_offset: int = 0, exact_scores: bool = True,
+                      corpus_stats=None):
+        """``nearest`` in two halves, for callers that keep the launch stream busy: ``nearest_begin`` queues the one-pass search and
+        the certificate's three-way split and returns at once (no host round trip); ``nearest_finish(handle)`` - on this or on
+        another stream that waits for an event recorded after ``nearest_begin`` - reads the two counts and queues the exact work
+        for the uncertified queries.  Same launches, same arithmetic, same keys as ``nearest``.  Keep the handle alive until the
+        stream ``nearest_finish`` ran on has been joined (its tensors were allocated on the stream of ``nearest_begin``)."""
+        small = corpus.n <= _capi.NEAREST3_MAX_ROWS and not (corpus.mode == _capi.PACK_F16 and queries.mode == _capi.PACK_F16)
+        if not small or queries.n == 0 or corpus.n == 0 or corpus.d != queries.d:
+            return {"keys_now": self.nearest(corpus, queries, metric, id_offset=id_offset, exact_scores=exact_scores,
+                                             corpus_stats=corpus_stats), "queries": queries}
+        coef, dpad = self._nearest_coef(corpus, queries, metric)
+        return self._nearest3_begin(corpus, queries, metric, id_offset, exact_scores, corpus_stats, None, coef, dpad,
+                                    dict(id_offset=id_offset, one_pass=False))
+
+    def nearest_finish(self, handle, stats: dict | None = None):
+        if "keys_now" in handle:
+            if stats is not None:
+                stats["queries"] = stats.get("queries", 0) + handle["queries"].n
+            return handle["keys_now"]
+        return self._nearest3_finish(handle, stats)
 
     def kmeans_centroid_shift(self, c_old, c_new):
         """-> (delta float32 [k], top2 float32 [3]): how far every centroid moved, the largest and second largest shift."""

@@ -37,6 +37,9 @@ def range_cuts(n: int, fracs) -> list[int]:
     cuts.append(n)
     return cuts
 SIDE_STREAM_PRIORITY = 0    # of the stream the sums of a range run on
+# the certificate's tail of a range (count read-back, pair dot products, exact search of the open rows) also runs on the side
+# stream, under the next range's search - the main stream then goes from one assignment launch straight to the next
+PIPELINE_CERTIFICATES = True
 
 
 @dataclass
@@ -191,6 +194,7 @@ def kmeans(x, k: int, niter: int = 20, seed: int = 1234, max_points_per_centroid
         fracs = [1.0 / int(parts)] * int(parts) if isinstance(parts, int) else [float(f) for f in parts]
         can_overlap = not use_bounds and hasattr(be, "kmeans_accumulate_keys_into") and dev.type == "cuda"
         nparts = len(fracs) if (can_overlap and min(fracs) * train.n >= 65536) else 1
+        pipelined = nparts > 1 and PIPELINE_CERTIFICATES and hasattr(be, "nearest_begin")
         if nparts > 1:
             side = torch.cuda.Stream(device=dev, priority=SIDE_STREAM_PRIORITY)
             side_ws = torch.empty(int(be.lib.lvs_kmeans_accumulate_workspace_bytes(train.n, k)) + 256, dtype=torch.uint8, device=dev)
@@ -205,9 +209,31 @@ def kmeans(x, k: int, niter: int = 20, seed: int = 1234, max_points_per_centroid
                 main = torch.cuda.current_stream(dev)
                 sums = torch.zeros((k, d), dtype=torch.float32, device=dev)
                 counts = torch.zeros((k,), dtype=torch.float32, device=dev)
-                held, last = [], None
+                held, kparts, last = [], [], None
+
+                def settle(sub, handle, searched_ev):
+                    # everything of a range that follows its one-pass search - the host's read of the certificate's two counts,
+                    # the exact dot products of the pairs, the exact search of the open rows, the in-row-order sums - on the
+                    # side stream, while the main stream already runs the next range's search
+                    nonlocal last
+                    with torch.cuda.stream(side):
+                        side.wait_event(searched_ev)
+                        kp = be.nearest_finish(handle, stats=stats)
+                        be.kmeans_accumulate_keys_into(sub, kp, k, sums, counts, workspace=side_ws)
+                        last = side.record_event()
+                    kparts.append(kp)
+
+                pending = None
                 for i in range(nparts):
                     sub = be.slice_rows(train, cuts[i], cuts[i + 1])
+                    if pipelined:
+                        handle = be.nearest_begin(cpk, sub, _capi.METRIC_L2, exact_scores=False, corpus_stats=cstats)
+                        ev = main.record_event()
+                        held.append((sub, handle))  # alive until the side stream is done with them (the wait below)
+                        if pending is not None:
+                            settle(*pending)  # range i - 1 settles while range i's search (already queued) runs
+                        pending = (sub, handle, ev)
+                        continue
                     kp = be.nearest(cpk, sub, _capi.METRIC_L2, exact_scores=False, corpus_stats=cstats, stats=stats)
                     searched_ev = main.record_event()
                     with torch.cuda.stream(side):
@@ -215,10 +241,13 @@ def kmeans(x, k: int, niter: int = 20, seed: int = 1234, max_points_per_centroid
                         be.kmeans_accumulate_keys_into(sub, kp, k, sums, counts, workspace=side_ws)
                         last = side.record_event()
                     held.append(kp)  # alive until the side stream is done with it (the wait below)
+                    kparts.append(kp)
+                if pending is not None:
+                    settle(*pending)
                 main.wait_event(last)
                 if trace is not None:
-                    trace.append({"centroids": centroids.clone(), "keys": torch.cat(held)})
-                del held
+                    trace.append({"centroids": centroids.clone(), "keys": torch.cat(kparts)})
+                del held, kparts, pending
             elif not use_bounds:
                 keys = be.nearest(cpk, train, _capi.METRIC_L2, exact_scores=False, corpus_stats=cstats, stats=stats)  # ids only ...
             else:

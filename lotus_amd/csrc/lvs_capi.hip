@@ -1283,11 +1283,11 @@ static int32_t flat_search_impl(const void* xb, int32_t xb_pack, int64_t nb, con
             // rows themselves are scanned again with the rest.
             int64_t sample = nb / 8 / 1024 * 1024;
             if (sample > LVS_STREAM_SEED_ROWS) sample = LVS_STREAM_SEED_ROWS;
-            if (ext_seeds && ext_rows >= k) {  // the caller's pooled sample scores
-                hipLaunchKernelGGL(seed_kth_kernel, dim3((unsigned)lvs_ceil_div(nq, 4)), dim3(256), 0, st, ext_seeds,
-                                   (int)ext_rows, (long long)nq, k, gtau);
-                LVS_HIP_CHECK(hipGetLastError());
-            } else if (nq >= lvs_tune("LVS_STREAM_SEED_MINQ", 2) && sample >= 4096 && lvs_tune("LVS_STREAM_SEED", 1) != 0) {
+            // A caller's pooled sample scores (ext_seeds) are NOT used here: they come from the tile kernel's SEED mode, whose
+            // accumulation order differs from this kernel's, and "the k-th largest of a subset is a lower bound" is only exact
+            // when the threshold and the scan see bit-identical scores - one ulp the wrong way could reject a true top-k row on
+            // its own shard.  This path seeds itself, with its own arithmetic.
+            if (nq >= lvs_tune("LVS_STREAM_SEED_MINQ", 2) && sample >= 4096 && lvs_tune("LVS_STREAM_SEED", 1) != 0) {
                 float* seeds = (float*)((char*)partial + lvs_stream_parts_bytes(nq, k));  // [ranges][nq]
                 LvsStreamArgs ss = sa;
                 ss.nb = sample;
