@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define LVS_ABI_VERSION 5 /* 2: pack modes in lvs_flat_search_workspace_bytes, lvs_build_flags, k-means device update;
+#define LVS_ABI_VERSION 6 /* 2: pack modes in lvs_flat_search_workspace_bytes, lvs_build_flags, k-means device update;
                              3: k-means iteration entirely on the device (objective, split, repack, accumulate from keys),
                                 lvs_pack_rows_checked (validation + power-of-two scale), lvs_absmax, lvs_margin_select_stats;
                                 scale exponents in lvs_unpack_rows / lvs_keys_to_result / lvs_scores / lvs_range_join;
@@ -37,7 +37,9 @@ extern "C" {
                                 lvs_flat_search_keys_seeded); query-streaming nearest-row search with a two-candidate
                                 certificate (lvs_nearest3 / _select / lvs_resolve_pairs);
                              5: banded candidate lists for the certified one-pass search (lvs_flat_search_keys_hi_banded,
-                                lvs_certify_topk_banded) */
+                                lvs_certify_topk_banded);
+                             6: the row-sharded search with its exchange steps inside the library (lvs_search_sharded with a
+                                caller-supplied all-gather, lvs_search_sharded_rccl on an ncclComm_t, lvs_rccl_available / _bind) */
 
 #define LVS_OK 0
 #define LVS_EINVAL (-1)   /* bad argument */
@@ -189,6 +191,36 @@ int32_t lvs_certify_topk_banded(const uint64_t* approx_keys, const uint64_t* exa
  * Any nparts >= 1 and k <= LVS_MAX_K (long lists are folded in rounds of at most 4096 keys per query). */
 int32_t lvs_merge_keys(const uint64_t* parts, int32_t nparts, int64_t nq, int32_t k, uint64_t* out_keys,
                        void* stream);
+/* ---- the row-sharded search with its exchange steps inside the library (one rank = one GPU = one caller; the split of
+ * sem_sim_join.py:132-134 over the GPUs of a node).  What it runs, on `stream`, never synchronising:
+ *   [seed_tiles > 0, fp16 rows, k <= 56, nranks > 1]  lvs_flat_search_seed_scores -> all-gather of the [tiles][nq] blocks
+ *   lvs_flat_search_keys_seeded(id_offset = global id of this shard's row 0)       -> all-gather of the [nq][k] key lists
+ *   lvs_merge_keys                                                                 -> out_keys [nq][k], identical on every rank
+ * Every rank must pass the same nq, d, k, metric, pack modes and seed_tiles (= lvs_flat_search_seed_tiles(nq, NOMINAL shard
+ * rows, k), or 0 for no pooled thresholds); nb_local may differ per rank and may be 0 (an empty shard contributes empty lists).
+ * Equal to the single-launch search of the concatenated shards key for key (keys are a total order). ---- */
+/* the all-gather the library calls: `send` [bytes_per_rank] of this rank -> `recv` [nranks][bytes_per_rank] in rank order,
+ * device pointers, enqueued on `stream` (or finished before returning); 0 on success */
+typedef int32_t (*lvs_all_gather_fn)(void* ctx, const void* send, void* recv, int64_t bytes_per_rank, void* stream);
+int64_t lvs_search_sharded_workspace_bytes(int32_t nranks, int64_t nq, int64_t nb_local, int32_t d, int32_t k, int32_t xb_pack,
+                                           int32_t xq_pack, int32_t seed_tiles);
+int32_t lvs_search_sharded(lvs_all_gather_fn all_gather, void* all_gather_ctx, int32_t nranks, const void* xb, int32_t xb_pack,
+                           int64_t nb_local, const void* xq, int32_t xq_pack, int64_t nq, int32_t d, int32_t metric, int32_t k,
+                           const float* xb_norms_sq, const float* xq_norms_sq, int64_t id_offset, int32_t seed_tiles,
+                           uint64_t* out_keys, void* workspace, int64_t workspace_bytes, void* stream);
+/* The same with RCCL as the transport: nccl_comm is the caller's ncclComm_t over the ranks that hold the shards (its size is
+ * the number of shards, its rank order the shard order); the two exchanges are ncclAllGather calls on `stream`.  librccl.so.1
+ * is resolved at run time, so this library loads and every other entry point works on a host without RCCL: first the
+ * ncclAllGather the process already exposes (a host linked against librccl), then dlopen of librccl.so.1 / librccl.so.
+ * lvs_rccl_available() = 1 when it resolved.  The communicator must come from THAT copy of RCCL; a process that holds
+ * several (PyTorch wheels bundle their own) names the one its communicator belongs to with lvs_rccl_bind (the addresses of
+ * its ncclAllGather, ncclCommCount and - optionally - ncclGetErrorString; NULL, NULL, NULL unbinds). */
+int32_t lvs_rccl_available(void);
+int32_t lvs_rccl_bind(void* nccl_all_gather, void* nccl_comm_count, void* nccl_get_error_string);
+int32_t lvs_search_sharded_rccl(void* nccl_comm, const void* xb, int32_t xb_pack, int64_t nb_local, const void* xq,
+                                int32_t xq_pack, int64_t nq, int32_t d, int32_t metric, int32_t k, const float* xb_norms_sq,
+                                const float* xq_norms_sq, int64_t id_offset, int32_t seed_tiles, uint64_t* out_keys,
+                                void* workspace, int64_t workspace_bytes, void* stream);
 /* keys -> faiss-shaped result (faiss_vs.py:67,75 return values): D float32 [nq][k], I int64 [nq][k];
  * empty slots become I = -1, D = -FLT_MAX (IP) / +FLT_MAX (L2).  id_map (nullable): I = id_map[id]
  * (the sub-index -> global id remap of faiss_vs.py:71-72).  score_exp: D is multiplied by 2^-score_exp (the sum of the two

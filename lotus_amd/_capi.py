@@ -18,7 +18,7 @@ METRIC_IP, METRIC_L2 = 0, 1
 PACK_F16, PACK_SPLIT = 0, 1
 MAX_K = 2048
 NEAREST3_MAX_ROWS = 16384
-ABI_VERSION = 5
+ABI_VERSION = 6
 BUILD_TUNING, BUILD_COUNT_EVENTS = 1, 2
 PACK_FLAG_NONFINITE, PACK_FLAG_RANGE = 1, 2
 
@@ -46,6 +46,13 @@ SIGNATURES = {
     "lvs_flat_search_keys_seeded": (_i32, [_vp, _i32, _i64, _vp, _i32, _i64, _i32, _i32, _i32, _vp, _vp, _i64, _vp, _vp, _i32,
                                            _vp, _vp, _i64, _vp]),
     "lvs_merge_keys": (_i32, [_vp, _i32, _i64, _i32, _vp, _vp]),
+    "lvs_search_sharded_workspace_bytes": (_i64, [_i32, _i64, _i64, _i32, _i32, _i32, _i32, _i32]),
+    "lvs_search_sharded": (_i32, [_vp, _vp, _i32, _vp, _i32, _i64, _vp, _i32, _i64, _i32, _i32, _i32, _vp, _vp, _i64, _i32, _vp,
+                                  _vp, _i64, _vp]),
+    "lvs_rccl_available": (_i32, []),
+    "lvs_rccl_bind": (_i32, [_vp, _vp, _vp]),
+    "lvs_search_sharded_rccl": (_i32, [_vp, _vp, _i32, _i64, _vp, _i32, _i64, _i32, _i32, _i32, _vp, _vp, _i64, _i32, _vp, _vp,
+                                       _i64, _vp]),
     "lvs_keys_to_result": (_i32, [_vp, _i64, _i32, _i32, _vp, _i32, _vp, _vp, _vp]),
     "lvs_scores": (_i32, [_vp, _i32, _i64, _vp, _i32, _i64, _i32, _i32, _vp, _vp, _i32, _vp, _i64, _vp]),
     "lvs_sort_rows_workspace_bytes": (_i64, [_i64, _i64]),

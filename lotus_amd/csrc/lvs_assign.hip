@@ -63,6 +63,7 @@ __device__ inline void top3_insert(float v, float& b, float& s, float& t) {
     b = max_nc(b, v);
 }
 
+template <bool SKEW>
 __global__ __launch_bounds__(512, 2) void lvs_assign_kernel(const AssignArgs a) {
     constexpr int MI = 4, QG = 4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -167,29 +168,10 @@ __global__ __launch_bounds__(512, 2) void lvs_assign_kernel(const AssignArgs a) 
     int ks = 0, ti = 0;
     if (wave >= 4) __builtin_amdgcn_s_setprio(1);
     const int holder = wm * 2 + (lane >> 5);
-    for (int t = 0; t < T; ++t) {
-        const int buf = t & 1;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        const char* sb = smem + buf * A_STAGE;
-        char* n_base = smem + (buf ^ 1) * A_STAGE;
-        if (t + 1 < T) {
-            if (++n_r == nkd) {
-                n_r = 0;
-                ++n_tile;
-                set_q_offsets(tile0 + n_tile);
-            }
-        }
-        const char* c_sbase = c_tile + (long long)n_r * BK * 2;
-        const char* q_sbase = (const char*)xq + ((long long)(tile0 + n_tile) * AQ * ldq + (long long)n_r * BK) * 2;
-        lvs_kstep::run<MI, QG>(sb, n_base, c_sbase, q_sbase, c_loff, q_loff, wave, a_base, b_base, foff, acc);
-        if (++ks < nkd) continue;
-        ks = 0;
-        // ======================== tile epilogue: (corpus tile ct) x (query tile tile0 + ti) ========================
-        const long long q0 = (long long)(tile0 + ti) * AQ;
-        ++ti;
-        float qn_v = 0.f;
-        if (tid < AQ && l2) qn_v = a.qn[q0 + tid < a.nq ? q0 + tid : a.nq - 1];  // used after the barrier below
+
+    // tile epilogue, first half (every wave): fold the 128 scores a lane holds into (best, second, third) per query block -
+    // four VALU operations per score -, start the accumulators afresh, leave the partial triples in LDS
+    auto fold_and_publish = [&]() {
         float bu[2] = {-INFINITY, -INFINITY}, su[2] = {-INFINITY, -INFINITY}, tu[2] = {-INFINITY, -INFINITY};
         lvs_kstep::static_for<MI>([&](auto mic) {
             constexpr int mi = decltype(mic)::value;
@@ -209,8 +191,9 @@ __global__ __launch_bounds__(512, 2) void lvs_assign_kernel(const AssignArgs a) 
             p[1] = su[ni];
             p[2] = tu[ni];
         }
-        __syncthreads();
-        // the next write of `part` is at least one K-step barrier away: no second barrier needed
+    };
+    // second half (256 threads, after a barrier): combine the four partial holders of a query, decode ids, write out
+    auto decode = [&](long long q0, float qn_v) {
         if (tid < AQ && q0 + tid < a.nq) {
             const float* p = part + tid * 12;
             float B = -INFINITY, S = -INFINITY, Tt = -INFINITY;
@@ -241,6 +224,64 @@ __global__ __launch_bounds__(512, 2) void lvs_assign_kernel(const AssignArgs a) 
             a.out2[o] = k2;
             a.out3[o] = score_of(Tt);
         }
+    };
+    // SKEW (tiles of three or more K-steps): the two waves of a SIMD fold at DIFFERENT moments, so that one wave's VALU work
+    // runs beside the other's MFMAs instead of both queueing at the one VALU while the matrix pipe idles.  Waves 4-7 (the
+    // half with issue priority) fold right after the tile's last K-step, as before; waves 0-3 pass the next K-step's barrier
+    // first and fold at the START of that K-step, while waves 4-7 already issue its MFMAs.  The partial triples of a tile are
+    // therefore complete one barrier later, and the decode runs after the barrier that follows (two K-step barriers after
+    // the tile's end; the next tile's first triple is written no earlier than the barrier after that).  Same scores, same
+    // folds, same decode: bit-identical output.
+    const bool late = SKEW && wave < 4;
+    bool fold_due = false;
+    int dec_wait = 0;
+    long long dec_q0 = 0;
+    float dec_qn = 0.f;
+    for (int t = 0; t < T; ++t) {
+        const int buf = t & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (SKEW && dec_wait && --dec_wait == 0) decode(dec_q0, dec_qn);
+        const char* sb = smem + buf * A_STAGE;
+        char* n_base = smem + (buf ^ 1) * A_STAGE;
+        if (t + 1 < T) {
+            if (++n_r == nkd) {
+                n_r = 0;
+                ++n_tile;
+                set_q_offsets(tile0 + n_tile);
+            }
+        }
+        const char* c_sbase = c_tile + (long long)n_r * BK * 2;
+        const char* q_sbase = (const char*)xq + ((long long)(tile0 + n_tile) * AQ * ldq + (long long)n_r * BK) * 2;
+        if (late && fold_due) {
+            fold_and_publish();
+            fold_due = false;
+        }
+        lvs_kstep::run<MI, QG>(sb, n_base, c_sbase, q_sbase, c_loff, q_loff, wave, a_base, b_base, foff, acc);
+        if (++ks < nkd) continue;
+        ks = 0;
+        // ======================== tile epilogue: (corpus tile ct) x (query tile tile0 + ti) ========================
+        const long long q0 = (long long)(tile0 + ti) * AQ;
+        ++ti;
+        float qn_v = 0.f;
+        if (tid < AQ && l2) qn_v = a.qn[q0 + tid < a.nq ? q0 + tid : a.nq - 1];  // used after the barrier(s) below
+        if (!SKEW) {
+            fold_and_publish();
+            __syncthreads();
+            // the next write of `part` is at least one K-step barrier away: no second barrier needed
+            decode(q0, qn_v);
+        } else {
+            if (late) fold_due = true;
+            else fold_and_publish();
+            dec_wait = 2;
+            dec_q0 = q0;
+            dec_qn = qn_v;
+        }
+    }
+    if (SKEW) {  // the last tile of the slab
+        if (late && fold_due) fold_and_publish();
+        __syncthreads();
+        if (dec_wait) decode(dec_q0, dec_qn);
     }
 }
 
@@ -473,12 +514,16 @@ extern "C" int32_t lvs_nearest3(const void* xb, int32_t xb_pack, int64_t nb, con
     int dev = 0;
     LVS_HIP_CHECK(hipGetDevice(&dev));
     if (!attr.done(dev, (size_t)A_LDS)) {
-        LVS_HIP_CHECK(hipFuncSetAttribute((const void*)lvs_assign_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, A_LDS));
+        LVS_HIP_CHECK(hipFuncSetAttribute((const void*)lvs_assign_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, A_LDS));
+        LVS_HIP_CHECK(hipFuncSetAttribute((const void*)lvs_assign_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, A_LDS));
         attr.set(dev, (size_t)A_LDS);
     }
     {
         LvsKernelTimer timer(st);
-        hipLaunchKernelGGL(lvs_assign_kernel, dim3((unsigned)lvs_tile_grid_blocks(p.nct, p.nslab, p.gq, 0)), dim3(512), A_LDS, st, a);
+        const dim3 grid((unsigned)lvs_tile_grid_blocks(p.nct, p.nslab, p.gq, 0));
+        // skewed folds need two K-step barriers between a tile's end and the next tile's first fold: tiles of >= 3 K-steps
+        if (p.nkd >= 3 && lvs_tune("LVS_ASSIGN_SKEW", 1) != 0) hipLaunchKernelGGL(lvs_assign_kernel<true>, grid, dim3(512), A_LDS, st, a);
+        else hipLaunchKernelGGL(lvs_assign_kernel<false>, grid, dim3(512), A_LDS, st, a);
         LVS_HIP_CHECK(hipGetLastError());
     }
     hipLaunchKernelGGL(assign_merge_kernel, dim3((unsigned)lvs_ceil_div(nq, 256)), dim3(256), 0, st, (const u64*)a.out1,

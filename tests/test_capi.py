@@ -28,7 +28,7 @@ def test_shared_object_is_gfx950_code():
 
 def test_host_side_entry_points_without_a_gpu():
     lib = _capi.load()
-    assert lib.lvs_abi_version() == _capi.ABI_VERSION == 5 and lib.lvs_build_flags() == 0
+    assert lib.lvs_abi_version() == _capi.ABI_VERSION == 6 and lib.lvs_build_flags() == 0
     assert lib.lvs_packed_ld(768, _capi.PACK_F16) == 768
     assert lib.lvs_packed_ld(100, _capi.PACK_F16) == 128
     assert lib.lvs_packed_ld(384, _capi.PACK_SPLIT) == 768
@@ -43,6 +43,20 @@ def test_host_side_entry_points_without_a_gpu():
     st = lib.lvs_merge_keys(None, 2, 5, 100, None, None)
     assert st == _capi.EINVAL
     assert lib.lvs_flat_search_keys(None, 0, 10, None, 0, 0, 8, 0, 3, None, None, 0, None, None, None, 0, None) == 0
+    # the sharded search: scratch = both all-gather images + this shard's lists + the search's own scratch; pooled thresholds
+    # only for fp16 rows, k <= 56 and more than one rank (decided from the arguments, identically on every rank)
+    one = lib.lvs_search_sharded_workspace_bytes(1, 100000, 1000000, 768, 10, 0, 0, 20)
+    assert ws <= one < ws + 2 * 100000 * 10 * 8 + 4096
+    w8 = lib.lvs_search_sharded_workspace_bytes(8, 100000, 125000, 768, 10, 0, 0, 20)
+    w8_unseeded = lib.lvs_search_sharded_workspace_bytes(8, 100000, 125000, 768, 10, 0, 0, 0)
+    assert w8 - w8_unseeded >= 9 * 20 * 100000 * 4 and w8_unseeded >= 9 * 100000 * 10 * 8
+    assert lib.lvs_search_sharded_workspace_bytes(8, 100000, 125000, 768, 10, _capi.PACK_SPLIT, 0, 20) < w8  # hi|lo rows: no pool
+    assert lib.lvs_search_sharded_workspace_bytes(0, 10, 10, 8, 1, 0, 0, 0) < 0
+    st = lib.lvs_search_sharded(None, None, 2, None, 0, 10, None, 0, 10, 8, 0, 3, None, None, 0, 0, None, None, 0, None)
+    assert st == _capi.EINVAL and b"all-gather" in lib.lvs_last_error()
+    assert lib.lvs_search_sharded(None, None, 1, None, 0, 10, None, 0, 0, 8, 0, 3, None, None, 0, 0, None, None, 0, None) == 0
+    assert lib.lvs_rccl_available() in (0, 1)
+    assert lib.lvs_search_sharded_rccl(None, None, 0, 10, None, 0, 10, 8, 0, 3, None, None, 0, 0, None, None, 0, None) != 0
 
 
 def test_missing_library_fails_loudly(monkeypatch):

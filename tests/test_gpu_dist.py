@@ -104,3 +104,175 @@ def test_bench_self_launches_its_ranks_and_prints_one_line():
     assert out["planted_neighbour_at_rank1"] > 0.99
     assert "REHEARSAL" in out["data"]
     assert not [f for f in os.listdir("/dev/shm") if f.startswith("lotus_bench_")]
+
+
+# ---- the row-sharded search with its exchange steps inside the library (lvs_search_sharded / _rccl) --------------------------
+class _DevBytes:
+    """A raw device pointer as something torch.as_tensor understands."""
+
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {"shape": (int(nbytes),), "typestr": "|u1", "data": (int(ptr), False), "version": 2}
+
+
+def _sharded_inputs(hip_backend, n, nq, d, seed):
+    import numpy as np
+
+    import synth
+    from lotus_amd import _capi
+
+    xb = synth.corpus(n, d, seed=seed).astype(np.float16)
+    xq = synth.corpus(nq, d, seed=seed + 1).astype(np.float16)
+    xb[n // 2 + 7] = xb[5]  # an exact duplicate across shards: equal scores, ids decide
+    return xb, xq, hip_backend.pack(xb, _capi.PACK_F16), hip_backend.pack(xq, _capi.PACK_F16)
+
+
+@pytest.mark.parametrize("sizes", [(90_000, 70_000, 40_000), (120_000, 80_000, 0), (200_000,)])
+def test_sharded_search_inside_the_library_with_a_thread_all_gather(hip_backend, sizes):
+    """lvs_search_sharded on `len(sizes)` ranks = threads of this process, each with its own stream on cuda:0; the all-gather the
+    library calls back into is a device copy through a shared pool + a thread barrier.  Uneven shards, an EMPTY shard, pooled
+    sample thresholds on: every rank's merged keys equal the single-launch search of the whole corpus bit for bit (and the
+    oracle's ids)."""
+    import ctypes
+    import threading
+
+    import numpy as np
+    import torch
+
+    import oracle
+    from lotus_amd import _capi
+    from lotus_amd.backend import _ptr
+
+    be, lib = hip_backend, hip_backend.lib
+    n, nq, d, k = sum(sizes), 4096, 128, 10
+    xb, xq, corpus, queries = _sharded_inputs(be, n, nq, d, seed=31)
+    want = be.search_keys(corpus, queries, k, _capi.METRIC_IP)
+    be.synchronize()
+    W = len(sizes)
+    offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    tiles = int(lib.lvs_flat_search_seed_tiles(nq, max(sizes), k))
+    assert W == 1 or tiles > 0
+    pool = torch.empty((W, max(tiles * nq * 4, nq * k * 8)), dtype=torch.uint8, device=be.device)
+    barrier = threading.Barrier(W)
+    FN = ctypes.CFUNCTYPE(ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p)
+    outs, errs, calls = [None] * W, [], [0] * W
+
+    def rank(r):
+        try:
+            s = torch.cuda.Stream(device=be.device)
+
+            def all_gather(ctx, send, recv, nbytes, stream):
+                try:
+                    assert int(stream or 0) == int(s.cuda_stream)
+                    calls[r] += 1
+                    with torch.cuda.stream(s):
+                        pool[r, :nbytes].copy_(torch.as_tensor(_DevBytes(send, nbytes), device=be.device))
+                    s.synchronize()
+                    barrier.wait(timeout=120)
+                    with torch.cuda.stream(s):
+                        torch.as_tensor(_DevBytes(recv, W * nbytes), device=be.device).copy_(pool[:, :nbytes].reshape(-1))
+                    s.synchronize()
+                    barrier.wait(timeout=120)
+                    return 0
+                except Exception as e:  # noqa: BLE001 - reported through the status
+                    errs.append(repr(e))
+                    return _capi.EDEVICE
+
+            cb = FN(all_gather)
+            shard = be.slice_rows(corpus, int(offs[r]), int(offs[r + 1]))
+            need = int(lib.lvs_search_sharded_workspace_bytes(W, nq, shard.n, d, k, shard.mode, queries.mode, tiles))
+            assert need > 0
+            with torch.cuda.stream(s):
+                ws = torch.empty(need, dtype=torch.uint8, device=be.device)
+                keys = torch.zeros((nq, k), dtype=torch.int64, device=be.device)
+                st = lib.lvs_search_sharded(ctypes.cast(cb, ctypes.c_void_p), None, W, _ptr(shard.rows) if shard.n else None,
+                                            shard.mode, shard.n, _ptr(queries.rows), queries.mode, nq, d, _capi.METRIC_IP, k,
+                                            _ptr(shard.norms) if shard.n else None, _ptr(queries.norms), int(offs[r]), tiles,
+                                            _ptr(keys), _ptr(ws), need, int(s.cuda_stream))
+            s.synchronize()
+            assert st == 0, lib.lvs_last_error()
+            outs[r] = keys
+        except Exception as e:  # noqa: BLE001
+            errs.append(repr(e))
+            barrier.abort()
+
+    threads = [threading.Thread(target=rank, args=(r,)) for r in range(W)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(300)
+    assert not errs, errs
+    assert calls == [0 if W == 1 else 2] * W  # sample scores + key lists
+    for r in range(W):
+        assert torch.equal(outs[r], want), r
+    _, I = be.keys_to_result(outs[0], _capi.METRIC_IP)
+    Dr, Ir = oracle.flat_search(xb.astype(np.float32), xq[:256].astype(np.float32), k, 0)
+    got = I[:256].cpu().numpy()
+    assert np.mean([len(set(a) & set(b)) / k for a, b in zip(got.tolist(), Ir.tolist())]) == 1.0
+    assert got[0, 0] >= 0
+
+
+def _rccl_sharded_worker(out_q):
+    import ctypes
+    import os
+
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import numpy as np
+    import torch
+
+    import synth
+    from lotus_amd import _capi
+    from lotus_amd.backend import HipBackend, _ptr
+
+    be = HipBackend("cuda:0")
+    lib = be.lib
+    rccl = ctypes.CDLL("librccl.so.1")
+
+    class UniqueId(ctypes.Structure):
+        _fields_ = [("internal", ctypes.c_char * 128)]
+
+    uid = UniqueId()
+    assert rccl.ncclGetUniqueId(ctypes.byref(uid)) == 0
+    comm = ctypes.c_void_p()
+    rccl.ncclCommInitRank.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, UniqueId, ctypes.c_int]
+    assert rccl.ncclCommInitRank(ctypes.byref(comm), 1, uid, 0) == 0
+    # the communicator belongs to THIS copy of RCCL (torch bundles another): name its entry points explicitly
+    addr = lambda f: ctypes.cast(f, ctypes.c_void_p)
+    assert lib.lvs_rccl_bind(addr(rccl.ncclAllGather), addr(rccl.ncclCommCount), addr(rccl.ncclGetErrorString)) == 0
+    assert lib.lvs_rccl_available() == 1
+    n, nq, d, k = 150_000, 2048, 128, 10
+    xb = synth.corpus(n, d, seed=41).astype(np.float16)
+    xq = synth.corpus(nq, d, seed=42).astype(np.float16)
+    corpus, queries = be.pack(xb, _capi.PACK_F16), be.pack(xq, _capi.PACK_F16)
+    want = be.search_keys(corpus, queries, k, _capi.METRIC_IP, id_offset=1000)
+    tiles = int(lib.lvs_flat_search_seed_tiles(nq, n, k))
+    need = int(lib.lvs_search_sharded_workspace_bytes(1, nq, n, d, k, 0, 0, tiles))
+    ws = torch.empty(need, dtype=torch.uint8, device=be.device)
+    keys = torch.zeros((nq, k), dtype=torch.int64, device=be.device)
+    s = torch.cuda.current_stream(be.device)
+    st = lib.lvs_search_sharded_rccl(comm, _ptr(corpus.rows), 0, n, _ptr(queries.rows), 0, nq, d, _capi.METRIC_IP, k,
+                                     _ptr(corpus.norms), _ptr(queries.norms), 1000, tiles, _ptr(keys), _ptr(ws), need,
+                                     int(s.cuda_stream))
+    be.synchronize()
+    # and the transport itself through the library's own wrapper: a one-rank all-gather of the key lists = a copy
+    gathered = torch.zeros_like(keys)
+    rc = rccl.ncclAllGather(ctypes.c_void_p(_ptr(keys)), ctypes.c_void_p(_ptr(gathered)), ctypes.c_size_t(keys.numel() * 8), 0,
+                            comm, ctypes.c_void_p(int(s.cuda_stream)))
+    be.synchronize()
+    out_q.put((int(st), bool(torch.equal(keys, want)), int(rc), bool(torch.equal(gathered, keys))))
+    rccl.ncclCommDestroy(comm)
+
+
+def test_sharded_search_over_rccl_on_a_one_rank_communicator():
+    """lvs_search_sharded_rccl with a real ncclComm_t (one rank: this box has one GPU and RCCL refuses two ranks on a device):
+    communicator size read through ncclCommCount, the library's RCCL resolution / lvs_rccl_bind, same keys as the plain search.
+    The two ncclAllGather calls of the N > 1 path are exercised by the thread test above with a stand-in transport and by the
+    driver's multi-GPU run with RCCL itself."""
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_sharded_worker, args=(q,))
+    p.start()
+    st, same, rc, copied = q.get(timeout=300)
+    p.join(60)
+    assert st == 0 and same and rc == 0 and copied
