@@ -278,11 +278,11 @@ def main():
             search_legs(ctx, legs)
             node_plan_legs(ctx, legs)
             world8_rehearsal(ctx, legs, checks)
-            fp32_leg(ctx, legs)
-            for fut in (fut_dedup, fut_km):  # T_call stages host memory with a few threads: let the generators of the other
-                if fut is not None:          # configs' rows (up to 64 threads on a 16-CPU quota) finish first
-                    fut.result()
-            t_call_leg(ctx, legs)
+            for fut in (fut_dedup, fut_km):  # the legs below have the HOST in their timed region (T_call stages host memory
+                if fut is not None:          # with a few threads; the certified fp32 search reads one count back per call): let
+                    fut.result()             # the generators of the other configs' rows (up to 64 threads on a 16-CPU quota)
+            fp32_leg(ctx, legs)              # finish first - with them running the fp32 10 k x 1 M call measured 18.4 instead
+            t_call_leg(ctx, legs)            # of 16.1 ms on the same box (gpurun_out/r07d vs r07e)
             t_op_leg(ctx, legs)
             if fut_dedup is not None:
                 dedup_leg(ctx, legs, checks, fut_dedup)
