@@ -106,18 +106,23 @@ def sem_sim_join(df1: pd.DataFrame, df2: pd.DataFrame, left_on: str, right_on: s
     out = vs(qv, K, ids=right_index if native else right_index.tolist())
     I = np.asarray(out.indices)
     D = np.asarray(out.distances)
-    ok = I >= 0  # ids come from df2.index, so every non-padded hit is a right row
-    qpos = np.broadcast_to(np.arange(I.shape[0])[:, None], I.shape)[ok]
-    right_ids = I[ok]
+    if I.size and int(I.min()) >= 0:
+        # no padded slot (the usual case: K <= rows of df2): views instead of three masked copies of a million entries
+        qpos = np.repeat(np.arange(I.shape[0]), I.shape[1])
+        right_ids, scores = I.reshape(-1), D.reshape(-1)
+    else:
+        ok = I >= 0  # ids come from df2.index, so every non-padded hit is a right row
+        qpos = np.broadcast_to(np.arange(I.shape[0])[:, None], I.shape)[ok]
+        right_ids, scores = I[ok], D[ok]
     left_ids = np.asarray(df1.index)[qpos]
-    fast = _joined_frame(df1, df2, qpos, left_ids, right_ids, D[ok], lsuffix, rsuffix, score_suffix, keep_index)
+    fast = _joined_frame(df1, df2, qpos, left_ids, right_ids, scores, lsuffix, rsuffix, score_suffix, keep_index)
     if fast is not None:
         return fast
     d1 = df1.copy()
     d2 = df2.copy()
     d1["_left_id"] = d1.index
     d2["_right_id"] = d2.index
-    temp = pd.DataFrame({"_left_id": left_ids, "_right_id": right_ids, "_scores" + score_suffix: D[ok]})
+    temp = pd.DataFrame({"_left_id": left_ids, "_right_id": right_ids, "_scores" + score_suffix: scores})
     joined = d1.join(temp.set_index("_left_id"), how="right", on="_left_id").join(
         d2.set_index("_right_id"), how="left", on="_right_id", lsuffix=lsuffix, rsuffix=rsuffix)
     if not keep_index:
@@ -142,9 +147,14 @@ def _joined_frame(df1, df2, qpos, left_ids, right_ids, scores, lsuffix, rsuffix,
     overlap = set(lcols) & set(rcols)
     if overlap and not lsuffix and not rsuffix:
         return None  # DataFrame.join raises here; let it
-    rpos = df2.index.get_indexer(right_ids)
-    if (rpos < 0).any():
-        return None
+    if isinstance(df2.index, pd.RangeIndex) and df2.index.start == 0 and df2.index.step == 1:
+        rpos = np.asarray(right_ids)  # labels ARE positions (a frame that was never re-indexed): no hash look-up
+        if rpos.size and (int(rpos.min()) < 0 or int(rpos.max()) >= len(df2)):
+            return None
+    else:
+        rpos = df2.index.get_indexer(right_ids)
+        if (rpos < 0).any():
+            return None
     index = df1.index.take(qpos)
     left = df1.take(qpos)
     right = df2.take(rpos)

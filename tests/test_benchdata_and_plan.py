@@ -44,16 +44,54 @@ def test_blobs_carry_their_labels():
 
 
 def test_split_planner():
-    assert plan.splits(8) == [(1, 8), (2, 4), (4, 2), (8, 1)]
-    for w in (1, 2, 4, 8):
+    plan.use_tables(dict(plan._BUILTIN))  # the model's behaviour on a FIXED set of numbers (round 4's fit)
+    try:
+        assert plan.splits(8) == [(1, 8), (2, 4), (4, 2), (8, 1)]
+        for w in (1, 2, 4, 8):
+            gq, gc = plan.pick_split(w)
+            assert gq * gc == w
+        assert plan.pick_split(8) == (8, 1)                       # configs[2] fits every GPU: the query split runs ~2 points faster
+        assert plan.pick_split(2) in ((1, 2), (2, 1))
+        assert plan.pick_split(8, nq=100_000, nb=400_000_000) == (1, 8)   # 614 GB of corpus: only the row split fits
+        assert plan.pick_split(8, nq=1_000_000, nb=8_000)[0] > 1  # a corpus of a few tiles: split the queries instead
+        f = plan.projected_fraction
+        assert f(100_000, 1_000_000) > f(100_000, 125_000) > f(1_000, 125_000)
+    finally:
+        plan.use_tables(None)
+
+
+def test_planner_tables_are_data(tmp_path, monkeypatch):
+    """The planner's numbers are data with a provenance: the shipped JSON (re-fitted from a bench.py line by
+    tools/refit_plan.py), a file named by $LOTUS_AMD_PLAN_TABLES (what `plan.calibrate(backend, save=...)` writes on the machine
+    at hand), the built-in fit as the last resort; a bench.py line's legs turn into tables by the documented arithmetic."""
+    import json
+
+    shipped = plan.load_tables()
+    assert plan._valid(shipped) and "source" in shipped and shipped["loss_rows"][0] == 0.0
+    for w in (2, 4, 8):  # whatever the shipped numbers are: a legal split, and BASELINE's corpus still fits the row split
         gq, gc = plan.pick_split(w)
         assert gq * gc == w
-    assert plan.pick_split(8) == (8, 1)                       # configs[2] fits every GPU: the query split runs ~2 points faster
-    assert plan.pick_split(2) in ((1, 2), (2, 1))
-    assert plan.pick_split(8, nq=100_000, nb=400_000_000) == (1, 8)   # 614 GB of corpus: only the row split fits
-    assert plan.pick_split(8, nq=1_000_000, nb=8_000)[0] > 1  # a corpus of a few tiles: split the queries instead
-    f = plan.projected_fraction
-    assert f(100_000, 1_000_000) > f(100_000, 125_000) > f(1_000, 125_000)
+        assert plan.pick_split(w, nb=400_000_000 * w // 8 if w == 8 else 1_000_000)[0] * gc >= 1
+    line = {"roofline": {"frac": 0.44, "csrc_sha": "abc"},
+            "legs": {"shard_100k_x_500k": {"frac": 0.425}, "shard_100k_x_250k": {"frac": 0.405},
+                     "node_plan_8gpu": {"splits": {"1x8": {"frac": 0.38}, "2x4": {"frac": 0.40}, "4x2": {"frac": 0.41},
+                                                   "8x1": {"frac": 0.43}}},
+                     "world8_rehearsal": {"frac": 0.42, "kernel_ms_per_shard": 18.0, "seed_pass_ms_per_shard": 0.72}}}
+    t = plan.tables_from_bench(line)
+    assert t["base_frac"] == 0.44 and t["loss_rows"][:4] == [0.0, 0.015, 0.035, 0.06] and t["loss_queries"][3] == 0.01
+    assert abs(t["pooled_gain_per_halving"] - (0.42 * 18.0 / 18.72 - 0.38) / 3) < 1e-4 and "abc" in t["source"]
+    path = tmp_path / "mine.json"
+    path.write_text(json.dumps(dict(t, base_frac=0.30)))
+    monkeypatch.setenv("LOTUS_AMD_PLAN_TABLES", str(path))
+    plan.use_tables(None)
+    try:
+        assert plan.tables()["base_frac"] == 0.30 and abs(plan.projected_fraction(100_000, 1_000_000) - 0.30) < 1e-9
+        path.write_text("{not json")
+        plan.use_tables(None)
+        assert plan.tables()["source"] == shipped["source"]  # an unreadable file falls through to the shipped tables
+    finally:
+        monkeypatch.delenv("LOTUS_AMD_PLAN_TABLES")
+        plan.use_tables(None)
 
 
 def test_bench_cpu_baseline_reports_a_parity_sample_of_the_timed_run():

@@ -359,3 +359,23 @@ def test_large_host_call_is_staged_and_equals_the_single_launch(hip_backend, tmp
     t2 = threading.Thread(target=run, args=("b", xq[::-1].copy()))
     t1.start(); t2.start(); t1.join(); t2.join()
     assert np.array_equal(outs["a"], plain.indices[:, :5]) and np.array_equal(outs["b"], plain.indices[::-1, :5])
+
+
+def test_split_planner_calibrates_on_the_machine_it_runs_on(hip_backend, tmp_path):
+    """`plan.calibrate(backend)`: the planner's tables measured on THIS GPU and build (seven shapes of the 100 k x 1 M join +
+    the pooled-threshold shard, ~2 s), saved as the JSON `$LOTUS_AMD_PLAN_TABLES` names - `shard="auto"` is then no longer a
+    constant of the box the shipped tables were fitted on."""
+    import json
+
+    from lotus_amd import plan
+
+    path = tmp_path / "plan.json"
+    try:
+        t = plan.calibrate(hip_backend, save=str(path), reps=1)
+        assert plan._valid(t) and 0.25 < t["base_frac"] < 0.7 and "calibrate()" in t["source"]
+        assert t["loss_rows"][3] >= t["loss_rows"][1] >= 0.0  # a 125 k-row shard loses at least what a 500 k-row one does
+        assert json.loads(path.read_text()) == t and plan.tables() is t
+        gq, gc = plan.pick_split(8)
+        assert gq * gc == 8
+    finally:
+        plan.use_tables(None)
