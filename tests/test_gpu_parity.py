@@ -658,15 +658,16 @@ def test_one_pass_certificate_refuses_rows_that_differ_below_fp16_resolution(hip
 def test_planner_shapes_sampled_parity(hip_backend, nq, nb, d):
     """Launch shapes that take the planner's 8 x 4 L2 groups with a leading slab, a remainder of groups dealt across all
     XCDs, remainder query tiles and the wide-group fallback (lvs_tile.h, make_plan): the whole launch runs on the GPU,
-    five (at d = 768: three) queries of EVERY 256-query tile are checked against the oracle (a query's list depends on every
-    (tile, slab) item of its tile)."""
+    EIGHT queries of EVERY 256-query tile are checked against the oracle - one in each 32-query block of the tile (= one per
+    (wave column, accumulator block) of the workgroup), at a lane position that walks with the tile number, so all 256
+    positions of a tile are hit across the launch (a query's list depends on every (tile, slab) item of its tile)."""
     k = 10
     xb = synth.corpus(nb, d, seed=11)
     xq, _ = synth.queries(xb, nq, seed=12)
     D, I, _ = _run(hip_backend, xb, xq, k, F16, IP)
-    rng = np.random.default_rng(nq)
     tiles = np.arange(0, nq, 256)
-    pick = np.unique(np.minimum(tiles[:, None] + rng.integers(0, 256, (len(tiles), 5 if d < 768 else 3)), nq - 1).reshape(-1))
+    t = np.arange(len(tiles))
+    pick = np.unique(np.minimum(tiles[:, None] + 32 * np.arange(8)[None, :] + ((37 * t) % 32)[:, None], nq - 1).reshape(-1))
     pick = np.union1d(pick, [0, nq - 1])
     Dr, Ir = oracle.flat_search(_stored(xb, F16), _stored(xq[pick], F16), k, IP)
     err, hard, recall = synth.compare_topk(Dr, Ir, D[pick], I[pick], atol=1e-5)
