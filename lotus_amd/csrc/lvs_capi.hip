@@ -1230,6 +1230,54 @@ static int32_t flat_search_impl(const void* xb, int32_t xb_pack, int64_t nb, con
     }
 #endif
 
+    // 97 .. 256 queries, one K segment of fp16 k-slices: the queries live in REGISTERS (lvs_rq.hip), the corpus streams through
+    // LDS once - between the HBM-bound batches below and the joins the list kernel is built for
+    if (lvs_tune("LVS_RQ", 1) != 0 && p.nseg == 1 && p.npass == 1 && !pred && g_band.kc == 0 && lvs_rq_fits(nq, nb, p.dpad, k)) {
+        LvsRqArgs ra;
+        memset(&ra, 0, sizeof(ra));
+        ra.xb = xb;
+        ra.xq = xq;
+        ra.bn = xb_norms_sq;
+        ra.qn = xq_norms_sq;
+        ra.row_ids = row_ids;
+        ra.gtau = gtau;
+        ra.out = partial;
+        ra.nb = nb;
+        ra.ldb = p.ldb;
+        ra.ldq = p.ldq;
+        ra.id_offset = id_offset;
+        ra.nq = (int)nq;
+        ra.k = k;
+        ra.metric = metric;
+        // thresholds seeded from a sample of the rows scanned by this kernel's own SEED mode (bit-identical scores; see the
+        // streaming path below for why a caller's pooled sample scores are not used)
+        int64_t sample = nb / 8 / 1024 * 1024;
+        if (sample > LVS_STREAM_SEED_ROWS) sample = LVS_STREAM_SEED_ROWS;
+        if (sample >= 4096 && lvs_tune("LVS_STREAM_SEED", 1) != 0) {
+            float* seeds = (float*)((char*)partial + lvs_stream_parts_bytes(nq, k));  // [ranges][nq]
+            LvsRqArgs rs = ra;
+            rs.nb = sample;
+            rs.seed_out = seeds;
+            LVS_HIP_CHECK(lvs_rq_launch(rs, p.dpad, st));
+            hipLaunchKernelGGL(seed_kth_kernel, dim3((unsigned)lvs_ceil_div(nq, 4)), dim3(256), 0, st, (const float*)seeds,
+                               rs.nparts, (long long)nq, k, gtau);  // writes every gtau[q]
+            LVS_HIP_CHECK(hipGetLastError());
+        } else {
+            LVS_HIP_CHECK(hipMemsetAsync(gtau, 0, (size_t)nq * 4, st));
+        }
+        {
+            ScopedKernelTimer timer(st);
+            LVS_HIP_CHECK(lvs_rq_launch(ra, p.dpad, st));
+        }
+        if (ra.nparts >= 16)
+            hipLaunchKernelGGL(merge_keys_wide_kernel, dim3((unsigned)nq), dim3(1024), 0, st, partial, ra.nparts, (long long)nq, k,
+                               (u64*)out_keys, (long long)k);
+        else
+            hipLaunchKernelGGL(merge_keys_kernel, dim3((unsigned)lvs_ceil_div(nq, 4)), dim3(256), 0, st, partial, ra.nparts,
+                               (long long)nq, k, (u64*)out_keys, (long long)k, (const uint32_t*)nullptr);
+        LVS_HIP_CHECK(hipGetLastError());
+        return LVS_OK;
+    }
     // HBM-bound regime (the literal sem_search: one query per call; small batches up to 256 queries): stream the corpus
     // once, queries resident in LDS
     {

@@ -213,6 +213,27 @@ struct LvsStreamArgs {
     int debug;               // -DLVS_TUNING builds only (env LVS_STREAM_DEBUG): 1 no MFMA / B reads, 2 no block epilogue
 };
 
+// ---- lvs_rq.hip: 97 .. 256 queries with the queries resident in registers ----
+#define LVS_RQ_MAXQ 256
+struct LvsRqArgs {
+    const void* xb;
+    const void* xq;
+    const float* bn;
+    const float* qn;
+    const uint32_t* row_ids;
+    uint32_t* gtau;   // [nq] zero-initialised, or seeded with a valid lower bound of every query's k-th best score
+    u64* out;         // [nparts][nq][k]
+    float* seed_out;  // non-NULL: SEED mode - [nparts][nq] best score of every (corpus range, query) instead of lists
+    long long nb, ldb, ldq, id_offset;
+    int nq, k, metric;
+    int blocks_per_wg;  // 32-row blocks per corpus range (set by lvs_rq_launch)
+    int nparts;         // out: corpus ranges of the launch
+    int debug;          // -DLVS_TUNING builds only (env LVS_RQ_DEBUG): timing ablations, see lvs_rq.hip
+    unsigned long long* stamps;  // -DLVS_TUNING builds only (env LVS_RQ_STAMPS): s_memtime stamps of one workgroup
+};
+bool lvs_rq_fits(int64_t nq, int64_t nb, int dpad, int k);
+hipError_t lvs_rq_launch(LvsRqArgs& a, int dpad, hipStream_t stream);
+
 int lvs_stream_ranges(int64_t nb, int groups);
 size_t lvs_stream_lds_bytes(int nbfrag, int nqb, int kcap);
 int lvs_stream_plan(int64_t nq, int k, int nbfrag, int* out_kcap, int* out_nqb, int* out_groups);

@@ -456,6 +456,14 @@ def test_seeded_streaming_search_with_duplicates_across_the_sample_boundary(hip_
     (1000, 90_000, 200, 10, SPLIT, IP),  # fp32-accurate operands (three K segments in the sample pass too)
     (3000, 66_000, 64, 5, SPLIT, L2),
     (130, 400_000, 64, 10, F16, IP),     # <= 256 queries beyond one sibling group: the list kernel, not the stream kernel
+    # 97 .. 256 fp16 queries, d padded to 256 / 384 / 512 / 768, k <= 16, >= 32 768 rows: the queries-in-registers kernel
+    # (lvs_rq.hip): four waves up to 128 queries, eight beyond; 12-slot lists up to k = 12, 16-slot ones beyond
+    (100, 100_000, 768, 10, F16, IP),
+    (128, 70_001, 512, 16, F16, L2),     # ragged last block, full 16-slot lists, row norms through the side words
+    (160, 90_000, 384, 12, F16, IP),     # one unit per block (24 k-slices), five of the eight waves hold queries
+    (256, 66_000, 256, 1, F16, L2),      # k = 1 through the lists
+    (200, 40_000, 768, 13, F16, IP),     # 16-slot lists at d = 768 on eight waves (the tightest register budget)
+    (97, 33_000, 200, 10, F16, L2),      # d padded from 200 to 256, a corpus barely long enough
 ])
 def test_seeded_list_kernel(hip_backend, nq, nb, d, k, mode, metric):
     """Launches with few query tiles seed their thresholds from a sample (LVS_MODE_SEED + k-th largest per-tile maximum)

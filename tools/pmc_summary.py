@@ -55,6 +55,12 @@ if "TCC_HIT_sum" in avg:
 if "SQ_VALU_MFMA_BUSY_CYCLES" in avg and "GRBM_GUI_ACTIVE" in avg:
     # GRBM_GUI_ACTIVE is summed over the 8 XCDs; MFMA busy cycles over the 1024 SIMDs
     summary["mfma_busy_frac"] = (avg["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024) / (avg["GRBM_GUI_ACTIVE"] / 8)
+if "SQ_LDS_IDX_ACTIVE" in avg and "GRBM_GUI_ACTIVE" in avg:
+    # the LDS port's occupancy (rocprofv3's own LdsUtil expression: SQ_LDS_IDX_ACTIVE summed over the CUs / (busy cycles x CUs));
+    # indexed operations only - the fragment reads (ds_read_b128) - the LDS-DMA writes of global_load_lds are not in it
+    summary["lds_idx_active_frac"] = (avg["SQ_LDS_IDX_ACTIVE"] / 256) / (avg["GRBM_GUI_ACTIVE"] / 8)
+    if "SQ_LDS_BANK_CONFLICT" in avg:
+        summary["lds_bank_conflict_frac_of_active"] = avg["SQ_LDS_BANK_CONFLICT"] / avg["SQ_LDS_IDX_ACTIVE"]
 if "SQ_WAVE_CYCLES" in avg:
     for c in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY"):
         if c in avg:

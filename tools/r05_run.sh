@@ -40,6 +40,8 @@ for w in $what; do
     kmpipe) timeout -k 10 600 python tools/km_pipeline_probe.py > $out/kmpipe.log 2>&1; grep -v "^\[" $out/kmpipe.log | tail -8 ;;
     fp32stride) timeout -k 10 400 python tools/fp32_stride_probe.py > $out/fp32stride.log 2>&1; cat $out/fp32stride.log | tail -80 ;;
     kmskew) timeout -k 10 600 python tools/km_skew_probe.py > $out/kmskew.log 2>&1; grep -v "^\[" $out/kmskew.log | tail -30 ;;
+    rq) timeout -k 10 600 python tools/rq_probe.py > $out/rq.log 2>&1; grep -v "^\[" $out/rq.log | tail -40 ;;
+    rqab) timeout -k 10 600 python tools/rq_ablate.py > $out/rqab.log 2>&1; grep -v "amdgpu.ids" $out/rqab.log | tail -30 ;;
     smoke) timeout -k 10 300 python -c 'import __graft_entry__ as g; g.smoke()' > $out/smoke.log 2>&1; tail -3 $out/smoke.log ;;
     *) echo "unknown step $w" ;;
   esac
