@@ -1252,7 +1252,8 @@ static int32_t flat_search_impl(const void* xb, int32_t xb_pack, int64_t nb, con
         // thresholds seeded from a sample of the rows scanned by this kernel's own SEED mode (bit-identical scores; see the
         // streaming path below for why a caller's pooled sample scores are not used)
         int64_t sample = nb / 8 / 1024 * 1024;
-        if (sample > LVS_STREAM_SEED_ROWS) sample = LVS_STREAM_SEED_ROWS;
+        const int64_t sample_cap = lvs_tune("LVS_RQ_SAMPLE", LVS_RQ_SEED_ROWS);
+        if (sample > sample_cap) sample = sample_cap;
         if (sample >= 4096 && lvs_tune("LVS_STREAM_SEED", 1) != 0) {
             float* seeds = (float*)((char*)partial + lvs_stream_parts_bytes(nq, k));  // [ranges][nq]
             LvsRqArgs rs = ra;

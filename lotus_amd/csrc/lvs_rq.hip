@@ -89,6 +89,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void lvs_rq_kernel(const Lvs
     using G = RqGeom<NJ, UK, WAVES, NQW, KCAP>;
     constexpr int RQ_WAVES = WAVES;
     constexpr int RQ_KCAP = KCAP;
+    constexpr int SIDE_EVERY = 1;  // blocks between two reads of the other workgroups' thresholds (a power of two; every 8th block measured 7 % slower)
     constexpr int NB_RING = G::NB_RING;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* ring = smem;
@@ -187,8 +188,8 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void lvs_rq_kernel(const Lvs
 #ifdef LVS_TUNING
         if (a.debug == 5) return;  // timing ablation: no side words (inner product only; thresholds are not exchanged)
 #endif
-        if (!SEED && kh == 0 && n < total_units) {
-            // the block's side words: lanes 0 .. 31 -> |y|^2 of its rows (any valid word under inner product), lanes 32 .. 63 ->
+        if (!SEED && kh == 0 && n < total_units && (l2 || (blk & (SIDE_EVERY - 1)) == 0)) {
+            // the block's side words (inner product: every SIDE_EVERY-th block only - nothing but thresholds rides in them): lanes 0 .. 31 -> |y|^2 of its rows (any valid word under inner product), lanes 32 .. 63 ->
             // the shared thresholds of this wave's queries.  NQW = 2: one DMA per query block, slots 64 words apart
             int row = lane & 31;
             row = row < last ? row : last;
@@ -315,6 +316,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void lvs_rq_kernel(const Lvs
 #ifdef LVS_TUNING
             if (a.debug != 5)
 #endif
+            if (l2 || (blk & (SIDE_EVERY - 1)) == 0)
             {   // the shared threshold as it was when this block's rows were requested (a lower bound of the k-th best score
                 // over ALL workgroups' rows so far): every block, every workgroup tightens from what the others have found
                 const uint32_t g = __float_as_uint(sideb[qb * 64 + 32 + (lane & 31)]);
@@ -328,12 +330,22 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void lvs_rq_kernel(const Lvs
                 ++slow_entries;
 #endif
                 uint32_t best_tau = 0;  // the tightest k-th key this lane's query reached in this block
+                // one candidate of one lane is the usual case: every lane finds its FIRST candidate (value and register index) in
+                // straight-line code - three VALU operations per score, no ballots - and only when some lane holds more than one
+                // do the remaining registers get their turn
+                float fs = 0.f;
+                int fr = 16, cnt = 0;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float s = acc[qb][r];
+                for (int r = 15; r >= 0; --r) {
+                    const bool c = th && acc[qb][r] >= tauf[qb];
+                    fs = c ? acc[qb][r] : fs;
+                    fr = c ? r : fr;
+                    cnt += c ? 1 : 0;
+                }
+                auto offer = [&](bool cand, float s, int r) __attribute__((always_inline)) {
                     bool pending = false;
                     u64 key = 0;
-                    if (th && s >= tauf[qb]) {
+                    if (cand && s >= tauf[qb]) {
                         const long long row = rbase + (r & 3) + 8 * (r >> 2);
                         if (row < a.nb) {
                             const uint32_t id = a.row_ids ? a.row_ids[row] : (uint32_t)(row + a.id_offset);
@@ -365,6 +377,11 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void lvs_rq_kernel(const Lvs
                             best_tau = ntau > best_tau ? ntau : best_tau;
                         }
                     }
+                };
+                offer(fr < 16, fs, fr);
+                if (__any(cnt > 1)) {
+#pragma unroll
+                    for (int r = 1; r < 16; ++r) offer(th && r > fr, acc[qb][r], r);
                 }
                 // lanes l and l + 32 hold the same query: both continue from the tighter threshold; a full list's k-th key is
                 // published to the other workgroups (fire and forget: nothing waits for the atomic)

@@ -215,6 +215,8 @@ struct LvsStreamArgs {
 
 // ---- lvs_rq.hip: 97 .. 256 queries with the queries resident in registers ----
 #define LVS_RQ_MAXQ 256
+#define LVS_RQ_SEED_ROWS 65536  // sample rows (the first of the shard) whose scores seed the thresholds: a workgroup sees ~4 000
+                                // rows, its lists never fill, so the seed IS its threshold - 64 k rows beat 32 k by 4 % per call, 128 k tie
 struct LvsRqArgs {
     const void* xb;
     const void* xq;

@@ -63,15 +63,13 @@ xq = unit(256, 768)
 for rnd in range(2):
     for nq in (97, 128, 160, 192, 256):
         cq = be.pack(xq[:nq].contiguous(), _capi.PACK_F16)
-        for rq, mode in (("0", "0"), ("1", "0"), ("1", "2")):
-            if mode != "0" and nq <= 128:
-                continue
-            os.environ["LVS_RQ_MODE"] = "2" if mode == "2" else "0"
-            os.environ["LVS_RQ_AD"] = mode[2:] if mode.startswith("ad") else "0"
+        for rq, mode in (("0", "0"), ("1", "0"), ("1", "s65536")):
+            os.environ["LVS_RQ_MODE"] = "0"
+            os.environ["LVS_RQ_SAMPLE"] = mode[1:] if mode.startswith("s") else "32768"
             keys, kms, wall = run(cb, cq, 10, 0, rq, 20)
             if rq == "0":
                 ref = keys
-            print(f"{nq:4d} queries x 1 M x 768, k = 10, LVS_RQ={rq} mode {mode}: kernel {kms:6.3f} ms  call {wall:6.3f} ms" +
+            print(f"{nq:4d} queries x 1 M x 768, k = 10, LVS_RQ={rq} sample {mode}: kernel {kms:6.3f} ms  call {wall:6.3f} ms" +
                   ("" if rq == "0" else f"  keys identical: {bool(torch.equal(keys, ref))}"), flush=True)
         os.environ["LVS_RQ_MODE"] = "0"
-        os.environ["LVS_RQ_AD"] = "0"
+        os.environ["LVS_RQ_SAMPLE"] = "32768"
