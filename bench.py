@@ -344,7 +344,7 @@ def shared_inputs(np, dist, benchdata, world, rank, n, d, nq):
         return (*(got if got is not None else draw()), None)
     if rank != 0:
         got = tuple(np.load(os.path.join(shm, name + ".npy"), mmap_mode="r") for name in ("xb", "xq", "planted"))
-        got = (got[0], np.ascontiguousarray(got[1]), np.ascontiguousarray(got[2]))
+        got = (got[0], np.array(got[1]), np.array(got[2]))  # the corpus stays mapped (a rank touches its shard only); queries copied
     return (*got, shm)
 
 
