@@ -230,8 +230,6 @@ struct LvsRqArgs {
     int nq, k, metric;
     int blocks_per_wg;  // 32-row blocks per corpus range (set by lvs_rq_launch)
     int nparts;         // out: corpus ranges of the launch
-    int debug;          // -DLVS_TUNING builds only (env LVS_RQ_DEBUG): timing ablations, see lvs_rq.hip
-    unsigned long long* stamps;  // -DLVS_TUNING builds only (env LVS_RQ_STAMPS): s_memtime stamps of one workgroup
 };
 bool lvs_rq_fits(int64_t nq, int64_t nb, int dpad, int k);
 hipError_t lvs_rq_launch(LvsRqArgs& a, int dpad, hipStream_t stream);
