@@ -86,6 +86,7 @@ __device__ inline void rq_glds4(const void* gsrc, void* ldst) {
 // 8 (two per SIMD, 256 each), NQW = 32-query blocks per wave (1; 2 with four waves), AD = A fragments in flight per wave
 template <int NJ, int UK, int WAVES, int NQW, int AD, int KCAP, bool SEED>
 __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void lvs_rq_kernel(const LvsRqArgs a) {
+    constexpr bool RQ_SETPRIO = true;
     constexpr bool PHASED = false;  // WAVES == 8 measured slower (0.51 vs 0.46 ms at 256 queries): see the comment at the block loop
     using G = RqGeom<NJ, UK, WAVES, NQW, KCAP>;
     constexpr int RQ_WAVES = WAVES;
@@ -335,6 +336,9 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void lvs_rq_kernel(const Lvs
     };
 
     for (int n = 0; n < G::RING - 1; ++n) issue_unit(n);
+    // two waves per SIMD: the second-dispatched half loses issue arbitration to the older half on every unit; static priority
+    // for it evens that out (the tile kernels' T5 recipe)
+    if (WAVES == 8 && wave >= 4 && RQ_SETPRIO) __builtin_amdgcn_s_setprio(1);
 
     // PHASED (eight waves, two per SIMD): the two waves of a SIMD run a unit's pieces in OPPOSITE order, so that one wave's
     // instruction-bound pieces - issuing its share of the staging loads, the block epilogue - run beside the other's MFMAs
