@@ -18,15 +18,15 @@
 // Same operand roles (corpus rows = A, queries = B), same MFMA, same k-slice order 0 .. K/16 - 1 into one accumulator as every
 // other kernel of the library: keys are bit-identical to the list kernel's (tools/rq_probe.py: 150 shapes, both metrics,
 // k = 1 / 10 / 16, ragged last block, duplicate rows); thresholds are seeded by this kernel's own SEED mode.
-// Measured (1 M x 768 fp16, k = 10, same box, kernel ms; profiles/r07_tuning.md): 97 / 128 queries 0.375-0.396 -> 0.325-0.349
-// (-11..13 %), 160 / 192 / 256 queries 0.462 / 0.478 / 0.502 -> 0.442 / 0.464 / 0.484 (-3..4 %).  What bounds it (s_memtime
-// stamps of the tuning build): per unit of 24 MFMAs a wave spends ~1 180 cycles in the read + MFMA phase, ~550 issuing its
-// share of the staging loads, ~500 at the unit's barrier and ~800 per unit in the block epilogue (whose slow path is entered
-// for every second to fourth block: a workgroup sees 3 900 rows, so its lists never fill and its thresholds stay at the seed)
-// - the staging data is always there (34 cycles at the vmcnt wait).  With one or two waves per SIMD none of that hides
-// behind another wave's MFMAs; folding the loads and the epilogue into the MFMA stream is what is left to do.
-#include <stdio.h>
-
+// Measured (1 M x 768 fp16, k = 10, same box, kernel ms; profiles/r08e_rq_probe.log, profiles/r07_tuning.md), structureless unit
+// rows - the worst case for thresholds: 97 / 128 queries 0.369 / 0.385 -> 0.274 / 0.281 ms (5.5 TB/s of corpus stream), 160 /
+// 192 / 256 queries 0.464 / 0.482 / 0.505 -> 0.393 / 0.404 / 0.420 ms; on the bench's data (planted neighbours) the legs
+// q128 / q192 / q256 read 0.294 / 0.403 / 0.427 ms = 65 / 48 / 45 % of the HBM roof (list kernel: 50 / 41 / 39 %).
+// What bounds it (s_memtime stamps of an instrumented copy, tools/lvs_rq_instrumented.hip.txt, first complete version): per unit
+// of 24 MFMAs a wave spent ~1 180 cycles in the read + MFMA phase, ~550 issuing its share of the staging loads, ~500 at the
+// unit's barrier and ~800 per unit in the block epilogue (whose slow path was entered for every second to fourth block: a
+// workgroup sees 3 900 rows, so its lists never fill and its thresholds stay at the seed) - the staging data was always there
+// (34 cycles at the vmcnt wait).  With one or two waves per SIMD none of that hides behind another wave's MFMAs.
 #include "lvs_common.h"
 #include "lvs_kstep.h"
 #include "lvs_tile.h"
