@@ -24,6 +24,13 @@ class PackedRows:
     flags: "object" = None  # device int32 [1] of LVS_PACK_FLAG_* when the pack was validated lazily (check="lazy")
 
 
+class _DevBytes:
+    """A raw device pointer as something ``torch.as_tensor`` understands (the all-gather callback of ``lvs_search_sharded``)."""
+
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {"shape": (int(nbytes),), "typestr": "|u1", "data": (int(ptr), False), "version": 2}
+
+
 def _ptr(t) -> int:
     return 0 if t is None else int(t.data_ptr())
 
@@ -801,6 +808,48 @@ class HipBackend:
         self._c("lvs_kmeans_bounds_step", _ptr(assign), _ptr(ub), _ptr(lb), _ptr(delta), _ptr(top2), n, _ptr(idx), _ptr(cnt),
                 self._stream())
         return idx[:int(cnt.item())]
+
+    def search_sharded(self, shard: PackedRows, queries: PackedRows, k: int, metric: int, id_offset: int, world: int,
+                       seed_tiles: int, all_gather):
+        """This rank's share of a row-sharded search with the exchange steps run INSIDE the C ABI (``lvs_search_sharded``, ABI 6):
+        sample scores -> all-gather -> seeded shard search -> all-gather of the key lists -> merge, all enqueued on the current
+        stream.  ``all_gather``: callable(device uint8 tensor [n]) -> device uint8 tensor [world, n] (rank order), called by the
+        library for its two exchanges - ``lotus_amd._dist.all_gather_rows`` over any ``torch.distributed`` backend.  (A host with
+        an ``ncclComm_t`` of its own calls ``lvs_search_sharded_rccl`` and needs no callback at all.)  -> int64 keys [nq, k],
+        identical on every rank and equal to what ``search_keys`` + ``merge_keys`` give."""
+        torch = self.torch
+        nq = queries.n
+        if shard.d != queries.d:
+            raise ValueError("corpus / query dimension mismatch")
+        errors = []
+        FN = ctypes.CFUNCTYPE(ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p)
+
+        def transport(_ctx, send, recv, nbytes, _stream):
+            try:  # the library's stream is torch's current stream (self._stream()): torch work queued here stays in order
+                src = torch.as_tensor(_DevBytes(send, nbytes), device=self.device)
+                out = all_gather(src)
+                torch.as_tensor(_DevBytes(recv, world * nbytes), device=self.device).copy_(out.reshape(-1))
+                return 0
+            except Exception as e:  # noqa: BLE001 - reported through the status code
+                errors.append(e)
+                return _capi.EDEVICE
+
+        cb = FN(transport)
+        need = int(self.lib.lvs_search_sharded_workspace_bytes(world, nq, shard.n, shard.d, k, shard.mode, queries.mode,
+                                                               int(seed_tiles)))
+        if need < 0:
+            raise LotusHipError("lvs_search_sharded_workspace_bytes rejected the shape")
+        ws = self._workspace(need)
+        keys = torch.zeros((nq, k), dtype=torch.int64, device=self.device)
+        with torch.cuda.device(self.device):
+            st = self.lib.lvs_search_sharded(ctypes.cast(cb, ctypes.c_void_p), None, world, _ptr(shard.rows) if shard.n else None,
+                                             shard.mode, shard.n, _ptr(queries.rows), queries.mode, nq, shard.d, metric, k,
+                                             _ptr(shard.norms) if shard.n else None, _ptr(queries.norms), int(id_offset),
+                                             int(seed_tiles), _ptr(keys), _ptr(ws), int(ws.numel()), self._stream())
+        if errors:
+            raise errors[0]
+        _capi.check(st, "lvs_search_sharded")
+        return keys
 
     def merge_keys(self, parts):
         """parts int64 [P, nq, k] -> [nq, k]."""

@@ -91,8 +91,11 @@ class HipVS(VS):
 
     def __init__(self, metric: int = METRIC_INNER_PRODUCT, storage: str = "auto", device: str | None = None,
                  shard: bool | str = False, max_resident: int = 4, backend=None, process_group=None,
-                 normalize: bool = False) -> None:
+                 normalize: bool = False, abi_exchange: bool = False) -> None:
         super().__init__()
+        # True: a row-sharded search runs its two exchanges from inside the C ABI (lvs_search_sharded, the process group's
+        # all-gather handed over as a callback) instead of from this file - same kernels, same order, same result
+        self.abi_exchange = bool(abi_exchange)
         if metric not in (METRIC_INNER_PRODUCT, METRIC_L2):
             raise ValueError("metric must be METRIC_INNER_PRODUCT or METRIC_L2")
         if storage not in ("auto", "fp16", "fp32"):
@@ -447,6 +450,16 @@ class HipVS(VS):
             if order is not None:
                 id_map = be.to_device(order)
             world = 1  # already complete on every rank: nothing left to merge
+        elif sub is None and world > 1 and self.abi_exchange and hasattr(be, "search_sharded") and k_eff <= 56:
+            # the same row-sharded search with its two exchanges issued from INSIDE the C ABI (lvs_search_sharded): the transport
+            # is this process group's all-gather, handed over as a callback
+            from . import _dist
+
+            per = -(-ent.n // world) if ent.n else 0
+            tiles = be.seed_tiles(queries.n, per, k_eff, ent.packed.mode, queries.mode) if hasattr(be, "seed_tiles") else 0
+            keys = be.search_sharded(ent.packed, queries, k_eff, self.metric, ent.lo, world, max(0, tiles),
+                                     lambda t: _dist.all_gather_rows(t, self._pg_corpus()))
+            world = 1  # merged already
         elif sub is None:
             keys = be.search_keys(ent.packed, queries, k_eff, self.metric, id_offset=ent.lo,
                                   seed_scores=self._pooled_seed_scores(ent, queries, k_eff, world))

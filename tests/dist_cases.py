@@ -132,6 +132,13 @@ def worker(rank, world, port, tmp, out_q, backend_kind):
         be.seed_scores = orig_seed
         res["seeded"] = (np.asarray(out.distances), np.asarray(out.indices), list(calls))
         res["seeded_small"] = (np.asarray(out_small.distances), np.asarray(out_small.indices))
+        if backend_kind == "hip":
+            # the same join with both exchanges issued from INSIDE the C ABI (lvs_search_sharded; this process group's all-gather is
+            # the callback it is handed): same kernels, same order - the same arrays
+            vabi = HipVS(backend=be, shard=True, abi_exchange=True)
+            vabi.index(None, xsb, os.path.join(tmp, "seeded_abi"), persist=False)
+            oa, ob = vabi(xsq, SEED_K), vabi(xb_small_q := xsq[:100], SEED_K)
+            res["seeded_abi"] = (np.asarray(oa.distances), np.asarray(oa.indices), np.asarray(ob.distances), np.asarray(ob.indices))
         # k-means on the row-sharded index: all rows, then a subset of rows
         xk = km_data()
         vk = HipVS(backend=be, shard=True)
@@ -218,6 +225,10 @@ def check(res, exact: bool):
         assert len(r["seeded"][2]) == 1 and r["seeded"][2][0] >= SEED_K  # ONE exchange, only for the big call
         same_topk(r["seeded_small"], (ref_seed[0][:100], ref_seed[1][:100]), SEED_K)
     assert np.array_equal(res[0]["seeded"][1], res[1]["seeded"][1])
+    for r in res:
+        if "seeded_abi" in r:  # HIP backend only: the exchange inside the C ABI gives the very same arrays
+            assert np.array_equal(r["seeded_abi"][0], r["seeded"][0]) and np.array_equal(r["seeded_abi"][1], r["seeded"][1])
+            assert np.array_equal(r["seeded_abi"][2], r["seeded_small"][0]) and np.array_equal(r["seeded_abi"][3], r["seeded_small"][1])
     ref_qf = oracle.flat_search(xb32, xq32[:299], 7)
     ref_qs = oracle.flat_search(xb32, xq32[:299], 7, ids=ids)
     ref_q1 = oracle.flat_search(xb32, xq32[:1], 5)
