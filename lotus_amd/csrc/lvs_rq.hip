@@ -18,10 +18,10 @@
 // Same operand roles (corpus rows = A, queries = B), same MFMA, same k-slice order 0 .. K/16 - 1 into one accumulator as every
 // other kernel of the library: keys are bit-identical to the list kernel's (tools/rq_probe.py: 150 shapes, both metrics,
 // k = 1 / 10 / 16, ragged last block, duplicate rows); thresholds are seeded by this kernel's own SEED mode.
-// Measured (1 M x 768 fp16, k = 10, same box, kernel ms; profiles/r08e_rq_probe.log, profiles/r07_tuning.md), structureless unit
-// rows - the worst case for thresholds: 97 / 128 queries 0.369 / 0.385 -> 0.274 / 0.281 ms (5.5 TB/s of corpus stream), 160 /
-// 192 / 256 queries 0.464 / 0.482 / 0.505 -> 0.393 / 0.404 / 0.420 ms; on the bench's data (planted neighbours) the legs
-// q128 / q192 / q256 read 0.294 / 0.403 / 0.427 ms = 65 / 48 / 45 % of the HBM roof (list kernel: 50 / 41 / 39 %).
+// Measured (1 M x 768 fp16, k = 10, same box, kernel ms; profiles/r08j_rq_probe.log, profiles/r07_tuning.md), structureless unit
+// rows - the worst case for thresholds: 97 / 128 queries 0.380 / 0.388 -> 0.278 / 0.284 ms (5.4 TB/s of corpus stream), 160 /
+// 192 / 256 queries 0.460 / 0.470 / 0.499 -> 0.379 / 0.381 / 0.398 ms; on the bench's data (planted neighbours) the legs
+// q128 / q192 / q256 read ~0.29 / 0.40 / 0.42 ms = 65 / 48 / 45 % of the HBM roof (list kernel: 50 / 41 / 39 %).
 // What bounds it (s_memtime stamps of an instrumented copy, tools/lvs_rq_instrumented.hip.txt, first complete version): per unit
 // of 24 MFMAs a wave spent ~1 180 cycles in the read + MFMA phase, ~550 issuing its share of the staging loads, ~500 at the
 // unit's barrier and ~800 per unit in the block epilogue (whose slow path was entered for every second to fourth block: a
@@ -49,6 +49,12 @@ __device__ inline float rq_max16(const f32x16& v) {
     const float a = rq_max3(v[0], v[1], v[2]), b = rq_max3(v[3], v[4], v[5]), c = rq_max3(v[6], v[7], v[8]);
     const float d = rq_max3(v[9], v[10], v[11]), e = rq_max3(v[12], v[13], v[14]);
     return rq_max3(rq_max3(a, b, c), rq_max3(d, e, v[15]), v[15]);
+}
+// which staging piece (0 .. lpw) goes out at MFMA step jj of a unit of uk steps: piece p at step p * uk / (lpw + 1) + 1
+constexpr int rq_piece_at(int jj, int uk, int lpw) {
+    for (int p = 0; p <= lpw; ++p)
+        if (jj == p * uk / (lpw + 1) + 1) return p;
+    return -1;
 }
 template <int N>
 __device__ inline void rq_lds_wait(half8& a) {
@@ -87,11 +93,11 @@ __device__ inline void rq_glds4(const void* gsrc, void* ldst) {
 template <int NJ, int UK, int WAVES, int NQW, int AD, int KCAP, bool SEED>
 __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void lvs_rq_kernel(const LvsRqArgs a) {
     constexpr bool RQ_SETPRIO = true;
+    constexpr bool SPREAD = true;  // the staging loads of a unit go out between the MFMAs of the unit being computed
     constexpr bool PHASED = false;  // WAVES == 8 measured slower (0.51 vs 0.46 ms at 256 queries): see the comment at the block loop
     using G = RqGeom<NJ, UK, WAVES, NQW, KCAP>;
     constexpr int RQ_WAVES = WAVES;
     constexpr int RQ_KCAP = KCAP;
-    constexpr int SIDE_EVERY = 1;  // blocks between two reads of the other workgroups' thresholds (a power of two; every 8th block measured 7 % slower)
     constexpr int NB_RING = G::NB_RING;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* ring = smem;
@@ -167,39 +173,60 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void lvs_rq_kernel(const Lvs
 #pragma unroll
     for (int i = 0; i < G::LPW; ++i) soff[i] = src_off(wave * G::LPW + i, lane, 31);
     soff[G::LPW] = src_off(UK, lane, 31);
-    auto issue_unit = [&](int n) {  // stage unit n (clamped: past the end the last unit is loaded again into a free slot)
-        const int nn = n < total_units ? n : total_units - 1;
-        const int blk = nn / G::U, kh = nn - blk * G::U;
-        const long long row0 = (b0 + blk) * 32;
-        char* dst = ring + (n % G::RING) * G::UB;
-        const char* src = xb + row0 * ldb2 + (long long)kh * UK * 32;
-        const int last = (int)(a.nb - 1 - row0);  // rows past the corpus' end (its last, partial block) re-read the last row
-        const bool extra = (n % WAVES) == wave;   // whose turn the unit's last, half-used load is
-        if (last >= 31) {
-#pragma unroll
-            for (int i = 0; i < G::LPW; ++i) glds16(src + soff[i], dst + (wave * G::LPW + i) * 1024);
-            if (extra) glds16(src + soff[G::LPW], dst + UK * 1024);
+    // Staging of unit n is issued in LPW + 1 PIECES (one 1 KiB load each; the last piece is the half-used load - when it is this
+    // wave's turn - and the block's side words): `issue_unit` issues them in one go (prologue), the unit loop spreads them between
+    // the MFMAs of the unit being computed, where their address arithmetic and issue slots cost nothing.
+    struct IssuePrep {
+        char* dst;
+        const char* src;
+        long long row0;
+        int last, blk, kh;
+        bool extra, real;
+    };
+    auto issue_prep = [&](int n) {  // wave-uniform: lives in scalar registers
+        IssuePrep pr;
+        const int nn = n < total_units ? n : total_units - 1;  // past the end the last unit is loaded again into a free slot
+        pr.blk = nn / G::U;
+        pr.kh = nn - pr.blk * G::U;
+        pr.row0 = (b0 + pr.blk) * 32;
+        pr.dst = ring + (n % G::RING) * G::UB;
+        pr.src = xb + pr.row0 * ldb2 + (long long)pr.kh * UK * 32;
+        pr.last = (int)(a.nb - 1 - pr.row0);  // rows past the corpus' end (its last, partial block) re-read the last row
+        pr.extra = (n % WAVES) == wave;       // whose turn the unit's last, half-used load is
+        pr.real = n < total_units;
+        return pr;
+    };
+    auto issue_piece = [&](auto pc, const IssuePrep& pr) {
+        constexpr int i = decltype(pc)::value;
+        if constexpr (i < G::LPW) {
+            const unsigned off = pr.last >= 31 ? soff[i] : src_off(wave * G::LPW + i, lane, pr.last);
+            glds16(pr.src + off, pr.dst + (wave * G::LPW + i) * 1024);
         } else {
-#pragma unroll
-            for (int i = 0; i < G::LPW; ++i) glds16(src + src_off(wave * G::LPW + i, lane, last), dst + (wave * G::LPW + i) * 1024);
-            if (extra) glds16(src + src_off(UK, lane, last), dst + UK * 1024);
-        }
-        if (!SEED && kh == 0 && n < total_units && (l2 || (blk & (SIDE_EVERY - 1)) == 0)) {
-            // the block's side words (inner product: every SIDE_EVERY-th block only - nothing but thresholds rides in them): lanes 0 .. 31 -> |y|^2 of its rows (any valid word under inner product), lanes 32 .. 63 ->
-            // the shared thresholds of this wave's queries.  NQW = 2: one DMA per query block, slots 64 words apart
-            int row = lane & 31;
-            row = row < last ? row : last;
-#pragma unroll
-            for (int qb = 0; qb < NQW; ++qb) {
-                const int q = qvalid[qb] ? qidx[qb] : 0;
-                const void* p = (lane < 32 && l2) ? (const void*)(a.bn + row0 + row) : (const void*)(a.gtau + q);
-                rq_glds4(p, side + ((blk % NB_RING) * NQW + qb) * 64);
+            if (pr.extra) {
+                const unsigned off = pr.last >= 31 ? soff[G::LPW] : src_off(UK, lane, pr.last);
+                glds16(pr.src + off, pr.dst + UK * 1024);
             }
-        } else if (SEED && l2 && kh == 0 && n < total_units) {
-            int row = lane & 31;
-            row = row < last ? row : last;
-            rq_glds4(a.bn + row0 + row, side + (blk % NB_RING) * NQW * 64);
+            if (!SEED && pr.kh == 0 && pr.real) {
+                // the block's side words: lanes 0 .. 31 -> |y|^2 of its rows (any valid word under inner product), lanes 32 .. 63 ->
+                // the shared thresholds of this wave's queries.  NQW = 2: one DMA per query block, slots 64 words apart
+                int row = lane & 31;
+                row = row < pr.last ? row : pr.last;
+#pragma unroll
+                for (int qb = 0; qb < NQW; ++qb) {
+                    const int q = qvalid[qb] ? qidx[qb] : 0;
+                    const void* p = (lane < 32 && l2) ? (const void*)(a.bn + pr.row0 + row) : (const void*)(a.gtau + q);
+                    rq_glds4(p, side + ((pr.blk % NB_RING) * NQW + qb) * 64);
+                }
+            } else if (SEED && l2 && pr.kh == 0 && pr.real) {
+                int row = lane & 31;
+                row = row < pr.last ? row : pr.last;
+                rq_glds4(a.bn + pr.row0 + row, side + (pr.blk % NB_RING) * NQW * 64);
+            }
         }
+    };
+    auto issue_unit = [&](int n) {
+        const IssuePrep pr = issue_prep(n);
+        static_for<G::LPW + 1>([&](auto pc) { issue_piece(pc, pr); });
     };
     // ---- fragment reads: lane (r = l & 31, h = l >> 5) reads bytes [(2 jj + h) * 16, + 16) of padded row r: lane base + jj * 32
     unsigned o_base = (unsigned)(unsigned long long)ring + (unsigned)((lane & 31) * G::ROWB + (lane >> 5) * 16);
@@ -213,7 +240,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void lvs_rq_kernel(const Lvs
     };
     // one unit of the current block: UK fragment reads (AD - 1 steps ahead of their MFMAs through a ring of AD registers) and
     // UK x NQW MFMAs; then the fragment base moves to the ring's next slot
-    auto mfma_phase = [&](auto khc) {
+    auto mfma_phase = [&](auto khc, const IssuePrep& pr) {
         constexpr int kh = decltype(khc)::value;
         half8 Af[AD];
         static_for<AD - 1>([&](auto jc) {
@@ -224,6 +251,10 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void lvs_rq_kernel(const Lvs
             constexpr int jj = decltype(jc)::value;
             constexpr int ahead = jj + AD - 1;
             if constexpr (ahead < UK) lds_read16<ahead * 32>(Af[ahead % AD], o_base);
+            if constexpr (SPREAD) {  // piece p of the NEXT-but-three unit's staging goes out at step p * UK / (LPW + 1) + 1
+                constexpr int piece = rq_piece_at(jj, UK, G::LPW);
+                if constexpr (piece >= 0) issue_piece(std::integral_constant<int, piece>{}, pr);
+            }
             __builtin_amdgcn_sched_barrier(0);
             rq_lds_wait<(ahead < UK) ? AD - 1 : (UK - 1 - jj)>(Af[jj % AD]);
 #pragma unroll
@@ -360,19 +391,22 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void lvs_rq_kernel(const Lvs
             // tells everybody that unit n - 1's slot is free again
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"((G::RING - 2) * G::LPW) : "memory");
             __builtin_amdgcn_s_barrier();
+            const IssuePrep pr = issue_prep(n + G::RING - 1);
             if (!late) {
-                issue_unit(n + G::RING - 1);
-                __builtin_amdgcn_sched_barrier(0);
+                if (!SPREAD) {
+                    static_for<G::LPW + 1>([&](auto pc) { issue_piece(pc, pr); });
+                    __builtin_amdgcn_sched_barrier(0);
+                }
                 if (kh == 0) zero_acc();
-                mfma_phase(khc);
+                mfma_phase(khc, pr);
             } else {
                 if (kh == 0) {
                     if (blk > 0) epilogue(blk - 1);
                     zero_acc();
                 }
-                mfma_phase(khc);
+                mfma_phase(khc, pr);
                 __builtin_amdgcn_sched_barrier(0);
-                issue_unit(n + G::RING - 1);
+                if (!SPREAD) static_for<G::LPW + 1>([&](auto pc) { issue_piece(pc, pr); });
             }
         });
         if (!late) epilogue(blk);
