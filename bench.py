@@ -337,7 +337,7 @@ def shared_inputs(np, dist, benchdata, world, rank, n, d, nq):
             for name, a in zip(("xb", "xq", "planted"), got):
                 np.save(os.path.join(shm, name + ".npy"), a)
             flag[0] = 1
-        except OSError:
+        except Exception:  # whatever went wrong on rank 0, the others must not wait for a file that will not come
             flag[0] = 0
     dist.broadcast_object_list(flag, src=0)  # also the barrier the readers wait at
     if not flag[0]:

@@ -38,6 +38,7 @@ def _ptr(t) -> int:
 class HipBackend:
     PACK_CHUNK_ROWS = 262144
     NEAREST3_WS_BUDGET = 2 << 30  # bytes of scratch one lvs_nearest3 call may ask for; more queries go through in chunks
+    MAX_STREAM_WORKSPACES = 4     # scratch buffers kept at a time (one per stream that has made a call)
 
     def __init__(self, device=None):
         import torch
@@ -78,6 +79,11 @@ class HipBackend:
         key = self._stream()
         ws = self._ws.get(key)
         if ws is None or ws.numel() < nbytes:
+            if ws is None and len(self._ws) >= self.MAX_STREAM_WORKSPACES:
+                # side streams come and go (one per k-means call): keep the default stream's buffer, drop the others - a dropped
+                # buffer goes back to the allocator's pool of the stream it was allocated on, so work still queued there is safe
+                for k_old in [k_ for k_ in self._ws if k_ != 0]:
+                    del self._ws[k_old]
             ws = self._ws[key] = self.torch.empty(max(nbytes, 1 << 20), dtype=self.torch.uint8, device=self.device)
         return ws
 
