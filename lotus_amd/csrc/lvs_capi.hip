@@ -676,6 +676,17 @@ static inline int64_t lvs_stream_parts_bytes(int64_t nq, int k) {
                             (k > 0 ? k : 1) * 8, 256);
 }
 
+// ... and for the register-resident-queries kernel beyond 256 queries: `groups` query groups x at most 256 / groups corpus
+// ranges = at most 65 536 lists (+ slack), and as many sample scores
+static inline int64_t lvs_rq_parts_bytes(int64_t nq, int k) {
+    if (nq <= LVS_STREAM_MAXQ) return lvs_stream_parts_bytes(nq, k);
+    return lvs_round_up((int64_t)(65536 + 8 * nq) * (k > 0 ? k : 1) * 8, 256);
+}
+static inline int64_t lvs_rq_seed_bytes(int64_t nq) {
+    if (nq <= LVS_STREAM_MAXQ) return lvs_round_up((int64_t)(nq > 0 ? nq : 1) * (LVS_STREAM_MAXWG + 8) * 4, 256);
+    return lvs_round_up((int64_t)(65536 + 8 * nq) * 4, 256);
+}
+
 struct Plan {
     int dpad, nkd, nk, ldb, ldq, nseg;
     int seg_q[3], seg_c[3];
@@ -859,6 +870,8 @@ int make_plan(int64_t nq, int64_t nb, int32_t d, int32_t xb_pack, int32_t xq_pac
     // scores of the sample that seeds its thresholds
     if (nq <= LVS_STREAM_MAXQ && k <= LVS_KPASS)
         off += lvs_stream_parts_bytes(nq, k) + lvs_round_up((int64_t)(nq > 0 ? nq : 1) * (LVS_STREAM_MAXWG + 8) * 4, 256);
+    else if (nq <= LVS_RQ_MAXQ && k <= LVS_KPASS)  // lvs_rq_kernel in query groups
+        off += lvs_rq_parts_bytes(nq, k) + lvs_rq_seed_bytes(nq);
     p.off_seed = off;  // [sample tiles][nq] per-tile best scores of a seeded list launch (tile_seed_tiles)
     if (p.npass == 1) off += lvs_round_up((int64_t)(nq > 0 ? nq : 1) * tile_seed_tiles(nq, nb, k) * 4, 256);
     p.total = off;
@@ -1230,8 +1243,9 @@ static int32_t flat_search_impl(const void* xb, int32_t xb_pack, int64_t nb, con
     }
 #endif
 
-    // 97 .. 256 queries, one K segment of fp16 k-slices: the queries live in REGISTERS (lvs_rq.hip), the corpus streams through
-    // LDS once - between the HBM-bound batches below and the joins the list kernel is built for
+    // 97 .. 256 queries (and up to 4 096 in groups of 256), one K segment of fp16 k-slices: the queries live in REGISTERS
+    // (lvs_rq.hip), the corpus streams through LDS once - between the HBM-bound batches below and the joins the list kernel is
+    // built for
     if (lvs_tune("LVS_RQ", 1) != 0 && p.nseg == 1 && p.npass == 1 && !pred && g_band.kc == 0 && lvs_rq_fits(nq, nb, p.dpad, k)) {
         LvsRqArgs ra;
         memset(&ra, 0, sizeof(ra));
@@ -1252,10 +1266,12 @@ static int32_t flat_search_impl(const void* xb, int32_t xb_pack, int64_t nb, con
         // thresholds seeded from a sample of the rows scanned by this kernel's own SEED mode (bit-identical scores; see the
         // streaming path below for why a caller's pooled sample scores are not used)
         int64_t sample = nb / 8 / 1024 * 1024;
-        const int64_t sample_cap = lvs_tune("LVS_RQ_SAMPLE", LVS_RQ_SEED_ROWS);
+        // (eight groups or more: a workgroup sees 30 000+ rows and fills its own lists - a quarter of the sample costs the main
+        // pass 1 % and saves 3 % of the call; profiles/r09b_rq_groups_sample_probe.log)
+        const int64_t sample_cap = lvs_tune("LVS_RQ_SAMPLE", nq > 7 * LVS_RQ_GROUPQ ? LVS_RQ_SEED_ROWS / 4 : LVS_RQ_SEED_ROWS);
         if (sample > sample_cap) sample = sample_cap;
         if (sample >= 4096 && lvs_tune("LVS_STREAM_SEED", 1) != 0) {
-            float* seeds = (float*)((char*)partial + lvs_stream_parts_bytes(nq, k));  // [ranges][nq]
+            float* seeds = (float*)((char*)partial + lvs_rq_parts_bytes(nq, k));  // [ranges][nq]
             LvsRqArgs rs = ra;
             rs.nb = sample;
             rs.seed_out = seeds;

@@ -109,7 +109,16 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void lvs_rq_kernel(const Lvs
     // workgroups have left them - read every block, for free, instead of through a vector load that would drain the staging
     float* side = (float*)(smem + G::RING * G::UB + (size_t)WAVES * NQW * 32 * RQ_KCAP * 8) + wave * (NB_RING * 64);
     const int k = a.k;
-    const int range = blockIdx.x;
+    // Beyond 256 queries the call is cut into GROUPS of 256: a corpus range is scanned by `groups` sibling workgroups, one per
+    // group.  Workgroup b lands on XCD b % 8; the siblings of a range take consecutive slots of ONE XCD, so the range is read
+    // from HBM once and by the siblings through that XCD's L2 (they run in step: same rows, same work)
+    int range = blockIdx.x, qbase = 0;
+    if (a.groups > 1) {
+        const int s = blockIdx.x >> 3;
+        range = (s / a.groups) * 8 + (blockIdx.x & 7);
+        qbase = (s % a.groups) * (WAVES * NQW * 32);
+        if (range >= a.nparts) return;  // (the grid is rounded up to whole XCD rows)
+    }
     const _Float16* xq = (const _Float16*)a.xq;
     const char* xb = (const char*)a.xb;
     const long long ldb2 = a.ldb * 2;  // bytes per corpus row
@@ -123,7 +132,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void lvs_rq_kernel(const Lvs
     uint32_t gord[NQW];
 #pragma unroll
     for (int qb = 0; qb < NQW; ++qb) {
-        qidx[qb] = (qb * RQ_WAVES + wave) * 32 + (lane & 31);
+        qidx[qb] = qbase + (qb * RQ_WAVES + wave) * 32 + (lane & 31);
         qvalid[qb] = qidx[qb] < a.nq;
         const int qrow = qvalid[qb] ? qidx[qb] : a.nq - 1;
         const _Float16* qp = xq + (long long)qrow * a.ldq + (lane >> 5) * 8;
@@ -145,11 +154,12 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void lvs_rq_kernel(const Lvs
     const long long nblocks = (a.nb + 31) / 32;
     const long long b0 = (long long)range * a.blocks_per_wg;
     const long long b1 = b0 + a.blocks_per_wg < nblocks ? b0 + a.blocks_per_wg : nblocks;
-    if (b0 >= b1) {  // an empty range still owns its slice of the output
+    if (b0 >= b1) {  // an empty range still owns its slice of the output (its group's queries)
+        const int q1 = a.nq < qbase + WAVES * NQW * 32 ? a.nq : qbase + WAVES * NQW * 32;
         if (!SEED) {
-            for (int i = tid; i < a.nq * k; i += RQ_WAVES * 64) a.out[(long long)range * a.nq * k + i] = 0;
+            for (int i = qbase * k + tid; i < q1 * k; i += RQ_WAVES * 64) a.out[(long long)range * a.nq * k + i] = 0;
         } else {
-            for (int i = tid; i < a.nq; i += RQ_WAVES * 64) a.seed_out[(long long)range * a.nq + i] = -INFINITY;
+            for (int i = qbase + tid; i < q1; i += RQ_WAVES * 64) a.seed_out[(long long)range * a.nq + i] = -INFINITY;
         }
         return;
     }
@@ -424,7 +434,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void lvs_rq_kernel(const Lvs
     __builtin_amdgcn_wave_barrier();
     for (int i = lane; i < NQW * 32 * k; i += 64) {
         const int ql = i / k, j = i - ql * k;
-        const int q = ((ql >> 5) * RQ_WAVES + wave) * 32 + (ql & 31);
+        const int q = qbase + ((ql >> 5) * RQ_WAVES + wave) * 32 + (ql & 31);
         if (q < a.nq) a.out[((long long)range * a.nq + q) * k + j] = mylists[ql * RQ_KCAP + j];
     }
     if (lane < 32) {
@@ -450,6 +460,7 @@ hipError_t rq_launch_k(const LvsRqArgs& a, int grid, hipStream_t stream) {
         if (e != hipSuccess) return e;
         attr.set(dev, lds);
     }
+    if (a.groups > 1 && WAVES * NQW * 32 != LVS_RQ_GROUPQ) return hipErrorInvalidValue;  // groups are the eight-wave variant's
     hipLaunchKernelGGL((lvs_rq_kernel<NJ, UK, WAVES, NQW, AD, KCAP, SEED>), dim3(grid), dim3(WAVES * 64), lds, stream, a);
     return hipGetLastError();
 }
@@ -470,7 +481,7 @@ hipError_t rq_launch_shape(const LvsRqArgs& a, int grid, hipStream_t stream) {
 #endif
     if (a.nq <= 128) return rq_launch_one<NJ, UK, 4, 1, 6, SEED>(a, grid, stream);
 #ifdef LVS_TUNING
-    if (lvs_tune("LVS_RQ_MODE", 0) == 2) return rq_launch_one<NJ, UK, 4, 2, 3, SEED>(a, grid, stream);
+    if (a.groups == 1 && lvs_tune("LVS_RQ_MODE", 0) == 2) return rq_launch_one<NJ, UK, 4, 2, 3, SEED>(a, grid, stream);
 #endif
     // (the depth of the fragment read-ahead makes no difference with two waves per SIMD - 2 / 3 / 4 registers sets measured
     // alike, profiles/r07_tuning.md - and at d = 768 the B fragments leave 64 registers for everything else: two sets)
@@ -479,28 +490,41 @@ hipError_t rq_launch_shape(const LvsRqArgs& a, int grid, hipStream_t stream) {
 
 }  // namespace
 
+// Corpus ranges a launch of `groups` query groups uses at most: every range has one workgroup per group, all on one XCD
+// (32 CUs), a workgroup fills a CU
+static int rq_max_ranges(int groups) { return groups <= 1 ? 256 : 8 * (32 / groups); }
+
 // Does the register-resident-queries kernel take this call?  fp16 k-slices of one K segment (d padded to 256, 384, 512 or
-// 768 halfs), 97 .. 256 queries, k <= 16, a corpus long enough to give every CU a few blocks.
+// 768 halfs), k <= 16, a corpus long enough to give every CU a few blocks, and 97 .. 256 queries - or up to LVS_RQ_MAXQ in
+// groups of 256 when the groups' workgroups fill (nearly) every CU: 2 .. 8, 10 or 16 groups.
 bool lvs_rq_fits(int64_t nq, int64_t nb, int dpad, int k) {
     const int nj = dpad / 16;
-    return nq > 96 && nq <= LVS_RQ_MAXQ && k >= 1 && k <= RQ_KMAX && nb >= 32768 && (nj == 16 || nj == 24 || nj == 32 || nj == 48);
+    if (!(nq > 96 && nq <= LVS_RQ_MAXQ && k >= 1 && k <= RQ_KMAX && nb >= 32768 && (nj == 16 || nj == 24 || nj == 32 || nj == 48))) return false;
+    const int groups = (int)((nq + LVS_RQ_GROUPQ - 1) / LVS_RQ_GROUPQ);
+    if (groups == 1) return true;
+    return groups <= lvs_tune("LVS_RQ_MAXG", LVS_RQ_MAXQ / LVS_RQ_GROUPQ) && groups * rq_max_ranges(groups) >= 224 &&
+           nb >= (int64_t)32768 * groups;
 }
 
 // On return a.nparts = candidate lists per query in a.out ([nparts][nq][k]) (SEED: rows of a.seed_out [nparts][nq]).
 hipError_t lvs_rq_launch(LvsRqArgs& a, int dpad, hipStream_t stream) {
     const int64_t nblocks = (a.nb + 31) / 32;
-    int64_t ranges = 256;
+    a.groups = (a.nq + LVS_RQ_GROUPQ - 1) / LVS_RQ_GROUPQ;
+    if (a.groups < 1) a.groups = 1;
+    int64_t ranges = rq_max_ranges(a.groups);
+    if (ranges < 1) return hipErrorInvalidValue;
     if (ranges > (nblocks + 3) / 4) ranges = (nblocks + 3) / 4;
     if (ranges < 1) ranges = 1;
     a.blocks_per_wg = (int)((nblocks + ranges - 1) / ranges);
     ranges = (nblocks + a.blocks_per_wg - 1) / a.blocks_per_wg;
     a.nparts = (int)ranges;
+    const int grid = a.groups == 1 ? (int)ranges : 8 * a.groups * (int)((ranges + 7) / 8);
     const bool seed = a.seed_out != nullptr;
     switch (dpad / 16) {
-        case 48: return seed ? rq_launch_shape<48, 24, true>(a, (int)ranges, stream) : rq_launch_shape<48, 24, false>(a, (int)ranges, stream);
-        case 32: return seed ? rq_launch_shape<32, 32, true>(a, (int)ranges, stream) : rq_launch_shape<32, 32, false>(a, (int)ranges, stream);
-        case 24: return seed ? rq_launch_shape<24, 24, true>(a, (int)ranges, stream) : rq_launch_shape<24, 24, false>(a, (int)ranges, stream);
-        case 16: return seed ? rq_launch_shape<16, 16, true>(a, (int)ranges, stream) : rq_launch_shape<16, 16, false>(a, (int)ranges, stream);
+        case 48: return seed ? rq_launch_shape<48, 24, true>(a, grid, stream) : rq_launch_shape<48, 24, false>(a, grid, stream);
+        case 32: return seed ? rq_launch_shape<32, 32, true>(a, grid, stream) : rq_launch_shape<32, 32, false>(a, grid, stream);
+        case 24: return seed ? rq_launch_shape<24, 24, true>(a, grid, stream) : rq_launch_shape<24, 24, false>(a, grid, stream);
+        case 16: return seed ? rq_launch_shape<16, 16, true>(a, grid, stream) : rq_launch_shape<16, 16, false>(a, grid, stream);
         default: return hipErrorInvalidValue;
     }
 }

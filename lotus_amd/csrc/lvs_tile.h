@@ -214,7 +214,8 @@ struct LvsStreamArgs {
 };
 
 // ---- lvs_rq.hip: 97 .. 256 queries with the queries resident in registers ----
-#define LVS_RQ_MAXQ 256
+#define LVS_RQ_GROUPQ 256   // queries of one workgroup (eight waves x 32)
+#define LVS_RQ_MAXQ 4096    // most queries per call: 16 groups
 #define LVS_RQ_SEED_ROWS 65536  // sample rows (the first of the shard) whose scores seed the thresholds: a workgroup sees ~4 000
                                 // rows, its lists never fill, so the seed IS its threshold - 64 k rows beat 32 k by 4 % per call, 128 k tie
 struct LvsRqArgs {
@@ -230,6 +231,7 @@ struct LvsRqArgs {
     int nq, k, metric;
     int blocks_per_wg;  // 32-row blocks per corpus range (set by lvs_rq_launch)
     int nparts;         // out: corpus ranges of the launch
+    int groups;         // out: query groups of LVS_RQ_GROUPQ (sibling workgroups per corpus range)
 };
 bool lvs_rq_fits(int64_t nq, int64_t nb, int dpad, int k);
 hipError_t lvs_rq_launch(LvsRqArgs& a, int dpad, hipStream_t stream);

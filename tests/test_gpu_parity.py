@@ -464,6 +464,13 @@ def test_seeded_streaming_search_with_duplicates_across_the_sample_boundary(hip_
     (256, 66_000, 256, 1, F16, L2),      # k = 1 through the lists
     (200, 40_000, 768, 13, F16, IP),     # 16-slot lists at d = 768 on eight waves (the tightest register budget)
     (97, 33_000, 200, 10, F16, L2),      # d padded from 200 to 256, a corpus barely long enough
+    # ... and 257 .. 4 096 queries in groups of 256 (sibling workgroups of a corpus range on one XCD)
+    (300, 70_001, 256, 10, F16, IP),     # two groups, the second one 44 queries; 128 ranges, ragged last block
+    (512, 66_000, 384, 16, F16, L2),     # two full groups, 16-slot lists
+    (700, 100_000, 768, 10, F16, IP),    # three groups: 80 ranges x 3 = 240 workgroups, the grid rounded up to XCD rows
+    (1300, 200_000, 256, 5, F16, L2),    # six groups x 40 ranges
+    (2304, 300_000, 256, 12, F16, IP),   # nine groups: 216 workgroups would idle too many CUs - the list kernel keeps it
+    (4000, 530_000, 200, 10, F16, IP),   # sixteen groups x 16 ranges, the last group 160 queries
 ])
 def test_seeded_list_kernel(hip_backend, nq, nb, d, k, mode, metric):
     """Launches with few query tiles seed their thresholds from a sample (LVS_MODE_SEED + k-th largest per-tile maximum)

@@ -41,6 +41,7 @@ for w in $what; do
     fp32stride) timeout -k 10 400 python tools/fp32_stride_probe.py > $out/fp32stride.log 2>&1; cat $out/fp32stride.log | tail -80 ;;
     kmskew) timeout -k 10 600 python tools/km_skew_probe.py > $out/kmskew.log 2>&1; grep -v "^\[" $out/kmskew.log | tail -30 ;;
     rq) timeout -k 10 600 python tools/rq_probe.py > $out/rq.log 2>&1; grep -v "^\[" $out/rq.log | tail -40 ;;
+    rqg) timeout -k 10 900 python tools/rq_groups_probe.py > $out/rqg.log 2>&1; grep -v "^\[\|amdgpu.ids" $out/rqg.log | tail -50 ;;
     rqab) timeout -k 10 600 python tools/rq_ablate.py > $out/rqab.log 2>&1; grep -v "amdgpu.ids" $out/rqab.log | tail -30 ;;
     bench2self) LOTUS_BENCH_REHEARSAL=1 timeout -k 10 900 python bench.py --gpus 2 --steps 3 --warmup 1 > $out/bench2.json 2> $out/bench2.err; tail -c 2500 $out/bench2.json; echo; grep -v "amdgpu.ids\|OMP_NUM\|\*\*\*" $out/bench2.err | tail -5 ;;
     smoke) timeout -k 10 300 python -c 'import __graft_entry__ as g; g.smoke()' > $out/smoke.log 2>&1; tail -3 $out/smoke.log ;;
