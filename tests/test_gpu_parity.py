@@ -469,7 +469,7 @@ def test_seeded_streaming_search_with_duplicates_across_the_sample_boundary(hip_
     (512, 66_000, 384, 16, F16, L2),     # two full groups, 16-slot lists
     (700, 100_000, 768, 10, F16, IP),    # three groups: 80 ranges x 3 = 240 workgroups, the grid rounded up to XCD rows
     (1300, 200_000, 256, 5, F16, L2),    # six groups x 40 ranges
-    (2304, 300_000, 256, 12, F16, IP),   # nine groups: 216 workgroups would idle too many CUs - the list kernel keeps it
+    (2304, 100_000, 256, 12, F16, IP),   # nine groups: 216 workgroups would idle too many CUs - the list kernel keeps it
     (4000, 530_000, 200, 10, F16, IP),   # sixteen groups x 16 ranges, the last group 160 queries
 ])
 def test_seeded_list_kernel(hip_backend, nq, nb, d, k, mode, metric):
@@ -484,9 +484,14 @@ def test_seeded_list_kernel(hip_backend, nq, nb, d, k, mode, metric):
     if metric == L2:
         xb, xq = xb * 1.3, xq * 1.3
     D, I, _ = _run(hip_backend, xb, xq, k, mode, metric)
-    Dr, Ir = oracle.flat_search(_stored(xb, mode), _stored(xq, mode), k, metric)
+    # the oracle answers every query - or, where that would take the CPU minutes (the sixteen-group row), the first 300 (the
+    # planted ties, the first group boundary), the last 200 (the ragged last group) and every 16th in between
+    sel = np.arange(nq)
+    if nq * nb * d > 2e11:
+        sel = np.unique(np.concatenate([np.arange(300), np.arange(300, nq - 200, 16), np.arange(nq - 200, nq)]))
+    Dr, Ir = oracle.flat_search(_stored(xb, mode), _stored(xq[sel], mode), k, metric)
     atol = 1e-5 if metric == IP else 4e-5
-    err, hard, recall = synth.compare_topk(Dr, Ir, D, I, atol=atol)
+    err, hard, recall = synth.compare_topk(Dr, Ir, D[sel], I[sel], atol=atol)
     assert err <= atol and hard == 0 and recall >= 0.9999, (err, hard, recall)
     # exact ties come back lowest id first, as the oracle's strict-better insertion leaves them
     same = np.concatenate([[40, nb // 2 + 40], np.arange(nb - 200, nb)])  # 202 identical rows
