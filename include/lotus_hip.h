@@ -198,7 +198,12 @@ int32_t lvs_merge_keys(const uint64_t* parts, int32_t nparts, int64_t nq, int32_
  *   lvs_merge_keys                                                                 -> out_keys [nq][k], identical on every rank
  * Every rank must pass the same nq, d, k, metric, pack modes and seed_tiles (= lvs_flat_search_seed_tiles(nq, NOMINAL shard
  * rows, k), or 0 for no pooled thresholds); nb_local may differ per rank and may be 0 (an empty shard contributes empty lists).
- * Equal to the single-launch search of the concatenated shards key for key (keys are a total order). ---- */
+ * Equal to the single-launch search of the concatenated shards key for key (keys are a total order).
+ * Errors and the collective: arguments, shapes and the workspace size are checked BEFORE the first exchange, so a rank
+ * with bad arguments returns without having entered a collective its peers would wait in - but the check is per rank: if
+ * the ranks disagree (one passes a short workspace) the others still enter the all-gather.  Any non-OK return after that
+ * point (a failed launch, an error from the all-gather) leaves the communicator in an undefined collective state: the
+ * caller must abort it, as after any failed NCCL collective. ---- */
 /* the all-gather the library calls: `send` [bytes_per_rank] of this rank -> `recv` [nranks][bytes_per_rank] in rank order,
  * device pointers, enqueued on `stream` (or finished before returning); 0 on success */
 typedef int32_t (*lvs_all_gather_fn)(void* ctx, const void* send, void* recv, int64_t bytes_per_rank, void* stream);

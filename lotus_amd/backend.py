@@ -610,8 +610,7 @@ class HipBackend:
             # Its scratch is 20 B per (corpus tile, query): the queries go through in chunks that keep it below a fixed budget
             # (10 M rows x 16 384 centroids would ask for 12.8 GB in one call - ADVICE r04); results are per query, so
             # chunking changes nothing
-            per_q = max(1, int(self.lib.lvs_nearest3_workspace_bytes(1 << 20, corpus.n, corpus.d)) >> 20)
-            step = max(1 << 16, (self.NEAREST3_WS_BUDGET // per_q) >> 16 << 16)
+            step = self._nearest3_step(corpus)
             if nq <= step:
                 return self._nearest3(corpus, queries, metric, id_offset, stats, exact_scores, corpus_stats, bounds, coef, dpad, plain)
             for q0 in range(0, nq, step):
@@ -786,14 +785,35 @@ class HipBackend:
             return {"keys_now": self.nearest(corpus, queries, metric, id_offset=id_offset, exact_scores=exact_scores,
                                              corpus_stats=corpus_stats), "queries": queries}
         coef, dpad = self._nearest_coef(corpus, queries, metric)
-        return self._nearest3_begin(corpus, queries, metric, id_offset, exact_scores, corpus_stats, None, coef, dpad,
-                                    dict(id_offset=id_offset, one_pass=False))
+        plain = dict(id_offset=id_offset, one_pass=False)
+        step = self._nearest3_step(corpus)
+        if queries.n <= step:
+            return self._nearest3_begin(corpus, queries, metric, id_offset, exact_scores, corpus_stats, None, coef, dpad, plain)
+        # the same scratch budget as nearest() (a 3 M-row range x 16 384 centroids asked for 3.8 GB in one call):
+        # the queries go through in chunks, one handle each; the launches of chunk i + 1 reuse the stream's scratch behind chunk
+        # i's (same stream: ordered)
+        chunks = []
+        for q0 in range(0, queries.n, step):
+            q1 = min(queries.n, q0 + step)
+            chunks.append((q0, q1, self._nearest3_begin(corpus, self.slice_rows(queries, q0, q1), metric, id_offset, exact_scores,
+                                                        corpus_stats, None, coef, dpad, plain)))
+        return {"chunks": chunks, "queries": queries}
+
+    def _nearest3_step(self, corpus) -> int:
+        """Most queries one ``lvs_nearest3`` call may take inside the scratch budget (20 B per corpus tile and query)."""
+        per_q = max(1, int(self.lib.lvs_nearest3_workspace_bytes(1 << 20, corpus.n, corpus.d)) >> 20)
+        return max(1 << 16, (self.NEAREST3_WS_BUDGET // per_q) >> 16 << 16)
 
     def nearest_finish(self, handle, stats: dict | None = None):
         if "keys_now" in handle:
             if stats is not None:
                 stats["queries"] = stats.get("queries", 0) + handle["queries"].n
             return handle["keys_now"]
+        if "chunks" in handle:
+            keys = self.torch.empty((handle["queries"].n, 1), dtype=self.torch.int64, device=self.device)
+            for q0, q1, h in handle["chunks"]:
+                keys[q0:q1] = self._nearest3_finish(h, stats)
+            return keys
         return self._nearest3_finish(handle, stats)
 
     def kmeans_centroid_shift(self, c_old, c_new):

@@ -870,8 +870,10 @@ int make_plan(int64_t nq, int64_t nb, int32_t d, int32_t xb_pack, int32_t xq_pac
     // scores of the sample that seeds its thresholds
     if (nq <= LVS_STREAM_MAXQ && k <= LVS_KPASS)
         off += lvs_stream_parts_bytes(nq, k) + lvs_round_up((int64_t)(nq > 0 ? nq : 1) * (LVS_STREAM_MAXWG + 8) * 4, 256);
-    else if (nq <= LVS_RQ_MAXQ && k <= LVS_KPASS)  // lvs_rq_kernel in query groups
-        off += lvs_rq_parts_bytes(nq, k) + lvs_rq_seed_bytes(nq);
+    else if (k <= LVS_RQ_KMAX) {  // lvs_rq_kernel in query groups, beyond LVS_RQ_MAXQ queries one chunk of that many at a time
+        const int64_t cq = nq <= LVS_RQ_MAXQ ? nq : LVS_RQ_MAXQ;
+        off += lvs_rq_parts_bytes(cq, k) + lvs_rq_seed_bytes(cq);
+    }
     p.off_seed = off;  // [sample tiles][nq] per-tile best scores of a seeded list launch (tile_seed_tiles)
     if (p.npass == 1) off += lvs_round_up((int64_t)(nq > 0 ? nq : 1) * tile_seed_tiles(nq, nb, k) * 4, 256);
     p.total = off;
@@ -1245,54 +1247,63 @@ static int32_t flat_search_impl(const void* xb, int32_t xb_pack, int64_t nb, con
 
     // 97 .. 256 queries (and up to 4 096 in groups of 256), one K segment of fp16 k-slices: the queries live in REGISTERS
     // (lvs_rq.hip), the corpus streams through LDS once - between the HBM-bound batches below and the joins the list kernel is
-    // built for
-    if (lvs_tune("LVS_RQ", 1) != 0 && p.nseg == 1 && p.npass == 1 && !pred && g_band.kc == 0 && lvs_rq_fits(nq, nb, p.dpad, k)) {
-        LvsRqArgs ra;
-        memset(&ra, 0, sizeof(ra));
-        ra.xb = xb;
-        ra.xq = xq;
-        ra.bn = xb_norms_sq;
-        ra.qn = xq_norms_sq;
-        ra.row_ids = row_ids;
-        ra.gtau = gtau;
-        ra.out = partial;
-        ra.nb = nb;
-        ra.ldb = p.ldb;
-        ra.ldq = p.ldq;
-        ra.id_offset = id_offset;
-        ra.nq = (int)nq;
-        ra.k = k;
-        ra.metric = metric;
-        // thresholds seeded from a sample of the rows scanned by this kernel's own SEED mode (bit-identical scores; see the
-        // streaming path below for why a caller's pooled sample scores are not used)
-        int64_t sample = nb / 8 / 1024 * 1024;
-        // (eight groups or more: a workgroup sees 30 000+ rows and fills its own lists - a quarter of the sample costs the main
-        // pass 1 % and saves 3 % of the call; profiles/r09b_rq_groups_sample_probe.log)
-        const int64_t sample_cap = lvs_tune("LVS_RQ_SAMPLE", nq > 7 * LVS_RQ_GROUPQ ? LVS_RQ_SEED_ROWS / 4 : LVS_RQ_SEED_ROWS);
-        if (sample > sample_cap) sample = sample_cap;
-        if (sample >= 4096 && lvs_tune("LVS_STREAM_SEED", 1) != 0) {
-            float* seeds = (float*)((char*)partial + lvs_rq_parts_bytes(nq, k));  // [ranges][nq]
-            LvsRqArgs rs = ra;
-            rs.nb = sample;
-            rs.seed_out = seeds;
-            LVS_HIP_CHECK(lvs_rq_launch(rs, p.dpad, st));
-            hipLaunchKernelGGL(seed_kth_kernel, dim3((unsigned)lvs_ceil_div(nq, 4)), dim3(256), 0, st, (const float*)seeds,
-                               rs.nparts, (long long)nq, k, gtau);  // writes every gtau[q]
+    // built for.  (r6) Beyond 4 096 queries the same launch repeats per CHUNK of 4 096 queries (16 groups x 16 corpus ranges):
+    // a query belongs to one chunk, so every chunk is a complete search of its own (own seeds, own lists, own merge).
+    const bool rq_ok = lvs_tune("LVS_RQ", 1) != 0 && p.nseg == 1 && p.npass == 1 && !pred && g_band.kc == 0;
+    const bool rq_join = rq_ok && nq > LVS_RQ_MAXQ && lvs_tune("LVS_RQ_JOIN", LVS_RQ_JOIN_DEFAULT) != 0 &&
+                         lvs_rq_fits(LVS_RQ_MAXQ, nb, p.dpad, k);
+    if (rq_join || (rq_ok && lvs_rq_fits(nq, nb, p.dpad, k))) {
+        const int64_t chunk = lvs_tune("LVS_RQ_CHUNK", LVS_RQ_MAXQ) / LVS_RQ_GROUPQ * LVS_RQ_GROUPQ;
+        for (int64_t c0 = 0; c0 < nq; c0 += chunk) {
+            const int64_t cn = nq - c0 < chunk ? nq - c0 : chunk;
+            LvsRqArgs ra;
+            memset(&ra, 0, sizeof(ra));
+            ra.xb = xb;
+            ra.xq = (const _Float16*)xq + c0 * p.ldq;
+            ra.bn = xb_norms_sq;
+            ra.qn = xq_norms_sq ? xq_norms_sq + c0 : nullptr;
+            ra.row_ids = row_ids;
+            ra.gtau = gtau + c0;
+            ra.out = partial;
+            ra.nb = nb;
+            ra.ldb = p.ldb;
+            ra.ldq = p.ldq;
+            ra.id_offset = id_offset;
+            ra.nq = (int)cn;
+            ra.k = k;
+            ra.metric = metric;
+            // thresholds seeded from a sample of the rows scanned by this kernel's own SEED mode (bit-identical scores; see the
+            // streaming path below for why a caller's pooled sample scores are not used)
+            int64_t sample = nb / 8 / 1024 * 1024;
+            // (eight groups or more: a workgroup sees 30 000+ rows and fills its own lists - a quarter of the sample costs the main
+            // pass 1 % and saves 3 % of the call; profiles/r09b_rq_groups_sample_probe.log)
+            const int64_t sample_cap = lvs_tune("LVS_RQ_SAMPLE", cn > 7 * LVS_RQ_GROUPQ ? LVS_RQ_SEED_ROWS / 4 : LVS_RQ_SEED_ROWS);
+            if (sample > sample_cap) sample = sample_cap;
+            if (sample >= 4096 && lvs_tune("LVS_STREAM_SEED", 1) != 0) {
+                float* seeds = (float*)((char*)partial + lvs_rq_parts_bytes(cn, k));  // [ranges][cn]
+                LvsRqArgs rs = ra;
+                rs.nb = sample;
+                rs.seed_out = seeds;
+                LVS_HIP_CHECK(lvs_rq_launch(rs, p.dpad, st));
+                hipLaunchKernelGGL(seed_kth_kernel, dim3((unsigned)lvs_ceil_div(cn, 4)), dim3(256), 0, st, (const float*)seeds,
+                                   rs.nparts, (long long)cn, k, gtau + c0);  // writes every gtau[q] of the chunk
+                LVS_HIP_CHECK(hipGetLastError());
+            } else {
+                LVS_HIP_CHECK(hipMemsetAsync(gtau + c0, 0, (size_t)cn * 4, st));
+            }
+            {
+                ScopedKernelTimer timer(st);
+                LVS_HIP_CHECK(lvs_rq_launch(ra, p.dpad, st));
+            }
+            u64* okeys = (u64*)out_keys + c0 * k;
+            if (ra.nparts >= 16)
+                hipLaunchKernelGGL(merge_keys_wide_kernel, dim3((unsigned)cn), dim3(1024), 0, st, partial, ra.nparts, (long long)cn, k,
+                                   okeys, (long long)k);
+            else
+                hipLaunchKernelGGL(merge_keys_kernel, dim3((unsigned)lvs_ceil_div(cn, 4)), dim3(256), 0, st, partial, ra.nparts,
+                                   (long long)cn, k, okeys, (long long)k, (const uint32_t*)nullptr);
             LVS_HIP_CHECK(hipGetLastError());
-        } else {
-            LVS_HIP_CHECK(hipMemsetAsync(gtau, 0, (size_t)nq * 4, st));
         }
-        {
-            ScopedKernelTimer timer(st);
-            LVS_HIP_CHECK(lvs_rq_launch(ra, p.dpad, st));
-        }
-        if (ra.nparts >= 16)
-            hipLaunchKernelGGL(merge_keys_wide_kernel, dim3((unsigned)nq), dim3(1024), 0, st, partial, ra.nparts, (long long)nq, k,
-                               (u64*)out_keys, (long long)k);
-        else
-            hipLaunchKernelGGL(merge_keys_kernel, dim3((unsigned)lvs_ceil_div(nq, 4)), dim3(256), 0, st, partial, ra.nparts,
-                               (long long)nq, k, (u64*)out_keys, (long long)k, (const uint32_t*)nullptr);
-        LVS_HIP_CHECK(hipGetLastError());
         return LVS_OK;
     }
     // HBM-bound regime (the literal sem_search: one query per call; small batches up to 256 queries): stream the corpus

@@ -115,6 +115,15 @@ extern "C" int32_t lvs_search_sharded(lvs_all_gather_fn all_gather, void* all_ga
         lvs_set_error("workspace too small: need %lld bytes, got %lld", (long long)p.total, (long long)workspace_bytes);
         return LVS_ENOMEM;
     }
+    // Everything that can fail on ONE rank only is checked before the first exchange: a rank that returned early would leave
+    // its peers waiting inside the all-gather.  (An error from the all-gather itself, or from a launch, still leaves the
+    // communicator in an undefined collective state - include/lotus_hip.h.)
+    LVS_REQUIRE(xq, "NULL queries");
+    LVS_REQUIRE(nb_local == 0 || xb, "NULL rows");
+    LVS_REQUIRE(metric == LVS_METRIC_IP || metric == LVS_METRIC_L2, "bad metric %d", metric);
+    LVS_REQUIRE(metric != LVS_METRIC_L2 || (xq_norms_sq && (nb_local == 0 || xb_norms_sq)), "L2 needs both norm vectors");
+    LVS_REQUIRE(k >= 1 && k <= LVS_MAX_K, "k=%d out of range", k);
+    LVS_REQUIRE(id_offset >= 0 && id_offset + nb_local < 0xFFFFFFFFll, "ids must stay below 2^32-1");
     char* ws = (char*)workspace;
     hipStream_t st = (hipStream_t)stream;
     float* seed_all = nullptr;
@@ -164,7 +173,8 @@ extern "C" int32_t lvs_search_sharded_rccl(void* nccl_comm, const void* xb, int3
                                            void* stream) {
     const Rccl* r = rccl();
     if (!r) {
-        lvs_set_error("librccl.so.1 could not be loaded (or lacks ncclAllGather / ncclCommCount): %s", dlerror() ? dlerror() : "");
+        const char* why = dlerror();  // (a second call would return NULL: the first one clears the message)
+        lvs_set_error("librccl.so.1 could not be loaded (or lacks ncclAllGather / ncclCommCount): %s", why ? why : "");
         return LVS_EDEVICE;
     }
     LVS_REQUIRE(nccl_comm, "NULL communicator");

@@ -215,7 +215,9 @@ struct LvsStreamArgs {
 
 // ---- lvs_rq.hip: 97 .. 256 queries with the queries resident in registers ----
 #define LVS_RQ_GROUPQ 256   // queries of one workgroup (eight waves x 32)
-#define LVS_RQ_MAXQ 4096    // most queries per call: 16 groups
+#define LVS_RQ_MAXQ 4096    // most queries per LAUNCH: 16 groups (a call with more runs one launch per chunk of that many)
+#define LVS_RQ_KMAX 16      // most list slots per query
+#define LVS_RQ_JOIN_DEFAULT 0  // calls beyond LVS_RQ_MAXQ queries in chunks through lvs_rq_kernel (1) or through the list kernel (0)
 #define LVS_RQ_SEED_ROWS 65536  // sample rows (the first of the shard) whose scores seed the thresholds: a workgroup sees ~4 000
                                 // rows, its lists never fill, so the seed IS its threshold - 64 k rows beat 32 k by 4 % per call, 128 k tie
 struct LvsRqArgs {
@@ -232,6 +234,8 @@ struct LvsRqArgs {
     int blocks_per_wg;  // 32-row blocks per corpus range (set by lvs_rq_launch)
     int nparts;         // out: corpus ranges of the launch
     int groups;         // out: query groups of LVS_RQ_GROUPQ (sibling workgroups per corpus range)
+    int debug;          // -DLVS_TUNING builds only (env LVS_RQ_DEBUG), timing ablations with WRONG results: bit 0 no staging loads in
+                        // the loop, bit 1 no block epilogue, bit 2 no MFMAs, bit 3 no fragment reads, bit 4 no unit barrier
 };
 bool lvs_rq_fits(int64_t nq, int64_t nb, int dpad, int k);
 hipError_t lvs_rq_launch(LvsRqArgs& a, int dpad, hipStream_t stream);

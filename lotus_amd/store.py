@@ -149,10 +149,20 @@ def _stamps_still_valid(index_dir: str, meta: dict) -> bool:
         return False
     try:
         meta = dict(meta, written_with=now)
-        tmp = os.path.join(index_dir, "rows.json.tmp")
-        with open(tmp, "w") as fp:
-            json.dump(meta, fp)
-        os.replace(tmp, os.path.join(index_dir, "rows.json"))
+        # several ranks may open the same copied directory at once: every writer gets a temporary file of its own, the rename
+        # is atomic, the last one wins (they all write the same stamps)
+        import tempfile
+
+        fd, tmp = tempfile.mkstemp(prefix="rows.json.", suffix=".tmp", dir=index_dir)
+        try:
+            with os.fdopen(fd, "w") as fp:
+                json.dump(meta, fp)
+            os.replace(tmp, os.path.join(index_dir, "rows.json"))
+        except OSError:
+            try:
+                os.unlink(tmp)
+            except OSError:
+                pass
     except OSError:
         pass
     return True

@@ -622,3 +622,28 @@ def test_ranges_with_overlapped_sums_equal_the_single_pass(hip_backend, mode):
     be.kmeans_accumulate_keys_into(be.slice_rows(p, 0, h), keys[:h].contiguous(), K, s2, c2)
     be.kmeans_accumulate_keys_into(be.slice_rows(p, h, n), keys[h:].contiguous(), K, s2, c2)
     assert bool(torch.equal(s1, s2)) and bool(torch.equal(c1, c2))
+
+
+def test_nearest_begin_chunks_its_queries_inside_the_scratch_budget(hip_backend, monkeypatch):
+    """`nearest()` cut its queries into chunks that keep the query-streaming search's scratch (20 B per corpus tile
+    and query) below NEAREST3_WS_BUDGET, but the two-halves form the pipelined k-means uses (`nearest_begin` / `nearest_finish`)
+    asked for a whole range at once.  With a budget that forces three chunks both forms return the single call's keys."""
+    be = hip_backend
+    rng = np.random.default_rng(77)
+    nq, nb, d = 150_000, 700, 96
+    xb = rng.standard_normal((nb, d)).astype(np.float32)
+    xq = (xb[rng.integers(0, nb, nq)] + 0.3 * rng.standard_normal((nq, d))).astype(np.float32)
+    cb, cq = be.pack(xb, SPLIT), be.pack(xq, SPLIT)
+    whole = be.nearest(cb, cq, L2, exact_scores=False)
+    per_q = max(1, int(be.lib.lvs_nearest3_workspace_bytes(1 << 20, nb, d)) >> 20)
+    monkeypatch.setattr(type(be), "NEAREST3_WS_BUDGET", per_q * (1 << 16))  # step = 65 536 queries -> 3 chunks
+    assert be._nearest3_step(cb) == 1 << 16
+    stats = {}
+    h = be.nearest_begin(cb, cq, L2, exact_scores=False)
+    assert "chunks" in h and len(h["chunks"]) == 3
+    two = be.nearest_finish(h, stats=stats)
+    assert stats["queries"] == nq
+    chunked = be.nearest(cb, cq, L2, exact_scores=False)
+    import torch
+
+    assert bool(torch.equal(two, whole)) and bool(torch.equal(chunked, whole))

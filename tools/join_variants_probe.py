@@ -1,0 +1,103 @@
+"""Round 6, review item 1: variants of the join-scale search (k = 10, d = 768 fp16, 1 M rows) on ONE box, alternating, each with
+kernel time (the library's events), wall time per call, mean board power and engine clock over >= 3 s of back-to-back calls, and
+the keys compared bit for bit with the list kernel's.  Tuning build (knobs read per call).
+   python tools/join_variants_probe.py [--nq 4096,10000,100000] [--secs 3] [--rounds 2] [--variants list,rq,rqx]"""
+import argparse, json, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+from lotus_amd import _capi
+_capi.load(os.path.join(ROOT, "lotus_amd", "liblotus_hip_tuning.so"))
+from lotus_amd.backend import HipBackend
+from powermon import PowerMonitor
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--nq", default="4096,10000,100000")
+ap.add_argument("--nb", type=int, default=1_000_000)
+ap.add_argument("--secs", type=float, default=3.0)
+ap.add_argument("--rounds", type=int, default=2)
+ap.add_argument("--variants", default="list,rq,rqx")
+ap.add_argument("--planted", type=int, default=1)
+args = ap.parse_args()
+
+VARIANTS = {  # name -> environment of the tuning build
+    "list": {"LVS_RQ_JOIN": "0", "LVS_RQ_MAXG": "0"},          # the list kernel for everything beyond 256 queries
+    "rq": {"LVS_RQ_JOIN": "1"},                                 # lvs_rq_kernel in chunks of 4 096 queries
+    "rqx": {"LVS_RQ_JOIN": "1", "LVS_RQ_XBAR": "1"},            # + fragment pipeline across the unit barriers
+    "rj": {"LVS_RQ_JOIN": "1", "LVS_RQ_MODE": "2"},             # one wave per SIMD, 64 queries per wave, B fragments in named AGPRs
+    "rjn": {"LVS_RQ_JOIN": "1", "LVS_RQ_MODE": "2", "LVS_RQ_XBAR": "0"},
+    "rq2k": {"LVS_RQ_JOIN": "1", "LVS_RQ_CHUNK": "2048"},
+    "rqx2k": {"LVS_RQ_JOIN": "1", "LVS_RQ_XBAR": "1", "LVS_RQ_CHUNK": "2048"},
+}
+KNOBS = sorted({k for v in VARIANTS.values() for k in v})
+
+be = HipBackend("cuda:0")
+g = torch.Generator(device=be.device); g.manual_seed(20260930)
+d, nb = 768, args.nb
+
+def unit(n):
+    out = torch.empty((n, d), dtype=torch.float16, device=be.device)
+    for r0 in range(0, n, 1 << 18):
+        r1 = min(n, r0 + (1 << 18))
+        out[r0:r1] = torch.nn.functional.normalize(torch.randn((r1 - r0, d), generator=g, device=be.device), dim=1).half()
+    return out
+
+xb = unit(nb)
+cb = be.pack(xb, _capi.PACK_F16)
+nq_max = max(int(x) for x in args.nq.split(","))
+if args.planted:  # q = normalize(0.7 x[j] + 0.7 u)
+    j = torch.randint(0, nb, (nq_max,), generator=g, device=be.device)
+    xq = torch.empty((nq_max, d), dtype=torch.float16, device=be.device)
+    for r0 in range(0, nq_max, 1 << 16):
+        r1 = min(nq_max, r0 + (1 << 16))
+        u = torch.nn.functional.normalize(torch.randn((r1 - r0, d), generator=g, device=be.device), dim=1)
+        xq[r0:r1] = torch.nn.functional.normalize(0.7 * xb[j[r0:r1]].float() + 0.7 * u, dim=1).half()
+else:
+    xq = unit(nq_max)
+del xb
+
+def setenv(name):
+    for k in KNOBS:
+        os.environ.pop(k, None)
+    os.environ.update(VARIANTS[name])
+
+def one(name, cq, secs):
+    setenv(name)
+    keys = be.search_keys(cb, cq, 10, 0)
+    be.synchronize()
+    be.timing_enable(True)
+    n = 0
+    with PowerMonitor() as pm:
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < secs or n < 3:
+            keys = be.search_keys(cb, cq, 10, 0)
+            n += 1
+            if n % 4 == 0:
+                be.synchronize()
+        be.synchronize()
+        wall = (time.perf_counter() - t0) / n * 1e3
+    tot, cnt = be.timing_read()
+    be.timing_enable(False)
+    return keys, tot / n, cnt / n, wall, pm.summary()
+
+names = [v for v in args.variants.split(",") if v in VARIANTS]
+rows = []
+for nq in (int(x) for x in args.nq.split(",")):
+    cq = be.pack(xq[:nq].contiguous(), _capi.PACK_F16)
+    flop = 2.0 * nq * nb * d
+    ref = None
+    for rnd in range(args.rounds):
+        for name in names:
+            keys, kms, launches, wall, pw = one(name, cq, args.secs)
+            if name == "list" and ref is None:
+                ref = keys.clone()
+            same = None if ref is None else bool(torch.equal(keys, ref))
+            tf = flop / (kms * 1e-3) / 1e12
+            row = {"nq": nq, "variant": name, "round": rnd, "kernel_ms": round(kms, 4), "launches": launches, "wall_ms": round(wall, 4),
+                   "tflops": round(tf, 1), "frac": round(tf / 2500, 4), "keys_equal_list": same, **{k: pw.get(k) for k in ("power_w", "sclk_mhz", "samples", "source")}}
+            if pw.get("power_w"):
+                row["gflop_per_j"] = round(flop / (wall * 1e-3) / pw["power_w"] / 1e9, 2)
+            rows.append(row)
+            print(json.dumps(row), flush=True)
+os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+json.dump(rows, open(os.path.join(ROOT, "gpurun_out", "join_variants_probe.json"), "w"), indent=1)

@@ -1,0 +1,40 @@
+"""Timing ablations of lvs_rq_kernel at join scale (4 096 queries x 1 M x 768, 16 groups): the eight-wave form (LVS_RQ_MODE=0) and the
+four-wave form with two query blocks per wave and the B fragments in named AGPRs (LVS_RQ_MODE=2).  Ablated runs give WRONG results."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+from lotus_amd import _capi
+_capi.load(os.path.join(ROOT, "lotus_amd", "liblotus_hip_tuning.so"))
+from lotus_amd.backend import HipBackend
+from powermon import PowerMonitor
+be = HipBackend("cuda:0")
+g = torch.Generator(device=be.device); g.manual_seed(5)
+def unit(n, d):
+    out = torch.empty((n, d), dtype=torch.float16, device=be.device)
+    for r0 in range(0, n, 1 << 18):
+        r1 = min(n, r0 + (1 << 18))
+        out[r0:r1] = torch.nn.functional.normalize(torch.randn((r1 - r0, d), generator=g, device=be.device), dim=1).half()
+    return out
+cb = be.pack(unit(1_000_000, 768), _capi.PACK_F16)
+cq = be.pack(unit(4096, 768), _capi.PACK_F16)
+os.environ["LVS_RQ_JOIN"] = "1"
+ABL = ((0, "full"), (1, "no staging loads"), (2, "no epilogue"), (3, "no staging, no epilogue"), (18, "no epilogue, no barrier"),
+       (19, "MFMA + reads only"), (27, "MFMA only"))
+for mode, xbar in (("2", "1"),):
+    os.environ["LVS_RQ_MODE"] = mode
+    os.environ["LVS_RQ_XBAR"] = xbar
+    for dbg, what in ABL:
+        os.environ["LVS_RQ_DEBUG"] = str(dbg)
+        be.search_keys(cb, cq, 10, 0); be.synchronize()
+        be.timing_enable(True)
+        with PowerMonitor(skip=0.1) as pm:
+            for _ in range(150):
+                be.search_keys(cb, cq, 10, 0)
+            be.synchronize()
+        tot, cnt = be.timing_read(); be.timing_enable(False)
+        ms = tot / max(cnt, 1)
+        p = pm.summary()
+        units = 3906.25  # 62 500 rows per range / 32 * 2
+        cyc = ms * 1e-3 / units * (p.get("sclk_mhz") or 0) * 1e6
+        print(f"mode {mode} xbar {xbar} {what:26s}: kernel {ms:6.3f} ms  sclk {p.get('sclk_mhz')} MHz  {p.get('power_w')} W  ~{cyc:5.0f} cycles per unit", flush=True)
