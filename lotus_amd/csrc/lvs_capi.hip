@@ -871,7 +871,10 @@ int make_plan(int64_t nq, int64_t nb, int32_t d, int32_t xb_pack, int32_t xq_pac
     if (nq <= LVS_STREAM_MAXQ && k <= LVS_KPASS)
         off += lvs_stream_parts_bytes(nq, k) + lvs_round_up((int64_t)(nq > 0 ? nq : 1) * (LVS_STREAM_MAXWG + 8) * 4, 256);
     else if (k <= LVS_RQ_KMAX) {  // lvs_rq_kernel in query groups, beyond LVS_RQ_MAXQ queries one chunk of that many at a time
-        const int64_t cq = nq <= LVS_RQ_MAXQ ? nq : LVS_RQ_MAXQ;
+        int64_t cmax = lvs_tune("LVS_RQ_CHUNK", LVS_RQ_CHUNK_DEFAULT);
+        if (cmax < LVS_RQ_MAXQ) cmax = LVS_RQ_MAXQ;
+        if (cmax > LVS_RQ_CHUNK_MAX) cmax = LVS_RQ_CHUNK_MAX;
+        const int64_t cq = nq <= cmax ? nq : cmax;
         off += lvs_rq_parts_bytes(cq, k) + lvs_rq_seed_bytes(cq);
     }
     p.off_seed = off;  // [sample tiles][nq] per-tile best scores of a seeded list launch (tile_seed_tiles)
@@ -1253,9 +1256,17 @@ static int32_t flat_search_impl(const void* xb, int32_t xb_pack, int64_t nb, con
     const bool rq_join = rq_ok && nq > LVS_RQ_MAXQ && lvs_tune("LVS_RQ_JOIN", LVS_RQ_JOIN_DEFAULT) != 0 &&
                          lvs_rq_fits(LVS_RQ_MAXQ, nb, p.dpad, k);
     if (rq_join || (rq_ok && lvs_rq_fits(nq, nb, p.dpad, k))) {
-        const int64_t chunk = lvs_tune("LVS_RQ_CHUNK", LVS_RQ_MAXQ) / LVS_RQ_GROUPQ * LVS_RQ_GROUPQ;
-        for (int64_t c0 = 0; c0 < nq; c0 += chunk) {
-            const int64_t cn = nq - c0 < chunk ? nq - c0 : chunk;
+        // a chunk is 4 096 queries (16 groups x 16 corpus ranges) or 8 192 x 2^i (32 / 64 / 128 / 256 groups x 8 / 4 / 2 / 1 ranges:
+        // a multiple of 32 groups - lvs_rq_item); what is left at the end goes out in launches of 8 192, 4 096 and one of <= 4 096 queries
+        int64_t chunk = lvs_tune("LVS_RQ_CHUNK", LVS_RQ_CHUNK_DEFAULT);
+        {
+            int64_t c = LVS_RQ_MAXQ;
+            while (2 * c <= chunk && 2 * c <= LVS_RQ_CHUNK_MAX) c *= 2;
+            chunk = c;
+        }
+        for (int64_t c0 = 0, cn = 0; c0 < nq; c0 += cn) {
+            const int64_t left = nq - c0;
+            cn = left >= chunk ? chunk : (left >= 8192 ? 8192 : (left > LVS_RQ_MAXQ ? LVS_RQ_MAXQ : left));
             LvsRqArgs ra;
             memset(&ra, 0, sizeof(ra));
             ra.xb = xb;
@@ -1280,18 +1291,44 @@ static int32_t flat_search_impl(const void* xb, int32_t xb_pack, int64_t nb, con
             const int64_t sample_cap = lvs_tune("LVS_RQ_SAMPLE", cn > 7 * LVS_RQ_GROUPQ ? LVS_RQ_SEED_ROWS / 4 : LVS_RQ_SEED_ROWS);
             if (sample > sample_cap) sample = sample_cap;
             if (sample >= 4096 && lvs_tune("LVS_STREAM_SEED", 1) != 0) {
-                float* seeds = (float*)((char*)partial + lvs_rq_parts_bytes(cn, k));  // [ranges][cn]
-                LvsRqArgs rs = ra;
-                rs.nb = sample;
-                rs.seed_out = seeds;
-                LVS_HIP_CHECK(lvs_rq_launch(rs, p.dpad, st));
-                hipLaunchKernelGGL(seed_kth_kernel, dim3((unsigned)lvs_ceil_div(cn, 4)), dim3(256), 0, st, (const float*)seeds,
-                                   rs.nparts, (long long)cn, k, gtau + c0);  // writes every gtau[q] of the chunk
-                LVS_HIP_CHECK(hipGetLastError());
+                // (the k-th largest of one maximum per corpus range needs >= k ranges: the sample pass keeps launches of <= 16 groups)
+                float* seeds = (float*)((char*)partial + lvs_rq_parts_bytes(cn, k));  // [ranges][<= 4 096]
+                for (int64_t s0 = 0; s0 < cn; s0 += LVS_RQ_MAXQ) {
+                    const int64_t sn = cn - s0 < LVS_RQ_MAXQ ? cn - s0 : LVS_RQ_MAXQ;
+                    LvsRqArgs rs = ra;
+                    rs.xq = (const _Float16*)ra.xq + s0 * p.ldq;
+                    rs.qn = ra.qn ? ra.qn + s0 : nullptr;
+                    rs.gtau = ra.gtau + s0;
+                    rs.nq = (int)sn;
+                    rs.nb = sample;
+                    rs.seed_out = seeds;
+                    LVS_HIP_CHECK(lvs_rq_launch(rs, p.dpad, st));
+                    hipLaunchKernelGGL(seed_kth_kernel, dim3((unsigned)lvs_ceil_div(sn, 4)), dim3(256), 0, st, (const float*)seeds,
+                                       rs.nparts, (long long)sn, k, gtau + c0 + s0);  // writes every gtau[q] of the piece
+                    LVS_HIP_CHECK(hipGetLastError());
+                }
             } else {
                 LVS_HIP_CHECK(hipMemsetAsync(gtau + c0, 0, (size_t)cn * 4, st));
             }
-            {
+            // (r6) one wave per SIMD, 64 queries per wave (lvs_rj.hip) for the launches it takes: whole 32-row blocks there, the
+            // corpus' last nb % 32 rows through lvs_rq_kernel as one more list per query
+            if (lvs_tune("LVS_RJ", LVS_RJ_DEFAULT) != 0 && lvs_rj_fits(cn, nb, p.dpad, k, row_ids != nullptr)) {
+                {
+                    ScopedKernelTimer timer(st);
+                    LVS_HIP_CHECK(lvs_rj_launch(ra, p.dpad, st));
+                }
+                const int64_t nb_full = nb / 32 * 32;
+                if (nb_full < nb) {
+                    LvsRqArgs rt = ra;
+                    rt.xb = (const char*)xb + nb_full * p.ldb * 2;
+                    rt.bn = xb_norms_sq ? xb_norms_sq + nb_full : nullptr;
+                    rt.nb = nb - nb_full;
+                    rt.id_offset = id_offset + nb_full;
+                    rt.out = partial + (int64_t)ra.nparts * cn * k;
+                    LVS_HIP_CHECK(lvs_rq_launch(rt, p.dpad, st));
+                    ra.nparts += rt.nparts;
+                }
+            } else {
                 ScopedKernelTimer timer(st);
                 LVS_HIP_CHECK(lvs_rq_launch(ra, p.dpad, st));
             }

@@ -155,13 +155,9 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void lvs_rq_kernel(const Lvs
     // Beyond 256 queries the call is cut into GROUPS of 256: a corpus range is scanned by `groups` sibling workgroups, one per
     // group.  Workgroup b lands on XCD b % 8; the siblings of a range take consecutive slots of ONE XCD, so the range is read
     // from HBM once and by the siblings through that XCD's L2 (they run in step: same rows, same work)
-    int range = blockIdx.x, qbase = 0;
-    if (a.groups > 1) {
-        const int s = blockIdx.x >> 3;
-        range = (s / a.groups) * 8 + (blockIdx.x & 7);
-        qbase = (s % a.groups) * (WAVES * NQW * 32);
-        if (range >= a.nparts) return;  // (the grid is rounded up to whole XCD rows)
-    }
+    int range, group;
+    if (!lvs_rq_item(blockIdx.x, a.groups, a.nparts, range, group)) return;
+    const int qbase = group * (WAVES * NQW * 32);
     const _Float16* xq = (const _Float16*)a.xq;
     const char* xb = (const char*)a.xb;
     const long long ldb2 = a.ldb * 2;  // bytes per corpus row
@@ -609,7 +605,7 @@ hipError_t rq_launch_shape(const LvsRqArgs& a, int grid, hipStream_t stream) {
 
 // Corpus ranges a launch of `groups` query groups uses at most: every range has one workgroup per group, all on one XCD
 // (32 CUs), a workgroup fills a CU
-static int rq_max_ranges(int groups) { return groups <= 1 ? 256 : 8 * (32 / groups); }
+static int rq_max_ranges(int groups) { return lvs_rq_ranges_for(groups); }
 
 // Does the register-resident-queries kernel take this call?  fp16 k-slices of one K segment (d padded to 256, 384, 512 or
 // 768 halfs), k <= 16, a corpus long enough to give every CU a few blocks, and 97 .. 256 queries - or up to LVS_RQ_MAXQ in
@@ -635,7 +631,8 @@ hipError_t lvs_rq_launch(LvsRqArgs& a, int dpad, hipStream_t stream) {
     a.blocks_per_wg = (int)((nblocks + ranges - 1) / ranges);
     ranges = (nblocks + a.blocks_per_wg - 1) / a.blocks_per_wg;
     a.nparts = (int)ranges;
-    const int grid = a.groups == 1 ? (int)ranges : 8 * a.groups * (int)((ranges + 7) / 8);
+    if (a.groups > 32 && a.groups % 32 != 0) return hipErrorInvalidValue;
+    const int grid = lvs_rq_grid(a.groups, (int)ranges);
     const bool seed = a.seed_out != nullptr;
     a.debug = (int)lvs_tune("LVS_RQ_DEBUG", 0);
     switch (dpad / 16) {

@@ -215,7 +215,9 @@ struct LvsStreamArgs {
 
 // ---- lvs_rq.hip: 97 .. 256 queries with the queries resident in registers ----
 #define LVS_RQ_GROUPQ 256   // queries of one workgroup (eight waves x 32)
-#define LVS_RQ_MAXQ 4096    // most queries per LAUNCH: 16 groups (a call with more runs one launch per chunk of that many)
+#define LVS_RQ_MAXQ 4096    // most queries of a call lvs_rq_fits takes as ONE launch of up to 16 groups (also the seed pass' chunk)
+#define LVS_RQ_CHUNK_MAX 65536  // most queries per launch of a chunked call: 256 groups x 1 range
+#define LVS_RQ_CHUNK_DEFAULT 4096
 #define LVS_RQ_KMAX 16      // most list slots per query
 #define LVS_RQ_JOIN_DEFAULT 0  // calls beyond LVS_RQ_MAXQ queries in chunks through lvs_rq_kernel (1) or through the list kernel (0)
 #define LVS_RQ_SEED_ROWS 65536  // sample rows (the first of the shard) whose scores seed the thresholds: a workgroup sees ~4 000
@@ -236,9 +238,43 @@ struct LvsRqArgs {
     int groups;         // out: query groups of LVS_RQ_GROUPQ (sibling workgroups per corpus range)
     int debug;          // -DLVS_TUNING builds only (env LVS_RQ_DEBUG), timing ablations with WRONG results: bit 0 no staging loads in
                         // the loop, bit 1 no block epilogue, bit 2 no MFMAs, bit 3 no fragment reads, bit 4 no unit barrier
+    int drain_every;    // lvs_rj_kernel: every wave empties its candidate buffer every that many blocks (a power of two)
 };
+// blockIdx -> (corpus range, query group) of a grouped launch (lvs_rq_kernel, lvs_rj_kernel).  Workgroup b lands on XCD b % 8
+// (observed; used for speed only): the siblings of a range take slots of ONE XCD, so the range comes from HBM once per XCD and
+// reaches the siblings - which run in step - through that XCD's L2.  Up to 32 groups: 32 / groups ranges per XCD at a time
+// (ranges 8 i + x on XCD x).  More than 32 groups (a multiple of 32; r6): the launch is 256 items in range-major order, XCD x runs
+// items 32 x .. 32 x + 31 - its 32 workgroups share one range, 256 / groups ranges in all: every query sees FEWER, LONGER
+// ranges, i.e. fewer list cold starts and candidates per query (16 groups x 16 ranges: ~24 candidates per query and range; 64 x 4: ~37).
+__host__ __device__ inline int lvs_rq_ranges_for(int groups) {
+    return groups <= 1 ? 256 : (groups <= 32 ? 8 * (32 / groups) : 256 / groups);
+}
+__host__ __device__ inline int lvs_rq_grid(int groups, int ranges) {
+    return groups <= 1 ? ranges : (groups <= 32 ? 8 * groups * ((ranges + 7) / 8) : 256);
+}
+__host__ __device__ inline bool lvs_rq_item(int b, int groups, int nparts, int& range, int& group) {
+    if (groups <= 1) {
+        range = b;
+        group = 0;
+        return true;
+    }
+    if (groups <= 32) {
+        const int s = b >> 3;
+        range = (s / groups) * 8 + (b & 7);
+        group = s % groups;
+        return range < nparts;  // (the grid is rounded up to whole XCD rows)
+    }
+    const int item = (b & 7) * 32 + (b >> 3);
+    range = item / groups;
+    group = item % groups;
+    return range < nparts;
+}
 bool lvs_rq_fits(int64_t nq, int64_t nb, int dpad, int k);
 hipError_t lvs_rq_launch(LvsRqArgs& a, int dpad, hipStream_t stream);
+// ---- lvs_rj.hip: the same launches with ONE wave per SIMD and 64 queries per wave (B fragments in named accumulation registers)
+#define LVS_RJ_DEFAULT 0    // launches lvs_rj_fits accepts go through lvs_rj_kernel (1) or lvs_rq_kernel (0)
+bool lvs_rj_fits(int64_t nq, int64_t nb, int dpad, int k, bool has_row_ids);
+hipError_t lvs_rj_launch(LvsRqArgs& a, int dpad, hipStream_t stream);  // whole 32-row blocks only: the caller adds the tail
 
 int lvs_stream_ranges(int64_t nb, int groups);
 size_t lvs_stream_lds_bytes(int nbfrag, int nqb, int kcap);

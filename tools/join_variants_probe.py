@@ -25,6 +25,16 @@ VARIANTS = {  # name -> environment of the tuning build
     "rq": {"LVS_RQ_JOIN": "1"},                                 # lvs_rq_kernel in chunks of 4 096 queries
     "rqx": {"LVS_RQ_JOIN": "1", "LVS_RQ_XBAR": "1"},            # + fragment pipeline across the unit barriers
     "rj": {"LVS_RQ_JOIN": "1", "LVS_RQ_MODE": "2"},             # one wave per SIMD, 64 queries per wave, B fragments in named AGPRs
+    "rjk": {"LVS_RQ_JOIN": "1", "LVS_RJ": "1"},                 # lvs_rj_kernel: the same with deferred insertions, lean staging
+    "rq8k": {"LVS_RQ_JOIN": "1", "LVS_RQ_CHUNK": "8192"},
+    "rq16k": {"LVS_RQ_JOIN": "1", "LVS_RQ_CHUNK": "16384"},
+    "rq32k": {"LVS_RQ_JOIN": "1", "LVS_RQ_CHUNK": "32768"},
+    "rjk8k": {"LVS_RQ_JOIN": "1", "LVS_RJ": "1", "LVS_RQ_CHUNK": "8192"},
+    "rjk16k": {"LVS_RQ_JOIN": "1", "LVS_RJ": "1", "LVS_RQ_CHUNK": "16384"},
+    "rjk32k": {"LVS_RQ_JOIN": "1", "LVS_RJ": "1", "LVS_RQ_CHUNK": "32768"},
+    "rjk64k": {"LVS_RQ_JOIN": "1", "LVS_RJ": "1", "LVS_RQ_CHUNK": "65536"},
+    "rjk16k_e4": {"LVS_RQ_JOIN": "1", "LVS_RJ": "1", "LVS_RQ_CHUNK": "16384", "LVS_RJ_EVERY": "4"},
+    "rjk16k_e64": {"LVS_RQ_JOIN": "1", "LVS_RJ": "1", "LVS_RQ_CHUNK": "16384", "LVS_RJ_EVERY": "64"},
     "rjn": {"LVS_RQ_JOIN": "1", "LVS_RQ_MODE": "2", "LVS_RQ_XBAR": "0"},
     "rq2k": {"LVS_RQ_JOIN": "1", "LVS_RQ_CHUNK": "2048"},
     "rqx2k": {"LVS_RQ_JOIN": "1", "LVS_RQ_XBAR": "1", "LVS_RQ_CHUNK": "2048"},

@@ -17,11 +17,14 @@ def unit(n, d):
         out[r0:r1] = torch.nn.functional.normalize(torch.randn((r1 - r0, d), generator=g, device=be.device), dim=1).half()
     return out
 cb = be.pack(unit(1_000_000, 768), _capi.PACK_F16)
-cq = be.pack(unit(4096, 768), _capi.PACK_F16)
+NQ = int(os.environ.get("RJ_ABLATE_NQ", "32768"))
+cq = be.pack(unit(NQ, 768), _capi.PACK_F16)
+os.environ["LVS_RQ_CHUNK"] = str(max(4096, NQ))
 os.environ["LVS_RQ_JOIN"] = "1"
-ABL = ((0, "full"), (1, "no staging loads"), (2, "no epilogue"), (3, "no staging, no epilogue"), (18, "no epilogue, no barrier"),
-       (19, "MFMA + reads only"), (27, "MFMA only"))
-for mode, xbar in (("2", "1"),):
+os.environ["LVS_RJ"] = "1"
+ABL = ((0, "full"), (1, "no staging loads"), (2, "no epilogue"), (6, "filter only"), (3, "no staging, no epilogue"), (18, "no epilogue, no barrier"),
+       (19, "MFMA + reads only"))
+for mode, xbar in (("0", "1"),):
     os.environ["LVS_RQ_MODE"] = mode
     os.environ["LVS_RQ_XBAR"] = xbar
     for dbg, what in ABL:
@@ -29,12 +32,13 @@ for mode, xbar in (("2", "1"),):
         be.search_keys(cb, cq, 10, 0); be.synchronize()
         be.timing_enable(True)
         with PowerMonitor(skip=0.1) as pm:
-            for _ in range(150):
+            for _ in range(max(4, 150 * 4096 // NQ)):
                 be.search_keys(cb, cq, 10, 0)
             be.synchronize()
         tot, cnt = be.timing_read(); be.timing_enable(False)
         ms = tot / max(cnt, 1)
         p = pm.summary()
-        units = 3906.25  # 62 500 rows per range / 32 * 2
+        ranges = 16 if NQ <= 4096 else 256 // (NQ // 256)
+        units = 1_000_000 / ranges / 32 * 2
         cyc = ms * 1e-3 / units * (p.get("sclk_mhz") or 0) * 1e6
         print(f"mode {mode} xbar {xbar} {what:26s}: kernel {ms:6.3f} ms  sclk {p.get('sclk_mhz')} MHz  {p.get('power_w')} W  ~{cyc:5.0f} cycles per unit", flush=True)
