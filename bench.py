@@ -224,7 +224,8 @@ def main():
         keys, (D, I) = step()
     barrier()
     dt = time.perf_counter() - t0
-    ktot_ms, klaunches = be.timing_read()
+    ktime = be.timing_read_full()
+    ktot_ms, klaunches, kcalls = ktime["total_ms"], ktime["launches"], ktime["calls"]
     be.timing_enable(False)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearsal else device)
@@ -235,9 +236,15 @@ def main():
     planted_at_1 = float((I[:, 0] == planted).float().mean().item())
 
     if rank == 0:
-        kernel_ms = ktot_ms / max(1, klaunches)
-        flops_per_launch = 2.0 * nq * (hi - lo) * d  # 2*Q*N*d, N = rows of this rank's shard
-        achieved = flops_per_launch / (kernel_ms * 1e-3) / 1e12
+        # 2*Q*N*d per step, N = rows of this rank's shard.  A step is ONE launch of the list kernel or - the
+        # register-resident-queries kernels beyond 4 096 queries - one launch per chunk of up to 32 768 queries: the roofline
+        # figure is (algorithmic flops of the launches) / (their summed durations) = flops per launch / average launch duration
+        # with both averaged over the same launches; `kernel_ms` is the dominant kernel's time per STEP, `launches` per step
+        flops_per_step = 2.0 * nq * (hi - lo) * d
+        kernel_ms = ktot_ms / max(1, kcalls)
+        launches_per_step = klaunches / max(1, kcalls)
+        flops_per_launch = flops_per_step / max(1.0, launches_per_step)
+        achieved = flops_per_step / (kernel_ms * 1e-3) / 1e12
         alg_bytes = (hi - lo) * d * 2 + nq * d * 2 + nq * k * 12  # 8(d): every input once + outputs once
         traffic, traffic_src = pmc_traffic(n, nq, world)
         out = {
@@ -260,8 +267,9 @@ def main():
             "planted_neighbour_at_rank1": planted_at_1,
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP16_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP16_MFMA_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": "lvs_tile_kernel<TOPK,256x256>", "kernel_ms": kernel_ms, "launches": klaunches,
-                         "algorithmic_flops_per_launch": flops_per_launch, "algorithmic_bytes_per_launch": alg_bytes,
+                         "kernel": ktime["kernel"], "kernel_ms": kernel_ms, "kernel_ms_per_launch": ktot_ms / max(1, klaunches),
+                         "launches": klaunches, "launches_per_step": launches_per_step,
+                         "algorithmic_flops_per_launch": flops_per_launch, "algorithmic_bytes_per_launch": alg_bytes / max(1.0, launches_per_step),
                          "csrc_sha": csrc_hash()},
         }
         details = {"gen_s": gen_s, "hbm_frac_secondary": alg_bytes / (kernel_ms * 1e-3) / 1e9 / PEAK_HBM_GBS}

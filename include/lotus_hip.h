@@ -384,6 +384,14 @@ int32_t lvs_kmeans_split_clusters_host(int32_t d, int32_t k, int64_t n, float* h
  * measured with HIP events on the launch stream (enabled with lvs_timing_enable(1)). ---- */
 int32_t lvs_timing_enable(int32_t on);
 int32_t lvs_timing_read(double* out_total_ms, int64_t* out_launches);
+/* The same plus: out_calls = searches (entry-point calls) that timed at least one launch - a search of more than 4 096 queries
+ * that runs through the register-resident-queries kernels times one launch per chunk of its queries, so total / calls is the
+ * dominant kernel's time per search -, out_kernel = LVS_KERNEL_* of the last timed launch (which kernel family served it). */
+#define LVS_KERNEL_TILE 0   /* lvs_tile_kernel: 256 x 256 score tiles, candidate lists under locks */
+#define LVS_KERNEL_STREAM 1 /* lvs_stream_kernel: up to 96 queries resident in LDS */
+#define LVS_KERNEL_RQ 2     /* lvs_rq_kernel: 32 queries per wave resident in registers */
+#define LVS_KERNEL_RJ 3     /* lvs_rj_kernel: 64 queries per wave resident in registers, one wave per SIMD */
+int32_t lvs_timing_read_calls(double* out_total_ms, int64_t* out_launches, int64_t* out_calls, int32_t* out_kernel);
 
 #ifdef __cplusplus
 }

@@ -92,6 +92,7 @@ SIGNATURES = {
     "lvs_kmeans_split_clusters_host": (_i32, [_i32, _i32, _i64, _vp, _vp, ctypes.POINTER(_i32)]),
     "lvs_timing_enable": (_i32, [_i32]),
     "lvs_timing_read": (_i32, [ctypes.POINTER(_dbl), ctypes.POINTER(_i64)]),
+    "lvs_timing_read_calls": (_i32, [ctypes.POINTER(_dbl), ctypes.POINTER(_i64), ctypes.POINTER(_i64), ctypes.POINTER(_i32)]),
 }
 
 

@@ -1080,7 +1080,16 @@ class HipBackend:
     def timing_enable(self, on: bool) -> None:
         _capi.check(self.lib.lvs_timing_enable(int(on)))
 
+    KERNEL_NAMES = {0: "lvs_tile_kernel", 1: "lvs_stream_kernel", 2: "lvs_rq_kernel", 3: "lvs_rj_kernel"}
+
     def timing_read(self):
-        tot, cnt = ctypes.c_double(0), ctypes.c_int64(0)
-        _capi.check(self.lib.lvs_timing_read(ctypes.byref(tot), ctypes.byref(cnt)))
-        return float(tot.value), int(cnt.value)
+        """-> (total ms of the dominant kernel's launches, searches that timed at least one): total / searches = kernel time per
+        search whether it ran as one launch or - beyond 4 096 queries on the register-resident kernels - as one per chunk."""
+        t = self.timing_read_full()
+        return t["total_ms"], t["calls"]
+
+    def timing_read_full(self) -> dict:
+        tot, cnt, calls, kern = ctypes.c_double(0), ctypes.c_int64(0), ctypes.c_int64(0), ctypes.c_int32(0)
+        _capi.check(self.lib.lvs_timing_read_calls(ctypes.byref(tot), ctypes.byref(cnt), ctypes.byref(calls), ctypes.byref(kern)))
+        return {"total_ms": float(tot.value), "launches": int(cnt.value), "calls": int(calls.value),
+                "kernel": self.KERNEL_NAMES.get(int(kern.value), str(int(kern.value)))}

@@ -66,16 +66,22 @@ struct TimingState {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
     double total_ms = 0;
     int64_t launches = 0;
+    int64_t calls = 0;   // entry-point calls that timed at least one launch (a chunked search times several per call)
+    int32_t kernel = 0;  // LVS_KERNEL_* of the last timed launch
 } g_timing;
+
 
 struct ScopedKernelTimer {
     hipEvent_t e0 = nullptr, e1 = nullptr;
     hipStream_t s;
     bool on;
-    explicit ScopedKernelTimer(hipStream_t st) : s(st) {
+    // continuation: a further launch of the SAME search (its next chunk of queries) - counted as a launch, not as a call
+    explicit ScopedKernelTimer(hipStream_t st, int32_t kernel = LVS_KERNEL_TILE, bool continuation = false) : s(st) {
         std::lock_guard<std::mutex> lk(g_timing.mu);
         on = g_timing.on;
         if (on) {
+            g_timing.kernel = kernel;
+            if (!continuation) ++g_timing.calls;
             if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) {
                 on = false;
                 return;
@@ -105,6 +111,7 @@ extern "C" int32_t lvs_timing_enable(int32_t on) {
     g_timing.pending.clear();
     g_timing.total_ms = 0;
     g_timing.launches = 0;
+    g_timing.calls = 0;
     return LVS_OK;
 }
 
@@ -122,6 +129,15 @@ extern "C" int32_t lvs_timing_read(double* out_total_ms, int64_t* out_launches) 
     g_timing.pending.clear();
     if (out_total_ms) *out_total_ms = g_timing.total_ms;
     if (out_launches) *out_launches = g_timing.launches;
+    return LVS_OK;
+}
+
+extern "C" int32_t lvs_timing_read_calls(double* out_total_ms, int64_t* out_launches, int64_t* out_calls, int32_t* out_kernel) {
+    const int32_t rc = lvs_timing_read(out_total_ms, out_launches);
+    if (rc != LVS_OK) return rc;
+    std::lock_guard<std::mutex> lk(g_timing.mu);
+    if (out_calls) *out_calls = g_timing.calls;
+    if (out_kernel) *out_kernel = g_timing.kernel;
     return LVS_OK;
 }
 
@@ -1314,7 +1330,7 @@ static int32_t flat_search_impl(const void* xb, int32_t xb_pack, int64_t nb, con
             // corpus' last nb % 32 rows through lvs_rq_kernel as one more list per query
             if (lvs_tune("LVS_RJ", LVS_RJ_DEFAULT) != 0 && lvs_rj_fits(cn, nb, p.dpad, k, row_ids != nullptr)) {
                 {
-                    ScopedKernelTimer timer(st);
+                    ScopedKernelTimer timer(st, LVS_KERNEL_RJ, c0 > 0);
                     LVS_HIP_CHECK(lvs_rj_launch(ra, p.dpad, st));
                 }
                 const int64_t nb_full = nb / 32 * 32;
@@ -1329,7 +1345,7 @@ static int32_t flat_search_impl(const void* xb, int32_t xb_pack, int64_t nb, con
                     ra.nparts += rt.nparts;
                 }
             } else {
-                ScopedKernelTimer timer(st);
+                ScopedKernelTimer timer(st, LVS_KERNEL_RQ, c0 > 0);
                 LVS_HIP_CHECK(lvs_rq_launch(ra, p.dpad, st));
             }
             u64* okeys = (u64*)out_keys + c0 * k;
@@ -1413,7 +1429,7 @@ static int32_t flat_search_impl(const void* xb, int32_t xb_pack, int64_t nb, con
                 LVS_HIP_CHECK(hipMemsetAsync(gtau, 0, (size_t)nq * 4, st));
             }
             {
-                ScopedKernelTimer timer(st);
+                ScopedKernelTimer timer(st, LVS_KERNEL_STREAM);
                 LVS_HIP_CHECK(lvs_stream_launch(sa, st));
             }
             if (sa.nparts >= 16 && k <= 64)

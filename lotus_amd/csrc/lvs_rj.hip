@@ -441,7 +441,7 @@ template <int NJ>
 hipError_t rj_launch_nj(const LvsRqArgs& a, int grid, hipStream_t stream) {
     const bool l2 = a.metric == LVS_METRIC_L2;
 #ifdef LVS_TUNING
-    if (!l2 && a.k <= 10) {  // timing ablations (LVS_RQ_DEBUG; WRONG results): 1 no staging loads, 2 no epilogue, 4 + filter only, 16 no barrier
+    if (NJ == 48 && !l2 && a.k <= 10) {  // timing ablations (LVS_RQ_DEBUG; WRONG results): 1 no staging loads, 2 no epilogue, 4 + filter only, 16 no barrier
         switch ((int)lvs_tune("LVS_RQ_DEBUG", 0)) {
             case 1: return rj_launch_k<NJ, 10, false, 1>(a, grid, stream);
             case 2: return rj_launch_k<NJ, 10, false, 2>(a, grid, stream);
@@ -462,7 +462,7 @@ hipError_t rj_launch_nj(const LvsRqArgs& a, int grid, hipStream_t stream) {
 // Does the one-wave-per-SIMD form take this launch?  Everything lvs_rq_kernel's grouped launch takes (lvs_rq_fits) with row ids
 // that are positions (no id table: a candidate's key is built where it is found) and at least one whole 32-row block per range.
 bool lvs_rj_fits(int64_t nq, int64_t nb, int dpad, int k, bool has_row_ids) {
-    if (has_row_ids || dpad != 768 || nq <= 128 || k < 1 || k > LVS_RQ_KMAX) return false;
+    if (has_row_ids || !(dpad == 256 || dpad == 384 || dpad == 512 || dpad == 768) || nq <= 128 || k < 1 || k > LVS_RQ_KMAX) return false;
     if (nq <= LVS_RQ_MAXQ) return lvs_rq_fits(nq, nb, dpad, k);
     const int64_t groups = (nq + LVS_RQ_GROUPQ - 1) / LVS_RQ_GROUPQ;  // a chunk of a larger call: 32 x 2^i groups
     return nq <= LVS_RQ_CHUNK_MAX && groups % 32 == 0 && nb >= (int64_t)32768 * 16;
@@ -487,6 +487,9 @@ hipError_t lvs_rj_launch(LvsRqArgs& a, int dpad, hipStream_t stream) {
     const int grid = lvs_rq_grid(a.groups, (int)ranges);
     switch (dpad / 16) {
         case 48: return rj_launch_nj<48>(a, grid, stream);
+        case 32: return rj_launch_nj<32>(a, grid, stream);
+        case 24: return rj_launch_nj<24>(a, grid, stream);
+        case 16: return rj_launch_nj<16>(a, grid, stream);
         default: return hipErrorInvalidValue;
     }
 }

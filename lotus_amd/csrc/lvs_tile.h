@@ -217,9 +217,9 @@ struct LvsStreamArgs {
 #define LVS_RQ_GROUPQ 256   // queries of one workgroup (eight waves x 32)
 #define LVS_RQ_MAXQ 4096    // most queries of a call lvs_rq_fits takes as ONE launch of up to 16 groups (also the seed pass' chunk)
 #define LVS_RQ_CHUNK_MAX 65536  // most queries per launch of a chunked call: 256 groups x 1 range
-#define LVS_RQ_CHUNK_DEFAULT 4096
+#define LVS_RQ_CHUNK_DEFAULT 32768  // 128 groups x 2 ranges: fastest of 4 096 .. 65 536 at 100 k x 1 M (profiles/r10j_join_variants.log)
 #define LVS_RQ_KMAX 16      // most list slots per query
-#define LVS_RQ_JOIN_DEFAULT 0  // calls beyond LVS_RQ_MAXQ queries in chunks through lvs_rq_kernel (1) or through the list kernel (0)
+#define LVS_RQ_JOIN_DEFAULT 1  // calls beyond LVS_RQ_MAXQ queries in chunks through lvs_rq_kernel / lvs_rj_kernel (1) or through the list kernel (0)
 #define LVS_RQ_SEED_ROWS 65536  // sample rows (the first of the shard) whose scores seed the thresholds: a workgroup sees ~4 000
                                 // rows, its lists never fill, so the seed IS its threshold - 64 k rows beat 32 k by 4 % per call, 128 k tie
 struct LvsRqArgs {
@@ -272,7 +272,7 @@ __host__ __device__ inline bool lvs_rq_item(int b, int groups, int nparts, int& 
 bool lvs_rq_fits(int64_t nq, int64_t nb, int dpad, int k);
 hipError_t lvs_rq_launch(LvsRqArgs& a, int dpad, hipStream_t stream);
 // ---- lvs_rj.hip: the same launches with ONE wave per SIMD and 64 queries per wave (B fragments in named accumulation registers)
-#define LVS_RJ_DEFAULT 0    // launches lvs_rj_fits accepts go through lvs_rj_kernel (1) or lvs_rq_kernel (0)
+#define LVS_RJ_DEFAULT 1    // launches lvs_rj_fits accepts go through lvs_rj_kernel (1) or lvs_rq_kernel (0)
 bool lvs_rj_fits(int64_t nq, int64_t nb, int dpad, int k, bool has_row_ids);
 hipError_t lvs_rj_launch(LvsRqArgs& a, int dpad, hipStream_t stream);  // whole 32-row blocks only: the caller adds the tail
 

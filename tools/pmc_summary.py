@@ -13,6 +13,7 @@ from bench import csrc_hash  # noqa: E402
 out_dir = os.path.join(root, "profiles")
 os.makedirs(out_dir, exist_ok=True)
 KERNEL = "lvs_tile_kernel"
+DOMINANT = None
 
 stats = glob.glob(os.path.join(src, "prof_*", "*kernel_stats.csv"))
 summary = {}
@@ -27,16 +28,22 @@ if stats:
             if len(r["Name"]) > 160:
                 r["Name"] = r["Name"][:157] + "..."
             w.writerow(r)
-    for r in rows:
-        if KERNEL in r["Name"] and "<0, 4>" in r["Name"]:
-            summary["kernel"] = r["Name"]
-            summary["rocprof_kernel_avg_ms"] = float(r["AverageNs"]) / 1e6
-            summary["rocprof_kernel_calls"] = int(r["Calls"])
+    # the dominant kernel of the search: the one of the library's search kernels with the largest total duration (r6: the
+    # register-resident-queries kernel lvs_rj_kernel in the default configuration, one launch per chunk of <= 32 768 queries;
+    # the list kernel lvs_tile_kernel<0, 4> before) - SEED-mode sample passes are other instantiations / far shorter
+    cand = [r for r in rows if any(kn in r["Name"] for kn in ("lvs_rj_kernel", "lvs_rq_kernel", "lvs_tile_kernel"))]
+    if cand:
+        r = max(cand, key=lambda r: float(r["TotalDurationNs"]))
+        DOMINANT = r["Name"]
+        summary["kernel"] = r["Name"]
+        summary["rocprof_kernel_avg_ms"] = float(r["AverageNs"]) / 1e6
+        summary["rocprof_kernel_calls"] = int(r["Calls"])
+        summary["rocprof_kernel_total_ms"] = float(r["TotalDurationNs"]) / 1e6
 
 counters = collections.defaultdict(list)
 for p in glob.glob(os.path.join(src, "pmc_*", "b_counter_collection.csv")):
     for r in csv.DictReader(open(p)):
-        if KERNEL in r["Kernel_Name"] and "<0, 4>" in r["Kernel_Name"]:  # the list kernel itself, not its SEED-mode sample pass
+        if (r["Kernel_Name"] == DOMINANT) if DOMINANT else (KERNEL in r["Kernel_Name"] and "<0, 4>" in r["Kernel_Name"]):
             counters[r["Counter_Name"]].append(float(r["Counter_Value"]))
             summary.setdefault("vgpr", int(r["VGPR_Count"]))
             summary.setdefault("sgpr", int(r["SGPR_Count"]))
