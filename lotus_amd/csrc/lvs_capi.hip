@@ -1269,8 +1269,16 @@ static int32_t flat_search_impl(const void* xb, int32_t xb_pack, int64_t nb, con
     // built for.  (r6) Beyond 4 096 queries the same launch repeats per CHUNK of 4 096 queries (16 groups x 16 corpus ranges):
     // a query belongs to one chunk, so every chunk is a complete search of its own (own seeds, own lists, own merge).
     const bool rq_ok = lvs_tune("LVS_RQ", 1) != 0 && p.nseg == 1 && p.npass == 1 && !pred && g_band.kc == 0;
+    // (a corpus SHARD qualifies from 65 536 rows on: its thresholds may come from the caller - the pooled sample scores of all
+    // shards, scored by the list kernel's SEED mode in the same arithmetic - or from its own first rows)
     const bool rq_join = rq_ok && nq > LVS_RQ_MAXQ && lvs_tune("LVS_RQ_JOIN", LVS_RQ_JOIN_DEFAULT) != 0 &&
-                         lvs_rq_fits(LVS_RQ_MAXQ, nb, p.dpad, k);
+                         lvs_rq_shape_ok(p.dpad, k) && nb >= lvs_tune("LVS_RQ_JOIN_MINROWS", LVS_RQ_JOIN_MINROWS);
+    const bool rq_ext_seeds = ext_seeds && ext_rows >= k;
+    if (rq_join && rq_ext_seeds) {  // the k-th largest of the caller's sample scores, for every query of the call at once
+        hipLaunchKernelGGL(seed_kth_kernel, dim3((unsigned)lvs_ceil_div(nq, 4)), dim3(256), 0, st, ext_seeds, (int)ext_rows,
+                           (long long)nq, k, gtau);
+        LVS_HIP_CHECK(hipGetLastError());
+    }
     if (rq_join || (rq_ok && lvs_rq_fits(nq, nb, p.dpad, k))) {
         // a chunk is 4 096 queries (16 groups x 16 corpus ranges) or 8 192 x 2^i (32 / 64 / 128 / 256 groups x 8 / 4 / 2 / 1 ranges:
         // a multiple of 32 groups - lvs_rq_item); what is left at the end goes out in launches of 8 192, 4 096 and one of <= 4 096 queries
@@ -1306,7 +1314,9 @@ static int32_t flat_search_impl(const void* xb, int32_t xb_pack, int64_t nb, con
             // pass 1 % and saves 3 % of the call; profiles/r09b_rq_groups_sample_probe.log)
             const int64_t sample_cap = lvs_tune("LVS_RQ_SAMPLE", cn > 7 * LVS_RQ_GROUPQ ? LVS_RQ_SEED_ROWS / 4 : LVS_RQ_SEED_ROWS);
             if (sample > sample_cap) sample = sample_cap;
-            if (sample >= 4096 && lvs_tune("LVS_STREAM_SEED", 1) != 0) {
+            if (rq_join && rq_ext_seeds) {
+                // seeded above
+            } else if (sample >= 4096 && lvs_tune("LVS_STREAM_SEED", 1) != 0) {
                 // (the k-th largest of one maximum per corpus range needs >= k ranges: the sample pass keeps launches of <= 16 groups)
                 float* seeds = (float*)((char*)partial + lvs_rq_parts_bytes(cn, k));  // [ranges][<= 4 096]
                 for (int64_t s0 = 0; s0 < cn; s0 += LVS_RQ_MAXQ) {

@@ -105,6 +105,11 @@ constexpr int rj_piece_at(int jj, int uk, int lpw) {  // staging piece p (0 .. l
     return -1;
 }
 
+#ifdef LVS_TUNING
+// tuning builds: cycle / event counters of the DBG = 32 instantiation (tools/rj_ablate.py), summed over all waves
+__device__ unsigned long long rj_dbg[16];
+#endif
+
 template <int NJ>
 struct RjGeom {
     static constexpr int UK = NJ % 24 == 0 ? 24 : 16;  // k-slices per staged unit
@@ -222,11 +227,18 @@ __global__ __launch_bounds__(256, 1) void lvs_rj_kernel(const LvsRqArgs a) {
                 // the block's side words, one 4-byte DMA per query block: lanes 0 .. 31 -> |y|^2 of its rows (any valid word under
                 // inner product), lanes 32 .. 63 -> the shared thresholds of this wave's queries as the other workgroups left them
                 const long long row0 = (b0 + is_blk) * 32;
+                // (inner product: ONE 4-byte DMA - words 0 .. 31 the thresholds of query block 0, words 32 .. 63 those of query
+                // block 1; squared L2: two - |y|^2 | thresholds 0, then thresholds 1 in the upper half of the second)
+                if constexpr (L2) {
 #pragma unroll
-                for (int qb = 0; qb < 2; ++qb) {
-                    const int q = qidx_of(qb) < a.nq ? qidx_of(qb) : 0;
-                    const void* p = (lane < 32 && L2) ? (const void*)(a.bn + row0 + (lane & 31)) : (const void*)(a.gtau + q);
-                    rj_glds4(p, side + ((is_blk % NB_RING) * 2 + qb) * 64);
+                    for (int qb = 0; qb < 2; ++qb) {
+                        const int q = qidx_of(qb) < a.nq ? qidx_of(qb) : 0;
+                        const void* p = lane < 32 ? (const void*)(a.bn + row0 + (lane & 31)) : (const void*)(a.gtau + q);
+                        rj_glds4(p, side + ((is_blk % NB_RING) * 2 + qb) * 64);
+                    }
+                } else {
+                    const int qi = qidx_of(lane >> 5);
+                    rj_glds4(a.gtau + (qi < a.nq ? qi : 0), side + ((is_blk % NB_RING) * 2) * 64);
                 }
             }
             // advance the cursor; past the range's end the last unit is loaded again (into a free slot, never read)
@@ -252,25 +264,75 @@ __global__ __launch_bounds__(256, 1) void lvs_rj_kernel(const LvsRqArgs a) {
     // ---- deferred insertion: candidates wait in the wave's buffer; `drain` inserts them (wave-cooperative sorted insertion: lane
     // j < k owns slot j of the query's list - no lock, the list is this wave's), tightens the lanes' thresholds and publishes
     int count = 0;  // wave-uniform
+    unsigned long long d_visit = 0, d_drain = 0, d_bar = 0, d_nvisit = 0, d_ndrain = 0, d_ncand = 0, d_epi = 0;
     auto drain = [&]() {
+        const unsigned long long t_d0 = (DBG & 32) ? __builtin_amdgcn_s_memtime() : 0;
+        d_ndrain += 1;
+        d_ncand += count;
         uint32_t best[2] = {0u, 0u};
-        for (int i = 0; i < count; ++i) {
-            const u64 ukey = ckey[i];                                       // (same address in every lane: a broadcast read)
-            const int uq = __builtin_amdgcn_readfirstlane((int)cql[i]);
-            u64* UL = mylists + uq * KCAP;
-            u64 mine = 0, prev = ~0ull;
-            if (lane < k) {
-                mine = UL[lane];
-                if (lane > 0) prev = UL[lane - 1];
+        const int grp = lane >> 4, slot16 = lane & 15;
+        for (int i0 = 0; i0 < count; i0 += 64) {
+            // every lane fetches ONE waiting entry (a single LDS round trip for up to 64 of them); then FOUR entries per round:
+            // the 16 lanes of group g own the list slots of entry i + g's query (k <= 16), so one list read + write serves four
+            // insertions - unless two of the four hit the same query, which then take their turns
+            const int n = count - i0 < 64 ? count - i0 : 64;
+            u64 ek = 0;
+            uint32_t eq = 0xFFFFFFFFu;
+            if (lane < n) {
+                ek = ckey[i0 + lane];
+                eq = cql[i0 + lane];
             }
-            u64 newv = 0;
-            if (lane < k) newv = mine > ukey ? mine : (prev > ukey ? ukey : prev);
-            __builtin_amdgcn_wave_barrier();
-            if (lane < k) UL[lane] = newv;
-            const uint32_t ntau = __builtin_amdgcn_readlane((uint32_t)(newv >> 32), k - 1);
+            if constexpr (L2) {  // (squared L2 has no registers to spare for the four-at-a-time form: one entry per round)
+                for (int i = 0; i < n; ++i) {
+                    const u64 ukey = ((u64)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(ek >> 32), i) << 32) |
+                                     (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)ek, i);
+                    const int uq = __builtin_amdgcn_readlane((int)eq, i);
+                    u64* UL = mylists + uq * KCAP;
+                    u64 mine = 0;
+                    if (lane < k) mine = UL[lane];
+                    u64 prev = ((u64)(uint32_t)__builtin_amdgcn_update_dpp(-1, (int)(uint32_t)(mine >> 32), 0x138, 0xf, 0xf, false) << 32) |
+                               (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)(uint32_t)mine, 0x138, 0xf, 0xf, false);
+                    if (lane == 0) prev = ~0ull;
+                    u64 newv = 0;
+                    if (lane < k) newv = mine > ukey ? mine : (prev > ukey ? ukey : prev);
+                    if (lane < k) UL[lane] = newv;
+                    const uint32_t ntau = __builtin_amdgcn_readlane((uint32_t)(newv >> 32), k - 1);
 #pragma unroll
-            for (int qb = 0; qb < 2; ++qb)
-                if (qb * 32 + (lane & 31) == uq) best[qb] = ntau > best[qb] ? ntau : best[qb];
+                    for (int qb = 0; qb < 2; ++qb)
+                        if (qb * 32 + (lane & 31) == uq) best[qb] = ntau > best[qb] ? ntau : best[qb];
+                }
+            } else
+            for (int i = 0; i < n; i += 4) {
+                uint32_t sq[4];  // (scalar) the four entries' queries; 0xFFFFFFFF = no entry
+#pragma unroll
+                for (int gg = 0; gg < 4; ++gg) sq[gg] = i + gg < n ? (uint32_t)__builtin_amdgcn_readlane((int)eq, (i + gg) & 63) : 0xFFFFFFFFu;
+                const bool clash = (sq[0] == sq[1] && sq[1] != 0xFFFFFFFFu) || (sq[0] == sq[2] && sq[2] != 0xFFFFFFFFu) ||
+                                   (sq[0] == sq[3] && sq[3] != 0xFFFFFFFFu) || (sq[1] == sq[2] && sq[2] != 0xFFFFFFFFu) ||
+                                   (sq[1] == sq[3] && sq[3] != 0xFFFFFFFFu) || (sq[2] == sq[3] && sq[3] != 0xFFFFFFFFu);
+                const int e = (i + grp) & 63;
+                const u64 ukey = ((u64)(uint32_t)__shfl((int)(uint32_t)(ek >> 32), e, 64) << 32) | (uint32_t)__shfl((int)(uint32_t)ek, e, 64);
+                const uint32_t uq = grp == 0 ? sq[0] : (grp == 1 ? sq[1] : (grp == 2 ? sq[2] : sq[3]));
+                for (int turn = 0; turn < (clash ? 4 : 1); ++turn) {
+                    const bool act = uq != 0xFFFFFFFFu && slot16 < k && (!clash || grp == turn);
+                    u64* UL = mylists + (act ? uq : 0u) * KCAP;
+                    u64 mine = 0;
+                    if (act) mine = UL[slot16];
+                    // the neighbour slot through a row shift instead of a second LDS read
+                    u64 prev = ((u64)(uint32_t)__builtin_amdgcn_update_dpp(-1, (int)(uint32_t)(mine >> 32), 0x111, 0xf, 0xf, false) << 32) |
+                               (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)(uint32_t)mine, 0x111, 0xf, 0xf, false);
+                    if (slot16 == 0) prev = ~0ull;
+                    const u64 newv = mine > ukey ? mine : (prev > ukey ? ukey : prev);
+                    if (act) UL[slot16] = newv;
+#pragma unroll
+                    for (int gg = 0; gg < 4; ++gg) {
+                        if (sq[gg] == 0xFFFFFFFFu || (clash && gg != turn)) continue;  // (wave-uniform)
+                        const uint32_t ntau = __builtin_amdgcn_readlane((uint32_t)(newv >> 32), gg * 16 + k - 1);
+#pragma unroll
+                        for (int qb = 0; qb < 2; ++qb)
+                            if ((uint32_t)(qb * 32 + (lane & 31)) == sq[gg]) best[qb] = ntau > best[qb] ? ntau : best[qb];
+                    }
+                }
+            }
         }
         count = 0;
 #pragma unroll
@@ -278,9 +340,11 @@ __global__ __launch_bounds__(256, 1) void lvs_rj_kernel(const LvsRqArgs a) {
             if (best[qb] > pub[qb]) {  // a full list's k-th key is published to the other workgroups (fire and forget)
                 tauf[qb] = fmaxf(tauf[qb], rj_tau_float(best[qb]));
                 pub[qb] = best[qb];
-                if (lane < 32) atomicMax(&a.gtau[qidx_of(qb)], best[qb]);
+                if (lane < 32 && !(DBG & 512)) atomicMax(&a.gtau[qidx_of(qb)], best[qb]);
             }
         }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the unit loop counts its fragment reads from zero
+        if (DBG & 32) d_drain += __builtin_amdgcn_s_memtime() - t_d0;
     };
     // what the other workgroups have found meanwhile (a lower bound of the k-th best over ALL rows), as it rode in with the block
     auto take_shared = [&](int qb, uint32_t g) {
@@ -292,31 +356,43 @@ __global__ __launch_bounds__(256, 1) void lvs_rj_kernel(const LvsRqArgs a) {
     // The lanes whose scores of query block qb reach their thresholds append them to the wave's buffer; lane holds query
     // qidx_of(qb), rows row0 + (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
     auto append = [&](const f32x16& v, int qb, long long row0) {
+        // all sixteen "which lanes hold a candidate in register r?" masks first, back to back: a compare whose result steers a
+        // scalar branch costs ~45 cycles of VALU -> SALU latency, and one per register (the obvious loop) made a visit ~1 400
+        // cycles on a wave that has nobody to hide behind (stamps: tools/rj_ablate.py).  ONE drain site behind the loop (a full
+        // buffer: hundreds of equal scores in a block) - inlined at every register it made the visit 25 KB of code, walked once
+        // per visit straight out of a cold instruction cache.
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            bool c = v[r] >= tauf[qb];
-            u64 m = __ballot(c);
-            if (m == 0) continue;
-            if (count + __popcll(m) > RJ_CAP) {  // (only with hundreds of equal scores in a block)
-                drain();
-                c = v[r] >= tauf[qb];
-                m = __ballot(c);
-                if (m == 0) continue;
+        for (int g4 = 0; g4 < 4; ++g4) {  // (four masks at a time, back to back: see above)
+            u64 m[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) m[e] = __ballot(v[g4 * 4 + e] >= tauf[qb]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int r = g4 * 4 + e;
+                if (m[e] == 0) continue;
+                if (count + __popcll(m[e]) > RJ_CAP) {  // (only with hundreds of equal scores in a block)
+                    drain();
+                    m[e] = __ballot(v[r] >= tauf[qb]);
+                    if (m[e] == 0) continue;
+                }
+                const int pos = count + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m[e] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m[e], 0u));
+                if ((m[e] >> lane) & 1) {
+                    const long long row = row0 + 4 * (lane >> 5) + (r & 3) + 8 * (r >> 2);
+                    ckey[pos] = lvs_pack_key(v[r], (uint32_t)(row + a.id_offset));
+                    cql[pos] = (uint32_t)(qb * 32 + (lane & 31));
+                }
+                count += __popcll(m[e]);
             }
-            const int pos = count + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-            if (c) {
-                const long long row = row0 + 4 * (lane >> 5) + (r & 3) + 8 * (r >> 2);
-                ckey[pos] = lvs_pack_key(v[r], (uint32_t)(row + a.id_offset));
-                cql[pos] = (uint32_t)(qb * 32 + (lane & 31));
-            }
-            count += __popcll(m);
         }
     };
     // every wave drains at the SAME blocks: a drain (hundreds of cycles per candidate) holds up the other three waves at the next
     // barrier, so four drains at four different moments cost the workgroup four times what four at once do
     auto block_end = [&](int blk) {
-        if (count > 0 && (count >= RJ_CAP - 64 || (blk & (a.drain_every - 1)) == a.drain_every - 1)) drain();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the unit loop counts its fragment reads from zero
+        if constexpr (DBG & 128) {
+            if ((blk & (a.drain_every - 1)) == a.drain_every - 1) count = 0;
+        } else {
+            if (count > 0 && (count >= RJ_CAP - 64 || (blk & (a.drain_every - 1)) == a.drain_every - 1)) drain();
+        }
     };
     // ---- block epilogue: 32 rows x this wave's 64 queries.  With one wave per SIMD nothing hides it, so as much of it as
     // possible has already happened inside the block's last MFMA steps (see `unit`): the side words are in registers (gsh) and the
@@ -325,6 +401,7 @@ __global__ __launch_bounds__(256, 1) void lvs_rj_kernel(const LvsRqArgs a) {
     unsigned gsh[2] = {0u, 0u};
     auto epilogue = [&](int blk) {
         const long long row0 = (b0 + blk) * 32;
+        const unsigned long long t_e0 = (DBG & 32) ? __builtin_amdgcn_s_memtime() : 0;
         // (inline-asm MFMAs are invisible to hipcc's hazard recogniser: the wait states between the block's last MFMA and the
         // first VALU read of its result are spelled out)
         asm volatile("s_nop 15\n\ts_nop 3" : "+v"(acc[0]), "+v"(acc[1]));
@@ -341,13 +418,29 @@ __global__ __launch_bounds__(256, 1) void lvs_rj_kernel(const LvsRqArgs a) {
             }
         }
         if constexpr (!(DBG & 4)) {
+            bool wrote = false;
+            const unsigned long long t_v0 = (DBG & 32) ? __builtin_amdgcn_s_memtime() : 0;
 #pragma unroll
             for (int qb = 0; qb < 2; ++qb)
-                if (__any(rj_max16(acc[qb]) >= tauf[qb])) append(acc[qb], qb, row0);
+                if (__any(rj_max16(acc[qb]) >= tauf[qb])) {
+                    if constexpr (!(DBG & 64)) {
+                        append(acc[qb], qb, row0);
+                        wrote = true;
+                    } else {
+                        count += 1;
+                    }
+                }
+            // (LDS writes of its own only behind a visit: the unit loop counts its fragment reads from zero)
+            if (wrote) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if ((DBG & 32) && wrote) {
+                d_visit += __builtin_amdgcn_s_memtime() - t_v0;
+                d_nvisit += 1;
+            }
         } else {
             if (__any(rj_max16(acc[0]) >= 3.0e38f) || __any(rj_max16(acc[1]) >= 3.0e38f)) count = 1;
         }
         block_end(blk);
+        if (DBG & 32) d_epi += __builtin_amdgcn_s_memtime() - t_e0;
     };
 
     // One unit of block `blk`.  In the block's LAST unit the epilogue's memory part rides along: step UK - 7 reads the block's side
@@ -355,7 +448,7 @@ __global__ __launch_bounds__(256, 1) void lvs_rj_kernel(const LvsRqArgs a) {
     // thresholds in.
     auto unit = [&](auto khc, int blk) {
         constexpr int kh = decltype(khc)::value;
-        constexpr bool F = kh == U - 1 && !(DBG & 2);
+        constexpr bool F = kh == U - 1 && !(DBG & 2) && !(DBG & 256);
         constexpr int JS = UK - 7;  // the step that reads the side words
         const unsigned o_next = o_base + (slot + 1 == RING ? (unsigned)(-(RING - 1) * G::UB) : (unsigned)G::UB);
         static_for<UK>([&](auto jc) {
@@ -364,7 +457,12 @@ __global__ __launch_bounds__(256, 1) void lvs_rj_kernel(const LvsRqArgs a) {
             if constexpr (ahead < UK) rj_read_a<ahead % AD, (ahead < UK ? ahead : 0) * 32>(o_base);
             else rj_read_a<ahead % AD, (ahead >= UK ? ahead - UK : 0) * 32>(o_next);  // the next unit's slot: certified at this unit's barrier
             if constexpr (F && jj == JS)
-                asm volatile("ds_read2_b32 %0, %1 offset0:32 offset1:96" : "=v"(*(unsigned long long*)gsh) : "v"(side_lds + (unsigned)((blk % NB_RING) * 512)) : "memory");
+            {
+                if constexpr (L2)
+                    asm volatile("ds_read2_b32 %0, %1 offset0:32 offset1:96" : "=v"(*(unsigned long long*)gsh) : "v"(side_lds + (unsigned)((blk % NB_RING) * 512)) : "memory");
+                else
+                    asm volatile("ds_read2_b32 %0, %1 offset0:0 offset1:32" : "=v"(*(unsigned long long*)gsh) : "v"(side_lds + (unsigned)((blk % NB_RING) * 512)) : "memory");
+            }
             constexpr int piece = rj_piece_at(jj, UK, LPW);
             if constexpr (piece >= 0 && !(DBG & 1)) issue_piece(std::integral_constant<int, piece>{});
             __builtin_amdgcn_sched_barrier(0);
@@ -398,14 +496,29 @@ __global__ __launch_bounds__(256, 1) void lvs_rj_kernel(const LvsRqArgs a) {
             // unit n + 1 has landed once this wave's loads of the RING - 3 younger units are all that is in flight (the half-used
             // load and the side words ride in the same queue: the wait is only more conservative); the barrier makes that true
             // for every wave's share and tells everybody that unit n - 1's slot is free again
+            const unsigned long long t_b0 = (DBG & 32) ? __builtin_amdgcn_s_memtime() : 0;
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"((RING - 3) * LPW) : "memory");
             if constexpr (!(DBG & 16)) __builtin_amdgcn_s_barrier();
+            if (DBG & 32) d_bar += __builtin_amdgcn_s_memtime() - t_b0;
             unit(khc, blk);
         });
         if constexpr (!(DBG & 2)) epilogue(blk);
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // the clamped tail loads still target the ring; the last fragment reads
     drain();
+#ifdef LVS_TUNING
+    if ((DBG & 32) && lane == 0) {
+        atomicAdd(&rj_dbg[0], d_visit);
+        atomicAdd(&rj_dbg[1], d_drain);
+        atomicAdd(&rj_dbg[2], d_bar);
+        atomicAdd(&rj_dbg[3], d_nvisit);
+        atomicAdd(&rj_dbg[4], d_ndrain);
+        atomicAdd(&rj_dbg[5], d_ncand);
+        atomicAdd(&rj_dbg[6], d_epi);
+        atomicAdd(&rj_dbg[7], (unsigned long long)nblk);
+        atomicAdd(&rj_dbg[8], 1ull);
+    }
+#endif
     __builtin_amdgcn_wave_barrier();
     for (int i = lane; i < 64 * k; i += 64) {
         const int ql = i / k, j = i - ql * k;
@@ -449,6 +562,12 @@ hipError_t rj_launch_nj(const LvsRqArgs& a, int grid, hipStream_t stream) {
             case 6: return rj_launch_k<NJ, 10, false, 6>(a, grid, stream);
             case 18: return rj_launch_k<NJ, 10, false, 18>(a, grid, stream);
             case 19: return rj_launch_k<NJ, 10, false, 19>(a, grid, stream);
+            case 32: return rj_launch_k<NJ, 10, false, 32>(a, grid, stream);
+            case 64: return rj_launch_k<NJ, 10, false, 64>(a, grid, stream);
+            case 512: return rj_launch_k<NJ, 10, false, 512>(a, grid, stream);
+            case 128: return rj_launch_k<NJ, 10, false, 128>(a, grid, stream);
+            case 192: return rj_launch_k<NJ, 10, false, 192>(a, grid, stream);
+            case 448: return rj_launch_k<NJ, 10, false, 448>(a, grid, stream);
             default: break;
         }
     }
@@ -459,13 +578,24 @@ hipError_t rj_launch_nj(const LvsRqArgs& a, int grid, hipStream_t stream) {
 
 }  // namespace
 
+#ifdef LVS_TUNING
+// tuning builds: read and clear the DBG = 32 counters (visit / drain / barrier cycles, visits, drains, candidates, epilogue cycles,
+// blocks, waves)
+extern "C" int32_t lvs_rj_debug_read(unsigned long long* out16) {
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(rj_dbg), sizeof(unsigned long long) * 16) != hipSuccess) return LVS_EDEVICE;
+    unsigned long long z[16] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(rj_dbg), z, sizeof(z)) != hipSuccess) return LVS_EDEVICE;
+    return LVS_OK;
+}
+#endif
+
 // Does the one-wave-per-SIMD form take this launch?  Everything lvs_rq_kernel's grouped launch takes (lvs_rq_fits) with row ids
 // that are positions (no id table: a candidate's key is built where it is found) and at least one whole 32-row block per range.
 bool lvs_rj_fits(int64_t nq, int64_t nb, int dpad, int k, bool has_row_ids) {
     if (has_row_ids || !(dpad == 256 || dpad == 384 || dpad == 512 || dpad == 768) || nq <= 128 || k < 1 || k > LVS_RQ_KMAX) return false;
-    if (nq <= LVS_RQ_MAXQ) return lvs_rq_fits(nq, nb, dpad, k);
+    if (nq <= LVS_RQ_MAXQ) return lvs_rq_fits(nq, nb, dpad, k) || (nq > 2048 && nb >= LVS_RQ_JOIN_MINROWS);  // (the last chunk of a call)
     const int64_t groups = (nq + LVS_RQ_GROUPQ - 1) / LVS_RQ_GROUPQ;  // a chunk of a larger call: 32 x 2^i groups
-    return nq <= LVS_RQ_CHUNK_MAX && groups % 32 == 0 && nb >= (int64_t)32768 * 16;
+    return nq <= LVS_RQ_CHUNK_MAX && groups % 32 == 0 && nb >= LVS_RQ_JOIN_MINROWS;
 }
 
 // a.nb rows are searched in whole 32-row blocks: the caller runs the last a.nb % 32 rows through lvs_rq_launch (one more list per

@@ -61,42 +61,6 @@ __device__ inline void rq_lds_wait(half8& a) {
     asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(a) : "n"(N));
 }
 
-// ---- NQW = 2 ("rj": one wave per SIMD, 64 queries per wave, 384 registers of B fragments at d = 768) ------------------------
-// hipcc keeps MFMA operands in VGPRs: left to itself it parks half of such a wave's B fragments in accumulation registers and
-// copies them back four v_accvgpr_read per MFMA.  Here the accumulation file is addressed by NAME: B fragment i < RJ_NB_AGPR
-// lives in a[4 i : 4 i + 3] for the whole kernel, the ring of A fragments in a[RJ_A0 ...] (ds_read_b128 writes AGPRs, the MFMA
-// reads both operands there), and the compiler - told that every such statement clobbers the whole file - keeps out of it.
-// Register numbers are template constants printed into the instruction text ("n" operands).
-#define RJ_C16(p) "a" #p "0", "a" #p "1", "a" #p "2", "a" #p "3", "a" #p "4", "a" #p "5", "a" #p "6", "a" #p "7", "a" #p "8", "a" #p "9"
-#define RJ_CLOBBER_AGPRS                                                                                                          \
-    "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", RJ_C16(1), RJ_C16(2), RJ_C16(3), RJ_C16(4), RJ_C16(5), RJ_C16(6), \
-        RJ_C16(7), RJ_C16(8), RJ_C16(9), RJ_C16(10), RJ_C16(11), RJ_C16(12), RJ_C16(13), RJ_C16(14), RJ_C16(15), RJ_C16(16),       \
-        RJ_C16(17), RJ_C16(18), RJ_C16(19), RJ_C16(20), RJ_C16(21), RJ_C16(22), RJ_C16(23), RJ_C16(24), "a250", "a251", "a252",    \
-        "a253", "a254", "a255"
-constexpr int RJ_NB_AGPR = 60;  // B fragments 0 .. 59 of a wave's 2 NJ in accumulation registers (the rest in VGPRs)
-constexpr int RJ_A0 = 240;      // first register of the A-fragment ring (four fragments)
-template <int I>
-__device__ inline void rj_load_b(const void* p) {  // 16 bytes per lane -> a[4 I : 4 I + 3]
-    asm volatile("global_load_dwordx4 a[%1:%2], %0, off" ::"v"(p), "n"(4 * I), "n"(4 * I + 3) : "memory", RJ_CLOBBER_AGPRS);
-}
-template <int R, int OFFSET>
-__device__ inline void rj_read_a(unsigned addr) {  // A fragment -> ring register R
-    static_assert(OFFSET >= 0 && OFFSET < 65536, "ds_read offset field is 16 bits");
-    asm volatile("ds_read_b128 a[%1:%2], %0 offset:%3" ::"v"(addr), "n"(RJ_A0 + 4 * R), "n"(RJ_A0 + 4 * R + 3), "n"(OFFSET)
-                 : "memory", RJ_CLOBBER_AGPRS);
-}
-template <int R, int I>
-__device__ inline void rj_mfma_aa(f32x16& acc) {  // acc += A(ring R) x B(accumulation registers of fragment I)
-    asm volatile("v_mfma_f32_32x32x16_f16 %0, a[%1:%2], a[%3:%4], %0"
-                 : "+v"(acc)
-                 : "n"(RJ_A0 + 4 * R), "n"(RJ_A0 + 4 * R + 3), "n"(4 * I), "n"(4 * I + 3)
-                 : RJ_CLOBBER_AGPRS);
-}
-template <int R>
-__device__ inline void rj_mfma_av(f32x16& acc, const half8& b) {  // acc += A(ring R) x B(VGPRs)
-    asm volatile("v_mfma_f32_32x32x16_f16 %0, a[%1:%2], %3, %0" : "+v"(acc) : "n"(RJ_A0 + 4 * R), "n"(RJ_A0 + 4 * R + 3), "v"(b) : RJ_CLOBBER_AGPRS);
-}
-
 template <int NJ, int UK, int WAVES, int NQW, int KCAP>
 struct RqGeom {
     static_assert(NJ % UK == 0, "a block is a whole number of units");
@@ -126,16 +90,9 @@ __device__ inline void rq_glds4(const void* gsrc, void* ldst) {
 
 // NJ = K / 16 (k-slices of a row), UK = k-slices per staged unit, WAVES = 4 (one wave per SIMD, up to 512 registers each) or
 // 8 (two per SIMD, 256 each), NQW = 32-query blocks per wave (1; 2 with four waves), AD = A fragments in flight per wave
-template <int NJ, int UK, int WAVES, int NQW, int AD, int KCAP, bool SEED, bool XBAR, int DBG = 0>
+template <int NJ, int UK, int WAVES, int NQW, int AD, int KCAP, bool SEED>
 __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void lvs_rq_kernel(const LvsRqArgs a) {
-    // XBAR: the fragment pipeline runs ACROSS the unit barriers - the first AD - 1 fragments of unit n + 1 are read during the
-    // last MFMAs of unit n, so a unit's MFMAs start right behind its barrier instead of one LDS latency later.  A barrier
-    // therefore certifies the unit AFTER the one about to be computed (one unit fewer in flight)
-    static_assert(!XBAR || (UK % AD == 0 && AD >= 2), "the fragment register ring must close over a unit");
     constexpr bool RQ_SETPRIO = true;
-    constexpr int dbg = DBG;  // timing ablations (tuning builds instantiate a few; results are WRONG with any bit set)
-    constexpr bool RJ = NQW == 2;  // B fragments and the A ring in named accumulation registers (see rj_* above)
-    static_assert(!RJ || (AD == 4 && WAVES == 4), "the rj form: four waves, a ring of four A fragments");
     constexpr bool SPREAD = true;  // the staging loads of a unit go out between the MFMAs of the unit being computed
     constexpr bool PHASED = false;  // WAVES == 8 measured slower (0.51 vs 0.46 ms at 256 queries): see the comment at the block loop
     using G = RqGeom<NJ, UK, WAVES, NQW, KCAP>;
@@ -155,7 +112,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void lvs_rq_kernel(const Lvs
     // Beyond 256 queries the call is cut into GROUPS of 256: a corpus range is scanned by `groups` sibling workgroups, one per
     // group.  Workgroup b lands on XCD b % 8; the siblings of a range take consecutive slots of ONE XCD, so the range is read
     // from HBM once and by the siblings through that XCD's L2 (they run in step: same rows, same work)
-    int range, group;
+    int range, group;  // (lvs_rq_item, lvs_tile.h: the siblings of a range share an XCD; beyond 32 groups one range per XCD)
     if (!lvs_rq_item(blockIdx.x, a.groups, a.nparts, range, group)) return;
     const int qbase = group * (WAVES * NQW * 32);
     const _Float16* xq = (const _Float16*)a.xq;
@@ -164,7 +121,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void lvs_rq_kernel(const Lvs
     const bool l2 = a.metric == LVS_METRIC_L2;
 
     // ---- this wave's queries -> registers as B fragments: block qb*WAVES + wave, fragment j, lane l = query (l & 31), halfs (l >> 5) * 8
-    half8 breg[NQW][NJ];  // (rj: only fragments RJ_NB_AGPR .. 2 NJ - 1 are ever touched - the others live in a[0 ..])
+    half8 breg[NQW][NJ];
     int qidx[NQW];      // query number (call-wide)
     bool qvalid[NQW];
     float tauf[NQW], qnv[NQW];
@@ -175,27 +132,12 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void lvs_rq_kernel(const Lvs
         qvalid[qb] = qidx[qb] < a.nq;
         const int qrow = qvalid[qb] ? qidx[qb] : a.nq - 1;
         const _Float16* qp = xq + (long long)qrow * a.ldq + (lane >> 5) * 8;
-        if constexpr (!RJ) {
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) breg[qb][j] = *(const half8*)(qp + j * 16);
-        } else {
-            static_for<NJ>([&](auto jc) {
-                constexpr int j = decltype(jc)::value;
-                // (qb is a loop variable: both halves of the fragment numbering are spelled out)
-                if (qb == 0) {
-                    if constexpr (j < RJ_NB_AGPR) rj_load_b<(j < RJ_NB_AGPR ? j : 0)>(qp + j * 16);
-                    else breg[0][j] = *(const half8*)(qp + j * 16);
-                } else {
-                    if constexpr (NJ + j < RJ_NB_AGPR) rj_load_b<(NJ + j < RJ_NB_AGPR ? NJ + j : 0)>(qp + j * 16);
-                    else breg[1][j] = *(const half8*)(qp + j * 16);
-                }
-            });
-        }
+        for (int j = 0; j < NJ; ++j) breg[qb][j] = *(const half8*)(qp + j * 16);
         gord[qb] = (!SEED && qvalid[qb]) ? a.gtau[qidx[qb]] : 0u;
         tauf[qb] = rq_tau_float(gord[qb]);
         qnv[qb] = l2 ? a.qn[qrow] : 0.f;
     }
-    if constexpr (RJ) asm volatile("s_waitcnt vmcnt(0)" ::: "memory", RJ_CLOBBER_AGPRS);  // (the loads into named registers are asm: nobody else waits for them)
     u64* mylists = lists + (long long)(wave * NQW * 32) * RQ_KCAP;  // wave-private: queries are never shared between waves
     if (!SEED) {
         for (int i = lane; i < NQW * 32 * RQ_KCAP; i += 64) mylists[i] = 0;
@@ -304,68 +246,35 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void lvs_rq_kernel(const Lvs
     };
     // one unit of the current block: UK fragment reads (AD - 1 steps ahead of their MFMAs through a ring of AD registers) and
     // UK x NQW MFMAs; then the fragment base moves to the ring's next slot
-    half8 Af[AD];
-    auto preread = [&]() {  // XBAR: the first fragments of the unit at o_base
-        static_for<AD - 1>([&](auto jc) {
-            constexpr int jj = decltype(jc)::value;
-            if constexpr (RJ) rj_read_a<jj % AD, jj * 32>(o_base);
-            else lds_read16<jj * 32>(Af[jj % AD], o_base);
-        });
-    };
     auto mfma_phase = [&](auto khc, const IssuePrep& pr) {
         constexpr int kh = decltype(khc)::value;
-        const unsigned delta = slot + 1 == G::RING ? (unsigned)(-(G::RING - 1) * G::UB) : (unsigned)G::UB;
-        const unsigned o_next = o_base + delta;
-        if constexpr (!XBAR) {
-            static_for<AD - 1>([&](auto jc) {
-                constexpr int jj = decltype(jc)::value;
-                if constexpr (RJ) rj_read_a<jj % AD, jj * 32>(o_base);
-                else if constexpr (jj < UK) lds_read16<jj * 32>(Af[jj % AD], o_base);
-            });
-        }
+        half8 Af[AD];
+        static_for<AD - 1>([&](auto jc) {
+            constexpr int jj = decltype(jc)::value;
+            if constexpr (jj < UK) lds_read16<jj * 32>(Af[jj % AD], o_base);
+        });
         static_for<UK>([&](auto jc) {
             constexpr int jj = decltype(jc)::value;
             constexpr int ahead = jj + AD - 1;
-            if (dbg & 8) {
-            } else if constexpr (RJ) {
-                if constexpr (ahead < UK) rj_read_a<ahead % AD, (ahead < UK ? ahead : 0) * 32>(o_base);
-                else if constexpr (XBAR) rj_read_a<ahead % AD, (ahead >= UK ? ahead - UK : 0) * 32>(o_next);
-            } else if constexpr (ahead < UK)
-                lds_read16<ahead * 32>(Af[ahead % AD], o_base);
-            else if constexpr (XBAR)
-                lds_read16<(ahead - UK) * 32>(Af[ahead % AD], o_next);  // the next unit's slot: certified at this unit's barrier
+            if constexpr (ahead < UK) lds_read16<ahead * 32>(Af[ahead % AD], o_base);
             if constexpr (SPREAD) {  // piece p of the NEXT-but-three unit's staging goes out at step p * UK / (LPW + 1) + 1
                 constexpr int piece = rq_piece_at(jj, UK, G::LPW);
-                if constexpr (piece >= 0)
-                    if (!(dbg & 1)) issue_piece(std::integral_constant<int, piece>{}, pr);
+                if constexpr (piece >= 0) issue_piece(std::integral_constant<int, piece>{}, pr);
             }
             __builtin_amdgcn_sched_barrier(0);
-            if (dbg & 4) {
-            } else if constexpr (RJ) {
-                if (!(dbg & 8)) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"((XBAR || ahead < UK) ? AD - 1 : (UK - 1 - jj)) : "memory");
-                static_for<NQW>([&](auto qbc) {
-                    constexpr int qb = decltype(qbc)::value;
-                    constexpr int frag = qb * NJ + kh * UK + jj;
-                    if constexpr (frag < RJ_NB_AGPR) rj_mfma_aa<jj % AD, (frag < RJ_NB_AGPR ? frag : 0)>(acc[qb]);
-                    else rj_mfma_av<jj % AD>(acc[qb], breg[qb][kh * UK + jj]);
-                });
-            } else {
-                rq_lds_wait<(XBAR || ahead < UK) ? AD - 1 : (UK - 1 - jj)>(Af[jj % AD]);
+            rq_lds_wait<(ahead < UK) ? AD - 1 : (UK - 1 - jj)>(Af[jj % AD]);
 #pragma unroll
-                for (int qb = 0; qb < NQW; ++qb)
-                    acc[qb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Af[jj % AD], breg[qb][kh * UK + jj], acc[qb], 0, 0, 0);
-            }
+            for (int qb = 0; qb < NQW; ++qb)
+                acc[qb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Af[jj % AD], breg[qb][kh * UK + jj], acc[qb], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         });
         ++slot;
+        const unsigned delta = slot == G::RING ? (unsigned)(-(G::RING - 1) * G::UB) : (unsigned)G::UB;
         if (slot == G::RING) slot = 0;
-        o_base = o_next;
+        o_base += delta;
     };
     // ---- block epilogue: 32 rows x this wave's queries; lane holds query qidx[*], rows row0 + (r&3) + 8*(r>>2) + 4*(lane>>5)
     auto epilogue = [&](int blk) {
-        // (inline-asm MFMAs are invisible to hipcc's hazard recogniser: the wait states between the last MFMA of a block and
-        // the first VALU read of its result are spelled out)
-        if constexpr (RJ) asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[0]), "+v"(acc[NQW - 1]));
         const long long row0 = (b0 + blk) * 32;
         const long long rbase = row0 + 4 * (lane >> 5);
         const float* sideb = side + (blk % NB_RING) * NQW * 64;
@@ -478,12 +387,6 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void lvs_rq_kernel(const Lvs
     // waits for the same number of younger loads; a late wave's accumulators and side words outlive the block by one unit
     // (the side ring holds the blocks in flight + 2).
     const bool late = PHASED && wave < WAVES / 2;
-    if constexpr (XBAR) {  // unit 0 certified by a barrier of its own; from then on every barrier certifies one unit ahead
-        static_assert(G::RING >= 4, "XBAR keeps RING - 3 units in flight behind the certified one");
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((G::RING - 2) * G::LPW) : "memory");
-        __builtin_amdgcn_s_barrier();
-        preread();
-    }
     for (int blk = 0; blk < nblk; ++blk) {
         static_for<G::U>([&](auto khc) {
             constexpr int kh = decltype(khc)::value;
@@ -492,8 +395,8 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void lvs_rq_kernel(const Lvs
             // half-load and the 4-byte side words ride in the same queue: with them more than LPW loads per unit are in flight
             // behind unit n, so the wait is only more conservative); the barrier makes that true for every wave's share and
             // tells everybody that unit n - 1's slot is free again
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((G::RING - (XBAR ? 3 : 2)) * G::LPW) : "memory");
-            if (!(dbg & 16)) __builtin_amdgcn_s_barrier();
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((G::RING - 2) * G::LPW) : "memory");
+            __builtin_amdgcn_s_barrier();
             const IssuePrep pr = issue_prep(n + G::RING - 1);
             if (!late) {
                 if (!SPREAD) {
@@ -512,7 +415,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void lvs_rq_kernel(const Lvs
                 if (!SPREAD) static_for<G::LPW + 1>([&](auto pc) { issue_piece(pc, pr); });
             }
         });
-        if (!late && !(dbg & 2)) epilogue(blk);
+        if (!late) epilogue(blk);
     }
     if (late) epilogue(nblk - 1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the clamped tail loads still target the ring
@@ -539,7 +442,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void lvs_rq_kernel(const Lvs
     }
 }
 
-template <int NJ, int UK, int WAVES, int NQW, int AD, int KCAP, bool SEED, bool XBAR = false, int DBG = 0>
+template <int NJ, int UK, int WAVES, int NQW, int AD, int KCAP, bool SEED>
 hipError_t rq_launch_k(const LvsRqArgs& a, int grid, hipStream_t stream) {
     using G = RqGeom<NJ, UK, WAVES, NQW, KCAP>;
     const size_t lds = (size_t)G::lds_bytes(G::RING);
@@ -548,19 +451,19 @@ hipError_t rq_launch_k(const LvsRqArgs& a, int grid, hipStream_t stream) {
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
     if (!attr.done(dev, lds)) {
-        e = hipFuncSetAttribute((const void*)lvs_rq_kernel<NJ, UK, WAVES, NQW, AD, KCAP, SEED, XBAR, DBG>,
+        e = hipFuncSetAttribute((const void*)lvs_rq_kernel<NJ, UK, WAVES, NQW, AD, KCAP, SEED>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         attr.set(dev, lds);
     }
     if (a.groups > 1 && WAVES * NQW * 32 != LVS_RQ_GROUPQ) return hipErrorInvalidValue;  // groups are the eight-wave variant's
-    hipLaunchKernelGGL((lvs_rq_kernel<NJ, UK, WAVES, NQW, AD, KCAP, SEED, XBAR, DBG>), dim3(grid), dim3(WAVES * 64), lds, stream, a);
+    hipLaunchKernelGGL((lvs_rq_kernel<NJ, UK, WAVES, NQW, AD, KCAP, SEED>), dim3(grid), dim3(WAVES * 64), lds, stream, a);
     return hipGetLastError();
 }
-template <int NJ, int UK, int WAVES, int NQW, int AD, bool SEED, bool XBAR = false>
+template <int NJ, int UK, int WAVES, int NQW, int AD, bool SEED>
 hipError_t rq_launch_one(const LvsRqArgs& a, int grid, hipStream_t stream) {
-    if (a.k <= 12) return rq_launch_k<NJ, UK, WAVES, NQW, AD, 12, SEED, XBAR && (RqGeom<NJ, UK, WAVES, NQW, 12>::RING >= 4)>(a, grid, stream);
-    return rq_launch_k<NJ, UK, WAVES, NQW, AD, RQ_KMAX, SEED, XBAR && (RqGeom<NJ, UK, WAVES, NQW, RQ_KMAX>::RING >= 4)>(a, grid, stream);
+    if (a.k <= 12) return rq_launch_k<NJ, UK, WAVES, NQW, AD, 12, SEED>(a, grid, stream);
+    return rq_launch_k<NJ, UK, WAVES, NQW, AD, RQ_KMAX, SEED>(a, grid, stream);
 }
 
 // up to 128 queries: four waves (one per SIMD), one query block each; up to 256: eight waves (two per SIMD, 256 registers
@@ -574,30 +477,10 @@ hipError_t rq_launch_shape(const LvsRqArgs& a, int grid, hipStream_t stream) {
 #endif
     if (a.nq <= 128) return rq_launch_one<NJ, UK, 4, 1, 6, SEED>(a, grid, stream);
 #ifdef LVS_TUNING
-    if constexpr (NJ == 48)
-        if (lvs_tune("LVS_RQ_MODE", 0) == 2) {
-#ifdef LVS_TUNING
-            if (!SEED && a.k <= 12) {  // timing ablations of the four-wave form (LVS_RQ_DEBUG bits, see LvsRqArgs::debug)
-                switch (a.debug) {
-                    case 1: return rq_launch_k<NJ, UK, 4, 2, 4, 12, SEED, true, 1>(a, grid, stream);
-                    case 2: return rq_launch_k<NJ, UK, 4, 2, 4, 12, SEED, true, 2>(a, grid, stream);
-                    case 3: return rq_launch_k<NJ, UK, 4, 2, 4, 12, SEED, true, 3>(a, grid, stream);
-                    case 18: return rq_launch_k<NJ, UK, 4, 2, 4, 12, SEED, true, 18>(a, grid, stream);
-                    case 19: return rq_launch_k<NJ, UK, 4, 2, 4, 12, SEED, true, 19>(a, grid, stream);
-                    case 27: return rq_launch_k<NJ, UK, 4, 2, 4, 12, SEED, true, 27>(a, grid, stream);
-                    default: break;
-                }
-            }
-#endif
-            if (lvs_tune("LVS_RQ_XBAR", 1) != 0) return rq_launch_one<NJ, UK, 4, 2, 4, SEED, true>(a, grid, stream);
-            return rq_launch_one<NJ, UK, 4, 2, 4, SEED, false>(a, grid, stream);
-        }
+    if (a.groups == 1 && lvs_tune("LVS_RQ_MODE", 0) == 2) return rq_launch_one<NJ, UK, 4, 2, 3, SEED>(a, grid, stream);
 #endif
     // (the depth of the fragment read-ahead makes no difference with two waves per SIMD - 2 / 3 / 4 registers sets measured
     // alike, profiles/r07_tuning.md - and at d = 768 the B fragments leave 64 registers for everything else: two sets)
-#ifdef LVS_TUNING
-    if (!SEED && lvs_tune("LVS_RQ_XBAR", 0) != 0) return rq_launch_one<NJ, UK, 8, 1, 2, SEED, true>(a, grid, stream);
-#endif
     return rq_launch_one<NJ, UK, 8, 1, (NJ >= 48 ? 2 : 3), SEED>(a, grid, stream);
 }
 
@@ -610,6 +493,10 @@ static int rq_max_ranges(int groups) { return lvs_rq_ranges_for(groups); }
 // Does the register-resident-queries kernel take this call?  fp16 k-slices of one K segment (d padded to 256, 384, 512 or
 // 768 halfs), k <= 16, a corpus long enough to give every CU a few blocks, and 97 .. 256 queries - or up to LVS_RQ_MAXQ in
 // groups of 256 when the groups' workgroups fill (nearly) every CU (>= 224 of 256): 2 .. 8, 10, 14, 15 or 16 groups.
+bool lvs_rq_shape_ok(int dpad, int k) {  // operand shapes the register-resident kernels are built for
+    const int nj = dpad / 16;
+    return dpad % 16 == 0 && k >= 1 && k <= RQ_KMAX && (nj == 16 || nj == 24 || nj == 32 || nj == 48);
+}
 bool lvs_rq_fits(int64_t nq, int64_t nb, int dpad, int k) {
     const int nj = dpad / 16;
     if (!(nq > 96 && nq <= LVS_RQ_MAXQ && k >= 1 && k <= RQ_KMAX && nb >= 32768 && (nj == 16 || nj == 24 || nj == 32 || nj == 48))) return false;
@@ -631,10 +518,9 @@ hipError_t lvs_rq_launch(LvsRqArgs& a, int dpad, hipStream_t stream) {
     a.blocks_per_wg = (int)((nblocks + ranges - 1) / ranges);
     ranges = (nblocks + a.blocks_per_wg - 1) / a.blocks_per_wg;
     a.nparts = (int)ranges;
-    if (a.groups > 32 && a.groups % 32 != 0) return hipErrorInvalidValue;
+    if (a.groups > 32 && a.groups % 32 != 0) return hipErrorInvalidValue;  // (chunks of a larger call: 32 x 2^i groups)
     const int grid = lvs_rq_grid(a.groups, (int)ranges);
     const bool seed = a.seed_out != nullptr;
-    a.debug = (int)lvs_tune("LVS_RQ_DEBUG", 0);
     switch (dpad / 16) {
         case 48: return seed ? rq_launch_shape<48, 24, true>(a, grid, stream) : rq_launch_shape<48, 24, false>(a, grid, stream);
         case 32: return seed ? rq_launch_shape<32, 32, true>(a, grid, stream) : rq_launch_shape<32, 32, false>(a, grid, stream);

@@ -270,6 +270,8 @@ __host__ __device__ inline bool lvs_rq_item(int b, int groups, int nparts, int& 
     return range < nparts;
 }
 bool lvs_rq_fits(int64_t nq, int64_t nb, int dpad, int k);
+bool lvs_rq_shape_ok(int dpad, int k);
+#define LVS_RQ_JOIN_MINROWS 65536  // shortest corpus (shard) a chunked call takes: 2 ranges of 1 024 blocks at 128 groups
 hipError_t lvs_rq_launch(LvsRqArgs& a, int dpad, hipStream_t stream);
 // ---- lvs_rj.hip: the same launches with ONE wave per SIMD and 64 queries per wave (B fragments in named accumulation registers)
 #define LVS_RJ_DEFAULT 1    // launches lvs_rj_fits accepts go through lvs_rj_kernel (1) or lvs_rq_kernel (0)

@@ -22,8 +22,7 @@ cq = be.pack(unit(NQ, 768), _capi.PACK_F16)
 os.environ["LVS_RQ_CHUNK"] = str(max(4096, NQ))
 os.environ["LVS_RQ_JOIN"] = "1"
 os.environ["LVS_RJ"] = "1"
-ABL = ((0, "full"), (1, "no staging loads"), (2, "no epilogue"), (6, "filter only"), (3, "no staging, no epilogue"), (18, "no epilogue, no barrier"),
-       (19, "MFMA + reads only"))
+ABL = ((0, "full"), (512, "no publication (atomicMax)"), (128, "no drains (visits stay)"), (2, "no epilogue"))
 for mode, xbar in (("0", "1"),):
     os.environ["LVS_RQ_MODE"] = mode
     os.environ["LVS_RQ_XBAR"] = xbar
@@ -42,3 +41,17 @@ for mode, xbar in (("0", "1"),):
         units = 1_000_000 / ranges / 32 * 2
         cyc = ms * 1e-3 / units * (p.get("sclk_mhz") or 0) * 1e6
         print(f"mode {mode} xbar {xbar} {what:26s}: kernel {ms:6.3f} ms  sclk {p.get('sclk_mhz')} MHz  {p.get('power_w')} W  ~{cyc:5.0f} cycles per unit", flush=True)
+
+# cycle / event counters of the instrumented instantiation (LVS_RQ_DEBUG=32)
+import ctypes
+os.environ["LVS_RQ_DEBUG"] = "32"
+buf = (ctypes.c_ulonglong * 16)()
+be.search_keys(cb, cq, 10, 0); be.synchronize()
+be.lib.lvs_rj_debug_read(buf)
+be.search_keys(cb, cq, 10, 0); be.synchronize()
+be.lib.lvs_rj_debug_read(buf)
+v = list(buf)
+waves, blocks = max(v[8], 1), max(v[7], 1)
+print(f"stamps (per wave-block): epilogue {v[6] / blocks:.0f} cycles of which visits {v[0] / blocks:.0f} ({v[3] / blocks:.3f} visits of {v[0] / max(v[3], 1):.0f} cycles), "
+      f"drains {v[1] / blocks:.0f} ({v[4] / blocks:.3f} drains of {v[1] / max(v[4], 1):.0f} cycles, {v[5] / max(v[4], 1):.1f} candidates each = {v[1] / max(v[5], 1):.0f} cycles per candidate); "
+      f"vmcnt wait + barrier {v[2] / blocks:.0f} per block; candidates per wave-block {v[5] / blocks:.3f}; waves {waves}, blocks per wave {blocks / waves:.0f}", flush=True)
