@@ -99,6 +99,10 @@ def parse():
     ap.add_argument("--dedup-rows", type=int, default=5_000_000, help="configs[3] leg: rows of the threshold self-join (0 = skip)")
     ap.add_argument("--kmeans-rows", type=int, default=10_000_000, help="configs[4] legs: rows (0 = skip)")
     ap.add_argument("--kmeans-k", type=int, default=1024)
+    ap.add_argument("--split", choices=("rows", "queries", "auto"), default="rows",
+                    help="N > 1: 'rows' = BASELINE's configuration (corpus row-sharded, RCCL all-gather + top-k merge); 'queries' = "
+                         "every GPU holds the corpus and answers Q / N queries (one all-gather, no merge); 'auto' = whichever "
+                         "lotus_amd.plan.pick_split projects ahead for this shape")
     return ap.parse_args()
 
 
@@ -191,17 +195,36 @@ def main():
         fut_km = pool.submit(benchdata.blobs, benchdata.CFG_KMEANS, args.kmeans_rows, d, args.kmeans_k)
     xb_h, xq_h, planted_h, shm_dir = shared_inputs(np, dist, benchdata, world, rank, n, d, nq)
     gen_s = time.perf_counter() - t_gen0
-    per = -(-n // world)
-    lo, hi = min(n, rank * per), min(n, (rank + 1) * per)
-    corpus = be.pack(xb_h[lo:hi], _capi.PACK_F16)  # this rank's shard, resident
+    # the split of the join over the ranks: BASELINE configs[2] names the ROW split (corpus sharded, RCCL top-k merge) - the
+    # default; --split queries / auto runs the query split (the planner's choice when the corpus fits every GPU)
+    split = args.split
+    if split == "auto":
+        from lotus_amd import plan as _plan
+
+        gq_, gc_ = _plan.pick_split(world, nq=nq, nb=n, d=d) if world > 1 else (1, 1)
+        split = "queries" if gq_ == world and world > 1 else "rows"
+    if world == 1:
+        split = "rows"
+    per = -(-n // world) if split == "rows" else n
+    lo, hi = (min(n, rank * per), min(n, (rank + 1) * per)) if split == "rows" else (0, n)
+    qper = -(-nq // world) if split == "queries" else nq
+    q_lo, q_hi = (min(nq, rank * qper), min(nq, (rank + 1) * qper)) if split == "queries" else (0, nq)
+    corpus = be.pack(xb_h[lo:hi], _capi.PACK_F16)  # this rank's shard (row split) or the whole corpus (query split), resident
     queries = be.pack(xq_h, _capi.PACK_F16)  # replicated
+    my_queries = be.slice_rows(queries, q_lo, q_hi) if split == "queries" else queries
     planted = torch.from_numpy(planted_h).to(device)
 
     # row-sharded join: every shard's starting thresholds come from ALL shards' samples (one small all-gather before the
     # search, lvs_flat_search_seed_scores / lvs_flat_search_keys_seeded - what HipVS(shard=True).__call__ does)
-    seed_tiles = be.seed_tiles(nq, per, k, _capi.PACK_F16, _capi.PACK_F16) if world > 1 else 0
+    seed_tiles = be.seed_tiles(nq, per, k, _capi.PACK_F16, _capi.PACK_F16) if (world > 1 and split == "rows") else 0
 
     def step():
+        if split == "queries":  # every rank answers its own queries against the whole corpus; one all-gather concatenates
+            keys = be.search_keys(corpus, my_queries, k, _capi.METRIC_IP)
+            if keys.shape[0] < qper:  # (the last rank's slice may be short: equal blocks for the all-gather)
+                keys = torch.cat([keys, torch.zeros((qper - keys.shape[0], k), dtype=keys.dtype, device=keys.device)])
+            keys = _dist.all_gather_rows(keys).reshape(world * qper, k)[:nq].contiguous()
+            return keys, be.keys_to_result(keys, _capi.METRIC_IP)
         seeds = None
         if seed_tiles:
             seeds = _dist.all_gather_rows(be.seed_scores(corpus, queries, _capi.METRIC_IP, seed_tiles)).reshape(world * seed_tiles, nq)
@@ -219,11 +242,15 @@ def main():
         keys, (D, I) = step()
     barrier()
     be.timing_enable(True)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        keys, (D, I) = step()
-    barrier()
-    dt = time.perf_counter() - t0
+    from powermon import PowerMonitor  # board power / engine clock sampled in a background thread during the timed steps
+
+    with PowerMonitor(index=dev_index, skip=0.15) as pmon:
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            keys, (D, I) = step()
+        barrier()
+        dt = time.perf_counter() - t0
+    power = pmon.summary()
     ktime = be.timing_read_full()
     ktot_ms, klaunches, kcalls = ktime["total_ms"], ktime["launches"], ktime["calls"]
     be.timing_enable(False)
@@ -240,7 +267,7 @@ def main():
         # register-resident-queries kernels beyond 4 096 queries - one launch per chunk of up to 32 768 queries: the roofline
         # figure is (algorithmic flops of the launches) / (their summed durations) = flops per launch / average launch duration
         # with both averaged over the same launches; `kernel_ms` is the dominant kernel's time per STEP, `launches` per step
-        flops_per_step = 2.0 * nq * (hi - lo) * d
+        flops_per_step = 2.0 * (q_hi - q_lo) * (hi - lo) * d
         kernel_ms = ktot_ms / max(1, kcalls)
         launches_per_step = klaunches / max(1, kcalls)
         flops_per_launch = flops_per_step / max(1.0, launches_per_step)
@@ -260,9 +287,12 @@ def main():
             "vs_baseline": None,
             "dtype": "f16",
             "data": "synthetic" if not rehearsal else "synthetic; REHEARSAL: all ranks on one GPU over gloo - not a measurement",
-            "config": {"workload": f"sem_sim_join {nq} x {n} rows, d={d} fp16, k={k}, IP; corpus row-sharded over {world} "
-                                   f"GPU(s) ({hi - lo} rows each), pooled sample thresholds + RCCL all-gather top-k merge; "
-                                   "device-resident in/out",
+            "config": {"workload": (f"sem_sim_join {nq} x {n} rows, d={d} fp16, k={k}, IP; corpus row-sharded over {world} "
+                                    f"GPU(s) ({hi - lo} rows each), pooled sample thresholds + RCCL all-gather top-k merge; "
+                                    "device-resident in/out") if split == "rows" else
+                                   (f"sem_sim_join {nq} x {n} rows, d={d} fp16, k={k}, IP; QUERY split over {world} GPUs ({qper} queries "
+                                    f"each against the whole corpus), one RCCL all-gather of the key lists; device-resident in/out"),
+                       "split": split,
                        "inputs": f"benchdata.py SeedSequence([{benchdata.SEED},{benchdata.CFG_JOIN},block])"},
             "planted_neighbour_at_rank1": planted_at_1,
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP16_MFMA_TFLOPS, "unit": "TFLOP/s",
@@ -270,6 +300,10 @@ def main():
                          "kernel": ktime["kernel"], "kernel_ms": kernel_ms, "kernel_ms_per_launch": ktot_ms / max(1, klaunches),
                          "launches": klaunches, "launches_per_step": launches_per_step,
                          "algorithmic_flops_per_launch": flops_per_launch, "algorithmic_bytes_per_launch": alg_bytes / max(1.0, launches_per_step),
+                         "sclk_mhz": power.get("sclk_mhz"), "power_w": power.get("power_w"), "power_samples": power.get("samples"),
+                         "power_source": power.get("source") or power.get("error"),
+                         "gflop_per_joule": (flops_per_step * world / (dt / args.steps) / power["power_w"] / 1e9 / world
+                                             if power.get("power_w") else None),
                          "csrc_sha": csrc_hash()},
         }
         details = {"gen_s": gen_s, "hbm_frac_secondary": alg_bytes / (kernel_ms * 1e-3) / 1e9 / PEAK_HBM_GBS}
@@ -304,6 +338,11 @@ def main():
             fn()
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(np, xb_h, xq_h, args.cpu_sample, k, D_h, I_h)
+        if legs.get("t_call_host_to_host"):
+            # SURVEY.md 8(d) calls T_call - VS.__call__(host ndarray) -> host (D, I), corpus resident - "the queries/sec figure"; the
+            # bench contract wants `value` device-resident.  Both are on the line's top level
+            out["value_t_call"] = legs["t_call_host_to_host"]["queries_per_s"]
+            out["value_t_call_note"] = "host ndarray in -> host (D, I) out through HipVS.__call__ (PCIe + packing included), median of 5"
         if legs:
             out["legs"] = legs
             out["legs_summary"] = legs_summary(out, legs)  # printed LAST: the tail of the line holds the figures that matter
@@ -461,6 +500,24 @@ def cpu_baseline(np, xb_h, xq_h, sample, k, Dg=None, Ig=None):
     xb32 = xb_h.astype(np.float32)
     xq32 = xq_h[:sample].astype(np.float32)
     impls = []
+    # If a faiss wheel is importable the reference's CPU path itself is timed - `faiss.IndexFlatIP` + `add` + `search`, exactly
+    # what FaissVS does (lotus/vector_store/faiss_vs.py:14 METRIC_INNER_PRODUCT, :23-24 index_factory + add, :75 search) - and it IS
+    # the stated baseline (kind "reference"), whatever the twins below measure.  No wheel exists in this image.
+    faiss_impl = None
+    try:
+        import faiss  # noqa: F401
+
+        def _faiss_search(xb, xq, kk):
+            index = faiss.index_factory(int(xb.shape[1]), "Flat", faiss.METRIC_INNER_PRODUCT)
+            index.add(np.ascontiguousarray(xb, dtype=np.float32))
+            Df, If = index.search(np.ascontiguousarray(xq, dtype=np.float32), int(kk))
+            return Df, If, int(faiss.omp_get_max_threads())
+
+        faiss_impl = ("faiss-cpu index_factory('Flat', METRIC_INNER_PRODUCT).search - the reference's own CPU path (faiss_vs.py:23-24,75)",
+                      _faiss_search)
+        impls.append(faiss_impl)
+    except ImportError:
+        pass
     if blas_twin.c_available():
         impls.append(("oracle/c/lvs_blas_twin.c (C + OpenMP, AVX-512 sgemm micro-kernel fused with the k-best collector)",
                       blas_twin.flat_search_c))
@@ -506,13 +563,17 @@ def cpu_baseline(np, xb_h, xq_h, sample, k, Dg=None, Ig=None):
             # (recall counts a swap across the k-th boundary inside a near-tie - scores < 2e-5 apart, different summation
             # order - as a miss; such swaps are not id mismatches)
     best = max(runs, key=lambda r: r["queries_per_s"])
+    if faiss_impl is not None:
+        best = next(r for r in runs if r["impl"] == faiss_impl[0])
     quota = _cpu_quota()
     # cores = CPUs the timed comparator could actually occupy: its threads, capped by the container's cgroup quota
     cores = int(min(best["threads"], quota)) if quota else int(best["threads"])
     cores_note = (f"{best['threads']} threads under a cgroup quota of {quota:g} CPUs ({os.cpu_count()} visible)" if quota else
                   f"{best['threads']} threads, {os.cpu_count()} CPUs visible, no cgroup quota")
-    short = "C+OpenMP AVX-512 sgemm+k-best twin" if "lvs_blas_twin.c" in best["impl"] else "torch-CPU MKL sgemm+topk"
-    out = {"value": best["queries_per_s"], "unit": "queries/s", "cores": cores, "cores_note": cores_note, "kind": "port",
+    short = ("faiss-cpu IndexFlatIP (the reference's dependency)" if faiss_impl is not None else
+             "C+OpenMP AVX-512 sgemm+k-best twin" if "lvs_blas_twin.c" in best["impl"] else "torch-CPU MKL sgemm+topk")
+    out = {"value": best["queries_per_s"], "unit": "queries/s", "cores": cores, "cores_note": cores_note,
+           "kind": "reference" if faiss_impl is not None else "port",
            "sample": f"first {best['queries']} queries x full {xb32.shape[0]}-row corpus, {short}, {best['seconds']:.1f} s",
            "gflops": best["gflops"], "threads": best["threads"], "host_cpus": os.cpu_count(), "host_cpu_quota": quota,
            "comparators_timed": runs}

@@ -40,9 +40,16 @@ def import_lotus():
                 importlib.import_module(name)
             except Exception:
                 sys.modules[name] = _Stub(name)
-    import fake_faiss
+    # the real faiss when a wheel is importable (then the reference's operators run on its own arithmetic); else the
+    # faiss-shaped double over the CPU oracle (tests/fake_faiss.py; tests/test_faiss_pin.py holds the two to each other)
+    try:
+        if os.environ.get("LOTUS_TESTS_FORCE_FAKE_FAISS") == "1":
+            raise ImportError("forced")
+        import faiss as _real_faiss  # noqa: F401
+    except ImportError:
+        import fake_faiss
 
-    sys.modules["faiss"] = fake_faiss
+        sys.modules["faiss"] = fake_faiss
     if REFERENCE not in sys.path:
         sys.path.insert(0, REFERENCE)
     for k in [k for k in sys.modules if k == "lotus" or k.startswith("lotus.")]:
