@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define LVS_ABI_VERSION 6 /* 2: pack modes in lvs_flat_search_workspace_bytes, lvs_build_flags, k-means device update;
+#define LVS_ABI_VERSION 7 /* 2: pack modes in lvs_flat_search_workspace_bytes, lvs_build_flags, k-means device update;
                              3: k-means iteration entirely on the device (objective, split, repack, accumulate from keys),
                                 lvs_pack_rows_checked (validation + power-of-two scale), lvs_absmax, lvs_margin_select_stats;
                                 scale exponents in lvs_unpack_rows / lvs_keys_to_result / lvs_scores / lvs_range_join;
@@ -348,6 +348,38 @@ int32_t lvs_kmeans_pack_centroids(const float* centroids, int32_t k, int32_t d, 
 int32_t lvs_kmeans_update_centroids(const float* sums, float* counts, int32_t k, int32_t d, int64_t n_train, float* centroids,
                                     int32_t* out_nsplit, int32_t pack_mode, void* packed_out, float* norms_out,
                                     float* stats_out, void* stream);
+/* ---- (ABI 7) ONE Lloyd iteration of faiss `Clustering::train` as one call (lotus/utils.py:61-62) - SURVEY.md 8(b)'s
+ * `lvs_kmeans`, cut at the iteration so that the caller owns the loop, the subsample and the initial centroids
+ * (lvs_rand_perm_host).  x: this rank's n training rows (packed, |x|^2 beside them; x_norms_sq_sum = device float64, their sum);
+ * centroids [k][d] float32 (in: the iteration's centroids; out: the next ones), c_packed / c_norms / c_stats = their hi|lo
+ * image as lvs_kmeans_pack_centroids / this call leave it (c_pack must be LVS_PACK_SPLIT: fp32-accurate centroids; k <=
+ * LVS_NEAREST3_MAX_ROWS); exp_sum = pack exponent of x + pack exponent of the centroids (0 for unscaled rows).
+ * Out: out_keys [n] = the iteration's assignment (row i -> centroid id(key)), *out_obj (device float64) = faiss's objective
+ * of the iteration (in the rows' stored domain), *out_nsplit (device int32, nullable) = clusters split_clusters re-seeded,
+ * out_host_counts (HOST int64[2], nullable) = rows settled by two exact dot products / by the exact search.
+ * What it runs: lvs_nearest3 -> lvs_nearest3_select -> lvs_resolve_pairs -> exact lvs_flat_search_keys of the open rows ->
+ * lvs_kmeans_accumulate_keys -> lvs_kmeans_objective -> [all_reduce of sums | counts (float32) and the objective (float64)]
+ * -> lvs_kmeans_update_centroids with n_train_total (all ranks' training rows; the split replays identically on every rank).
+ * Bit-identical to issuing those calls one by one (lotus_amd/cluster.py).  THE ONE ENTRY POINT THAT SYNCHRONISES `stream`:
+ * once per 2 GiB of search scratch (once per call up to ~100 M rows x 1 024 centroids), to size the exact search of the open rows.
+ * all_reduce (nullable = single rank): in-place sum of `count` values of dtype 0 = float32 / 1 = float64 across the ranks,
+ * enqueued on `stream`; 0 on success. */
+typedef int32_t (*lvs_all_reduce_fn)(void* ctx, void* buf, int64_t count, int32_t dtype, void* stream);
+int64_t lvs_kmeans_iteration_workspace_bytes(int64_t n, int32_t d, int32_t k, int32_t x_pack, int32_t c_pack);
+int32_t lvs_kmeans_iteration(lvs_all_reduce_fn all_reduce, void* all_reduce_ctx, const void* x, int32_t x_pack, int64_t n,
+                             int32_t d, const float* x_norms_sq, const double* x_norms_sq_sum, int32_t exp_sum, int32_t k,
+                             int64_t n_train_total, float* centroids, int32_t c_pack, void* c_packed, float* c_norms,
+                             float* c_stats, uint64_t* out_keys, double* out_obj, int32_t* out_nsplit,
+                             int64_t* out_host_counts, void* workspace, int64_t workspace_bytes, void* stream);
+/* The same with RCCL as the transport: two ncclAllReduce calls (sum) on the caller's communicator and stream (SURVEY.md 8(e)
+ * row 3).  librccl is resolved at run time as for lvs_search_sharded_rccl; a process holding several copies names the one
+ * its communicator belongs to with lvs_rccl_bind_all_reduce(address of its ncclAllReduce; NULL unbinds). */
+int32_t lvs_rccl_bind_all_reduce(void* nccl_all_reduce);
+int32_t lvs_kmeans_iteration_rccl(void* nccl_comm, const void* x, int32_t x_pack, int64_t n, int32_t d, const float* x_norms_sq,
+                                  const double* x_norms_sq_sum, int32_t exp_sum, int32_t k, int64_t n_train_total,
+                                  float* centroids, int32_t c_pack, void* c_packed, float* c_norms, float* c_stats,
+                                  uint64_t* out_keys, double* out_obj, int32_t* out_nsplit, int64_t* out_host_counts,
+                                  void* workspace, int64_t workspace_bytes, void* stream);
 /* ---- exact distance bounds across k-means iterations (Hamerly): rows whose nearest centroid provably has not changed are
  * not searched again - same assignments as faiss's exhaustive iteration (lotus/utils.py:62), less work once the centroids
  * settle.  Per training row: assign (int32, -1 = unknown), ub >= its distance to the assigned centroid, lb <= its distance

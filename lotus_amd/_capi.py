@@ -18,7 +18,7 @@ METRIC_IP, METRIC_L2 = 0, 1
 PACK_F16, PACK_SPLIT = 0, 1
 MAX_K = 2048
 NEAREST3_MAX_ROWS = 16384
-ABI_VERSION = 6
+ABI_VERSION = 7
 BUILD_TUNING, BUILD_COUNT_EVENTS = 1, 2
 PACK_FLAG_NONFINITE, PACK_FLAG_RANGE = 1, 2
 
@@ -90,6 +90,12 @@ SIGNATURES = {
     "lvs_rand_perm_host": (_i32, [_i64, _i64, _vp]),
     "lvs_rand_perm_prefix_host": (_i32, [_i64, _i64, _i64, _vp]),
     "lvs_kmeans_split_clusters_host": (_i32, [_i32, _i32, _i64, _vp, _vp, ctypes.POINTER(_i32)]),
+    "lvs_kmeans_iteration_workspace_bytes": (_i64, [_i64, _i32, _i32, _i32, _i32]),
+    "lvs_kmeans_iteration": (_i32, [_vp, _vp, _vp, _i32, _i64, _i32, _vp, _vp, _i32, _i32, _i64, _vp, _i32, _vp, _vp, _vp, _vp, _vp,
+                                    _vp, _vp, _vp, _i64, _vp]),
+    "lvs_kmeans_iteration_rccl": (_i32, [_vp, _vp, _i32, _i64, _i32, _vp, _vp, _i32, _i32, _i64, _vp, _i32, _vp, _vp, _vp, _vp, _vp,
+                                         _vp, _vp, _vp, _i64, _vp]),
+    "lvs_rccl_bind_all_reduce": (_i32, [_vp]),
     "lvs_timing_enable": (_i32, [_i32]),
     "lvs_timing_read": (_i32, [ctypes.POINTER(_dbl), ctypes.POINTER(_i64)]),
     "lvs_timing_read_calls": (_i32, [ctypes.POINTER(_dbl), ctypes.POINTER(_i64), ctypes.POINTER(_i64), ctypes.POINTER(_i32)]),

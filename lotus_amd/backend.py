@@ -1051,6 +1051,51 @@ class HipBackend:
                 _ptr(nsplit_out), mode, _ptr(rows), _ptr(norms), _ptr(cstats), self._stream())
         return PackedRows(rows=rows, norms=norms, n=k, d=d, mode=mode, exp=int(exp)), cstats
 
+    def kmeans_iteration(self, x: PackedRows, x2, k: int, n_train_total: int, centroids, cpk: PackedRows, cstats, keys_out,
+                         obj_out, nsplit_out=None, all_reduce=None, stats: dict | None = None) -> None:
+        """ONE exhaustive Lloyd iteration as one C-ABI call (``lvs_kmeans_iteration``, ABI 7): the certified assignment of the
+        rows ``x`` against the centroids, the in-row-order sums, the objective, [``all_reduce(tensor)``: the in-place sum over the
+        ranks of a float32 / float64 device tensor], division + faiss's split + repack - ``centroids`` (float32 [k,d]), ``cpk``
+        (their hi|lo image) and ``cstats`` are updated in place, ``keys_out`` [n] receives the assignment, ``obj_out`` (float64
+        [1]) the objective, ``nsplit_out`` (int32 [1]) the split count.  Bit-identical to ``nearest`` + ``kmeans_accumulate_keys``
+        + ``kmeans_objective`` + ``kmeans_finish``.  One host round trip inside (the open rows' count)."""
+        torch = self.torch
+        need = int(self.lib.lvs_kmeans_iteration_workspace_bytes(x.n, x.d, int(k), x.mode, cpk.mode))
+        if need < 0:
+            raise LotusHipError("lvs_kmeans_iteration_workspace_bytes rejected the shape")
+        ws = self._workspace(need)
+        cb, errors = None, []
+        if all_reduce is not None:
+            FN = ctypes.CFUNCTYPE(ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_void_p)
+
+            def transport(_ctx, buf, count, dtype, _stream):
+                try:  # the library's stream is torch's current stream: torch work queued here stays in order
+                    dt, size = (torch.float32, 4) if dtype == 0 else (torch.float64, 8)
+                    all_reduce(torch.as_tensor(_DevBytes(buf, int(count) * size), device=self.device).view(dt))
+                    return 0
+                except Exception as e:  # noqa: BLE001 - reported through the status code
+                    errors.append(e)
+                    return _capi.EDEVICE
+
+            fn = FN(transport)
+            cb = ctypes.cast(fn, ctypes.c_void_p)
+        host_counts = (ctypes.c_int64 * 2)()
+        try:
+            self._c("lvs_kmeans_iteration", cb, None, _ptr(x.rows), x.mode, x.n, x.d, _ptr(x.norms), _ptr(x2),
+                    int(x.exp) + int(cpk.exp), int(k), int(n_train_total), _ptr(centroids), cpk.mode, _ptr(cpk.rows), _ptr(cpk.norms),
+                    _ptr(cstats), _ptr(keys_out), _ptr(obj_out), _ptr(nsplit_out), ctypes.addressof(host_counts), _ptr(ws),
+                    int(ws.numel()), self._stream())
+        except LotusHipError:
+            if errors:
+                raise errors[0]
+            raise
+        if stats is not None:
+            n_pair, n_open = int(host_counts[0]), int(host_counts[1])
+            stats["uncertified"] = stats.get("uncertified", 0) + n_pair + n_open
+            stats["pairs"] = stats.get("pairs", 0) + n_pair
+            stats["open"] = stats.get("open", 0) + n_open
+            stats["queries"] = stats.get("queries", 0) + x.n
+
     def kmeans_update_centroids(self, sums, counts, centroids) -> None:
         """centroids (device float32 [k,d], in place) = sums / counts where counts > 0 (faiss compute_centroids) - the
         division alone, for callers that split empty clusters on the host (``split_clusters``)."""

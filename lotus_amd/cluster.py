@@ -39,6 +39,7 @@ def range_cuts(n: int, fracs) -> list[int]:
 SIDE_STREAM_PRIORITY = 0    # of the stream the sums of a range run on
 # the certificate's tail of a range (count read-back, pair dot products, exact search of the open rows) also runs on the side
 # stream, under the next range's search - the main stream then goes from one assignment launch straight to the next
+USE_ITERATION_OP = True  # single-range exhaustive iterations through lvs_kmeans_iteration (one C-ABI call each)
 PIPELINE_CERTIFICATES = True
 
 
@@ -195,6 +196,11 @@ def kmeans(x, k: int, niter: int = 20, seed: int = 1234, max_points_per_centroid
         can_overlap = not use_bounds and hasattr(be, "kmeans_accumulate_keys_into") and dev.type == "cuda"
         nparts = len(fracs) if (can_overlap and min(fracs) * train.n >= 65536) else 1
         pipelined = nparts > 1 and PIPELINE_CERTIFICATES and hasattr(be, "nearest_begin")
+        # one range, no distance bounds, fp32-accurate centroids of at most 16 384: the iteration is the ABI's single call
+        use_iter_op = (USE_ITERATION_OP and nparts == 1 and not use_bounds and cmode == _capi.PACK_SPLIT and hasattr(be, "kmeans_iteration")
+                       and k <= _capi.NEAREST3_MAX_ROWS and dev.type == "cuda" and niter > 0)
+        if use_iter_op:
+            iter_keys = torch.empty((train.n,), dtype=torch.int64, device=dev)
         if nparts > 1:
             side = torch.cuda.Stream(device=dev, priority=SIDE_STREAM_PRIORITY)
             side_ws = torch.empty(int(be.lib.lvs_kmeans_accumulate_workspace_bytes(train.n, k)) + 256, dtype=torch.uint8, device=dev)
@@ -248,6 +254,17 @@ def kmeans(x, k: int, niter: int = 20, seed: int = 1234, max_points_per_centroid
                 if trace is not None:
                     trace.append({"centroids": centroids.clone(), "keys": torch.cat(kparts)})
                 del held, kparts, pending
+            elif not use_bounds and use_iter_op:
+                # the whole iteration - assignment, sums, objective, all-reduce, division + split + repack - is ONE C-ABI call
+                # (lvs_kmeans_iteration): the same launches in the same order as the branches below issue one by one
+                if trace is not None:
+                    c_before = centroids.clone()
+                be.kmeans_iteration(train, x2, k, nt, centroids, cpk, cstats, iter_keys, obj_dev[it:it + 1], nsplit_dev[it:it + 1],
+                                    all_reduce=(lambda t: _dist.all_reduce_sum_([t], process_group)) if dist is not None else None,
+                                    stats=stats)
+                if trace is not None:
+                    trace.append({"centroids": c_before, "keys": iter_keys.clone().reshape(-1, 1)})
+                continue
             elif not use_bounds:
                 keys = be.nearest(cpk, train, _capi.METRIC_L2, exact_scores=False, corpus_stats=cstats, stats=stats)  # ids only ...
             else:

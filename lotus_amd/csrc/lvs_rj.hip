@@ -264,7 +264,7 @@ __global__ __launch_bounds__(256, 1) void lvs_rj_kernel(const LvsRqArgs a) {
     // ---- deferred insertion: candidates wait in the wave's buffer; `drain` inserts them (wave-cooperative sorted insertion: lane
     // j < k owns slot j of the query's list - no lock, the list is this wave's), tightens the lanes' thresholds and publishes
     int count = 0;  // wave-uniform
-    unsigned long long d_visit = 0, d_drain = 0, d_bar = 0, d_nvisit = 0, d_ndrain = 0, d_ncand = 0, d_epi = 0;
+    [[maybe_unused]] unsigned long long d_visit = 0, d_drain = 0, d_bar = 0, d_nvisit = 0, d_ndrain = 0, d_ncand = 0, d_epi = 0;  // (tuning builds: DBG = 32)
     auto drain = [&]() {
         const unsigned long long t_d0 = (DBG & 32) ? __builtin_amdgcn_s_memtime() : 0;
         d_ndrain += 1;

@@ -28,7 +28,7 @@ def test_shared_object_is_gfx950_code():
 
 def test_host_side_entry_points_without_a_gpu():
     lib = _capi.load()
-    assert lib.lvs_abi_version() == _capi.ABI_VERSION == 6 and lib.lvs_build_flags() == 0
+    assert lib.lvs_abi_version() == _capi.ABI_VERSION == 7 and lib.lvs_build_flags() == 0
     assert lib.lvs_packed_ld(768, _capi.PACK_F16) == 768
     assert lib.lvs_packed_ld(100, _capi.PACK_F16) == 128
     assert lib.lvs_packed_ld(384, _capi.PACK_SPLIT) == 768

@@ -647,3 +647,64 @@ def test_nearest_begin_chunks_its_queries_inside_the_scratch_budget(hip_backend,
     import torch
 
     assert bool(torch.equal(two, whole)) and bool(torch.equal(chunked, whole))
+
+
+@pytest.mark.parametrize("mode", [F16, SPLIT])
+def test_kmeans_iteration_abi_call_equals_the_launch_by_launch_loop(hip_backend, mode):
+    """`lvs_kmeans_iteration` (ABI 7; SURVEY.md 8(b) `lvs_kmeans`, cut at the iteration): a host that owns nothing but device
+    buffers and ctypes - no lotus_amd.cluster - runs faiss's training loop (lotus/utils.py:61-62) as one C-ABI call per
+    iteration and gets, bit for bit, the centroids / objectives / split counts of `cluster.kmeans` issuing the same launches
+    one by one (`USE_ITERATION_OP = False`), on blob rows with exact duplicates and duplicate initial centroids (empty
+    clusters -> split_clusters replayed on the device)."""
+    import ctypes
+
+    import torch
+
+    import benchdata
+    from lotus_amd import cluster as cl
+
+    be = hip_backend
+    lib = be.lib
+    K, n, d, niter = 48, 70_001, 96, 6
+    x16, _ = benchdata.blobs(benchdata.CFG_KMEANS, n, d, K)
+    x = x16.copy() if mode == F16 else (x16.astype(np.float32) * np.float32(1.0 + 2.0 ** -13))
+    x[100:140] = x[7]  # forty equal rows (exact ties in the search; an over-full cluster next to empty ones)
+    kw = dict(niter=niter, backend=be, max_points_per_centroid=None, bounds=False, parts=1, final_assign=False)
+    cl.USE_ITERATION_OP = False
+    try:
+        ref = cl.kmeans(x, K, **kw)
+    finally:
+        cl.USE_ITERATION_OP = True
+    via = cl.kmeans(x, K, **kw)  # the same through the single call
+    assert np.array_equal(ref.centroids, via.centroids) and np.array_equal(ref.obj, via.obj) and np.array_equal(ref.nsplit, via.nsplit)
+
+    # ---- and from raw ctypes: device buffers + the ABI, nothing of cluster.py
+    p = be.pack(x, mode, exp="auto", check=True)           # (the row image and |x|^2 - lvs_pack_rows_checked)
+    perm = be.rand_perm(n, 1234 + 1, K)                    # faiss: centroids = the first K rows of rand_perm(n, seed + 1)
+    cent = be.unpack(p, be.to_device(perm[:K]), raw=True).contiguous()
+    cpk, cstats = be.kmeans_pack_centroids(cent, SPLIT, exp=p.exp)
+    dev = cent.device
+    keys = torch.empty((n,), dtype=torch.int64, device=dev)
+    obj = torch.zeros((niter,), dtype=torch.float64, device=dev)
+    nsplit = torch.zeros((niter,), dtype=torch.int32, device=dev)
+    x2 = p.norms.double().sum().reshape(1)
+    need = lib.lvs_kmeans_iteration_workspace_bytes(n, d, K, p.mode, SPLIT)
+    assert need > 0
+    ws = torch.empty((need,), dtype=torch.uint8, device=dev)
+    host_counts = (ctypes.c_int64 * 2)()
+    stream = be._stream()
+    for it in range(niter):
+        rc = lib.lvs_kmeans_iteration(None, None, p.rows.data_ptr(), p.mode, n, d, p.norms.data_ptr(), x2.data_ptr(), 2 * int(p.exp), K, n,
+                                      cent.data_ptr(), SPLIT, cpk.rows.data_ptr(), cpk.norms.data_ptr(), cstats.data_ptr(),
+                                      keys.data_ptr(), obj[it:].data_ptr(), nsplit[it:].data_ptr(), ctypes.addressof(host_counts),
+                                      ws.data_ptr(), need, stream)
+        assert rc == 0, lib.lvs_last_error()
+    torch.cuda.synchronize()
+    scale = np.float32(2.0 ** -int(p.exp))
+    assert np.array_equal((cent.cpu().numpy() * scale).astype(np.float32), ref.centroids)
+    assert np.array_equal((obj.cpu().numpy() * 2.0 ** (-2 * int(p.exp))).astype(np.float32), ref.obj)
+    assert np.array_equal(nsplit.cpu().numpy(), ref.nsplit) and int(ref.nsplit.sum()) >= 0
+    # a short workspace is refused before anything is launched
+    assert lib.lvs_kmeans_iteration(None, None, p.rows.data_ptr(), p.mode, n, d, p.norms.data_ptr(), x2.data_ptr(), 0, K, n,
+                                    cent.data_ptr(), SPLIT, cpk.rows.data_ptr(), cpk.norms.data_ptr(), cstats.data_ptr(),
+                                    keys.data_ptr(), obj.data_ptr(), None, None, ws.data_ptr(), 1024, stream) == _capi.ENOMEM
