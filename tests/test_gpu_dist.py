@@ -77,7 +77,8 @@ def test_rccl_transport_branch_runs_on_device_tensors():
     assert s == 35.0 and c == 10.0 and o == 3.5
 
 
-def test_bench_self_launches_its_ranks_and_prints_one_line():
+@pytest.mark.parametrize("gpus,split,queries,corpus", [(2, "rows", 4096, 262144), (8, "rows", 20480, 600_003), (8, "queries", 20480, 262144)])
+def test_bench_self_launches_its_ranks_and_prints_one_line(gpus, split, queries, corpus):
     """`python bench.py --gpus 2 ...` with no launcher around it (the form of the driver's N = 1 command): bench.py starts its
     own two ranks under torch.distributed.run, rank 0 prints the one JSON line.  Rehearsal mode (both ranks on cuda:0 over
     gloo) because this box has one GPU - the code path is the N > 1 path of the real run: shared inputs through /dev/shm,
@@ -91,14 +92,17 @@ def test_bench_self_launches_its_ranks_and_prints_one_line():
     env = dict(os.environ, LOTUS_BENCH_REHEARSAL="1")
     for var in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR"):
         env.pop(var, None)
-    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-                        "--queries", "4096", "--corpus", "262144", "--check-sample", "128"],
-                       env=env, cwd=root, capture_output=True, text=True, timeout=900)
+    # (r6: the EIGHT-rank forms too - the driver's N = 8 command on a one-GPU box: row split with 75 000-row shards through the
+    # chunked register-resident path and pooled thresholds, and the query split; RCCL itself cannot run here - two ranks on one
+    # device are refused - so the transport under rehearsal is gloo)
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(gpus), "--steps", "2", "--warmup", "1",
+                        "--queries", str(queries), "--corpus", str(corpus), "--check-sample", "128", "--split", split],
+                       env=env, cwd=root, capture_output=True, text=True, timeout=1500)
     assert p.returncode == 0, p.stderr[-3000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, p.stdout[-2000:]
     out = json.loads(lines[0])
-    assert out["n_gpus"] == 2 and out["steps"] == 2 and out["unit"] == "queries/s"
+    assert out["n_gpus"] == gpus and out["steps"] == 2 and out["unit"] == "queries/s" and out["config"]["split"] == split
     assert out["roofline"]["bound"] == "mfma" and out["roofline"]["frac"] > 0
     assert out["recall_at_k"] == 1.0 and out["id_mismatches_outside_near_ties"] == 0
     assert out["planted_neighbour_at_rank1"] > 0.99
@@ -126,7 +130,9 @@ def _sharded_inputs(hip_backend, n, nq, d, seed):
     return xb, xq, hip_backend.pack(xb, _capi.PACK_F16), hip_backend.pack(xq, _capi.PACK_F16)
 
 
-@pytest.mark.parametrize("sizes", [(90_000, 70_000, 40_000), (120_000, 80_000, 0), (200_000,)])
+@pytest.mark.parametrize("sizes", [(90_000, 70_000, 40_000), (120_000, 80_000, 0), (200_000,),
+                                   # the node's shape: EIGHT shards (one of them empty, one a single ragged block) - r6
+                                   (40_000, 30_000, 25_001, 0, 45_000, 31, 35_000, 24_968)])
 def test_sharded_search_inside_the_library_with_a_thread_all_gather(hip_backend, sizes):
     """lvs_search_sharded on `len(sizes)` ranks = threads of this process, each with its own stream on cuda:0; the all-gather the
     library calls back into is a device copy through a shared pool + a thread barrier.  Uneven shards, an EMPTY shard, pooled
