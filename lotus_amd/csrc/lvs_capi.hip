@@ -1312,7 +1312,11 @@ static int32_t flat_search_impl(const void* xb, int32_t xb_pack, int64_t nb, con
             int64_t sample = nb / 8 / 1024 * 1024;
             // (eight groups or more: a workgroup sees 30 000+ rows and fills its own lists - a quarter of the sample costs the main
             // pass 1 % and saves 3 % of the call; profiles/r09b_rq_groups_sample_probe.log)
-            const int64_t sample_cap = lvs_tune("LVS_RQ_SAMPLE", cn > 7 * LVS_RQ_GROUPQ ? LVS_RQ_SEED_ROWS / 4 : LVS_RQ_SEED_ROWS);
+            // (chunks of 16 384 queries or more see the corpus in <= 4 long ranges whose lists fill at once: half of that sample again
+            // costs the launches nothing and the sample pass half - 100 k x 1 M: call 126.0-127.8 -> 125.4-126.2 ms, same box,
+            // profiles/r12d_knobs.log)
+            const int64_t sample_cap = lvs_tune("LVS_RQ_SAMPLE", cn >= 16384 ? LVS_RQ_SEED_ROWS / 8
+                                                                 : (cn > 7 * LVS_RQ_GROUPQ ? LVS_RQ_SEED_ROWS / 4 : LVS_RQ_SEED_ROWS));
             if (sample > sample_cap) sample = sample_cap;
             if (rq_join && rq_ext_seeds) {
                 // seeded above

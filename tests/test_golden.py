@@ -50,8 +50,8 @@ def test_hip_matches_flat_golden(path, hip_backend, tmp_path):
     vs = HipVS(metric=metric, backend=hip_backend)
     vs.index(None, xb, str(tmp_path / "g"))  # fp16 embeddings -> fp16 storage, bit-identical values on the device
     out = vs(xq, k, ids=None if ids is None else ids.tolist())
-    err, hard, recall = synth.compare_topk(D, I, out.distances, out.indices, atol=1e-5 if metric == 0 else 4e-5)
-    assert err <= (1e-5 if metric == 0 else 4e-5) and hard == 0 and recall == 1.0
+    err, hard, recall = synth.compare_topk(D, I, out.distances, out.indices, atol=1e-5)
+    assert err <= 1e-5 and hard == 0 and recall == 1.0
     assert np.array_equal(out.indices < 0, I < 0)
     if "dups" in path:
         assert np.array_equal(out.indices, I)  # exact ties: id-ascending, exactly as the oracle

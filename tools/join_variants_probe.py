@@ -35,6 +35,15 @@ VARIANTS = {  # name -> environment of the tuning build
     "rjk64k": {"LVS_RQ_JOIN": "1", "LVS_RJ": "1", "LVS_RQ_CHUNK": "65536"},
     "rjk16k_e4": {"LVS_RQ_JOIN": "1", "LVS_RJ": "1", "LVS_RQ_CHUNK": "16384", "LVS_RJ_EVERY": "4"},
     "rjk16k_e64": {"LVS_RQ_JOIN": "1", "LVS_RJ": "1", "LVS_RQ_CHUNK": "16384", "LVS_RJ_EVERY": "64"},
+    "d_s8k": {"LVS_RQ_SAMPLE": "8192"},
+    "d_s4k": {"LVS_RQ_SAMPLE": "4096"},
+    "d_s32k": {"LVS_RQ_SAMPLE": "32768"},
+    "d_e8": {"LVS_RJ_EVERY": "8"},
+    "d_e32": {"LVS_RJ_EVERY": "32"},
+    "d_e4": {"LVS_RJ_EVERY": "4"},
+    "d_64k": {"LVS_RQ_CHUNK": "65536"},
+    "d_16k": {"LVS_RQ_CHUNK": "16384"},
+    "default": {},
     "rjn": {"LVS_RQ_JOIN": "1", "LVS_RQ_MODE": "2", "LVS_RQ_XBAR": "0"},
     "rq2k": {"LVS_RQ_JOIN": "1", "LVS_RQ_CHUNK": "2048"},
     "rqx2k": {"LVS_RQ_JOIN": "1", "LVS_RQ_XBAR": "1", "LVS_RQ_CHUNK": "2048"},
