@@ -1,7 +1,7 @@
 """Round 6, review item 1: variants of the join-scale search (k = 10, d = 768 fp16, 1 M rows) on ONE box, alternating, each with
 kernel time (the library's events), wall time per call, mean board power and engine clock over >= 3 s of back-to-back calls, and
 the keys compared bit for bit with the list kernel's.  Tuning build (knobs read per call).
-   python tools/join_variants_probe.py [--nq 4096,10000,100000] [--secs 3] [--rounds 2] [--variants list,rq,rqx]"""
+   python tools/join_variants_probe.py [--nq 4096,10000,100000] [--secs 3] [--rounds 2] [--variants list,rq32k,default]"""
 import argparse, json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -16,37 +16,26 @@ ap.add_argument("--nq", default="4096,10000,100000")
 ap.add_argument("--nb", type=int, default=1_000_000)
 ap.add_argument("--secs", type=float, default=3.0)
 ap.add_argument("--rounds", type=int, default=2)
-ap.add_argument("--variants", default="list,rq,rqx")
+ap.add_argument("--variants", default="list,rq32k,default")
 ap.add_argument("--planted", type=int, default=1)
 args = ap.parse_args()
 
 VARIANTS = {  # name -> environment of the tuning build
-    "list": {"LVS_RQ_JOIN": "0", "LVS_RQ_MAXG": "0"},          # the list kernel for everything beyond 256 queries
-    "rq": {"LVS_RQ_JOIN": "1"},                                 # lvs_rq_kernel in chunks of 4 096 queries
-    "rqx": {"LVS_RQ_JOIN": "1", "LVS_RQ_XBAR": "1"},            # + fragment pipeline across the unit barriers
-    "rj": {"LVS_RQ_JOIN": "1", "LVS_RQ_MODE": "2"},             # one wave per SIMD, 64 queries per wave, B fragments in named AGPRs
-    "rjk": {"LVS_RQ_JOIN": "1", "LVS_RJ": "1"},                 # lvs_rj_kernel: the same with deferred insertions, lean staging
-    "rq8k": {"LVS_RQ_JOIN": "1", "LVS_RQ_CHUNK": "8192"},
-    "rq16k": {"LVS_RQ_JOIN": "1", "LVS_RQ_CHUNK": "16384"},
-    "rq32k": {"LVS_RQ_JOIN": "1", "LVS_RQ_CHUNK": "32768"},
+    "default": {},                                              # what the shipped library does: lvs_rj_kernel, chunks of 32 768 queries
+    "list": {"LVS_RQ_JOIN": "0", "LVS_RQ_MAXG": "0"},          # the list kernel for everything beyond 256 queries (round 5's path)
+    "rq": {"LVS_RQ_JOIN": "1", "LVS_RJ": "0", "LVS_RQ_CHUNK": "4096"},   # lvs_rq_kernel (two waves per SIMD) in chunks of 4 096 queries
+    "rq32k": {"LVS_RQ_JOIN": "1", "LVS_RJ": "0", "LVS_RQ_CHUNK": "32768"},
+    "rjk": {"LVS_RQ_JOIN": "1", "LVS_RJ": "1", "LVS_RQ_CHUNK": "4096"},  # lvs_rj_kernel (one wave per SIMD) in chunks of 4 096 queries
     "rjk8k": {"LVS_RQ_JOIN": "1", "LVS_RJ": "1", "LVS_RQ_CHUNK": "8192"},
     "rjk16k": {"LVS_RQ_JOIN": "1", "LVS_RJ": "1", "LVS_RQ_CHUNK": "16384"},
     "rjk32k": {"LVS_RQ_JOIN": "1", "LVS_RJ": "1", "LVS_RQ_CHUNK": "32768"},
     "rjk64k": {"LVS_RQ_JOIN": "1", "LVS_RJ": "1", "LVS_RQ_CHUNK": "65536"},
-    "rjk16k_e4": {"LVS_RQ_JOIN": "1", "LVS_RJ": "1", "LVS_RQ_CHUNK": "16384", "LVS_RJ_EVERY": "4"},
-    "rjk16k_e64": {"LVS_RQ_JOIN": "1", "LVS_RJ": "1", "LVS_RQ_CHUNK": "16384", "LVS_RJ_EVERY": "64"},
-    "d_s8k": {"LVS_RQ_SAMPLE": "8192"},
-    "d_s4k": {"LVS_RQ_SAMPLE": "4096"},
+    "d_s4k": {"LVS_RQ_SAMPLE": "4096"},                         # sample rows of the seed pass
+    "d_s16k": {"LVS_RQ_SAMPLE": "16384"},
     "d_s32k": {"LVS_RQ_SAMPLE": "32768"},
+    "d_e4": {"LVS_RJ_EVERY": "4"},                              # blocks between the waves' common drains
     "d_e8": {"LVS_RJ_EVERY": "8"},
     "d_e32": {"LVS_RJ_EVERY": "32"},
-    "d_e4": {"LVS_RJ_EVERY": "4"},
-    "d_64k": {"LVS_RQ_CHUNK": "65536"},
-    "d_16k": {"LVS_RQ_CHUNK": "16384"},
-    "default": {},
-    "rjn": {"LVS_RQ_JOIN": "1", "LVS_RQ_MODE": "2", "LVS_RQ_XBAR": "0"},
-    "rq2k": {"LVS_RQ_JOIN": "1", "LVS_RQ_CHUNK": "2048"},
-    "rqx2k": {"LVS_RQ_JOIN": "1", "LVS_RQ_XBAR": "1", "LVS_RQ_CHUNK": "2048"},
 }
 KNOBS = sorted({k for v in VARIANTS.values() for k in v})
 
