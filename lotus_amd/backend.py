@@ -377,6 +377,7 @@ class HipBackend:
     # k = 11: 15.9 ms (0.4 % of the queries open) against 20.5 ms with k + 8 slots on the 128-query geometry; k = 12: 17.0 (3.8 % open)
     # against 20.6; k = 13: 21.7 (17 % open) against 20.7
     CERT_MAX_K_SMALL_LISTS = 12
+    CERT_RJ_MIN_QUERIES = 4097  # from here on the certified search's one pass takes the chunked lvs_rj_kernel path (plain lists)
     CERT_BAND_SEARCH = 2.05   # banded lists: rows further than this many error bounds below the k-th one-pass score are not
     CERT_BAND_CERTIFY = 2.02  # listed; the certificate assumes a slightly narrower band (> 2 is what its proof needs)
 
@@ -526,6 +527,13 @@ class HipBackend:
             raise LotusHipError("lvs_flat_search_workspace_bytes rejected the shape")
         ws = self._workspace(need)
         banded = k1 > k
+        # (r6) joins of fp32 embeddings: the one pass over the hi parts runs on the register-resident-queries kernel
+        # (lvs_rj_kernel: chunks of <= 32 768 queries, 0.5 instead of 0.43 of the MFMA roof) whenever the shape is its - that kernel
+        # has no banded admission, so the lists are plain k1-deep ones (k1 <= 16 there) and the certificate the plain one
+        dpad = int(corpus.rows.shape[1]) // (2 if corpus.mode == _capi.PACK_SPLIT else 1)
+        if (banded and first_round and k1 <= 16 and nq >= self.CERT_RJ_MIN_QUERIES and corpus.n >= 65536
+                and dpad in (256, 384, 512, 768) and corpus.mode == queries.mode == _capi.PACK_SPLIT):
+            banded = False
         if banded:
             self._c("lvs_flat_search_keys_hi_banded", _ptr(corpus.rows), corpus.mode, corpus.n, _ptr(queries.rows), queries.mode,
                     nq, corpus.d, metric, k1, k, float(self.CERT_BAND_SEARCH * scale), float(self.CERT_BAND_SEARCH * slack),

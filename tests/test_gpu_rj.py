@@ -124,3 +124,39 @@ def test_a_corpus_of_whole_blocks_and_one_with_a_single_tail_row(hip_backend):
         err, hard, recall = synth.compare_topk(Dr, Ir, D.cpu().numpy(), I.cpu().numpy(), atol=1e-5)
         assert err <= 1e-5 and hard == 0 and recall >= 0.9999
         assert int(I[299, 0]) == nb - 1
+
+
+@pytest.mark.parametrize("metric", [IP, L2])
+def test_fp32_embeddings_take_the_same_kernel_for_their_one_certified_pass(hip_backend, metric):
+    """LOTUS's default embeddings are float32 (hi|lo rows here).  A join of 4 097 queries or more runs its ONE pass over the hi parts
+    on lvs_rj_kernel (plain 15-deep lists instead of the list kernel's banded ones), rescoring and the certificate as before:
+    the exact top k of the plain multi-segment search, and the float32 oracle's ids / scores."""
+    SPLIT = _capi.PACK_SPLIT
+    be = hip_backend
+    nq, nb, d, k = 9_000, 140_001, 256, 10
+    xb = synth.corpus(nb, d, seed=17) * np.float32(1.0 + 2.0 ** -12)  # (values that need their lo halves)
+    xq, _ = synth.queries(xb, nq, seed=18)
+    xb[nb // 3] = xb[9]
+    xq[4], xq[nq - 1] = xb[9], xb[nb - 1]
+    cb = be.pack(xb, SPLIT, exp="auto")
+    cq = be.pack(xq, SPLIT, exp=cb.exp)  # (squared L2 needs one scale on both operands)
+    stats = {}
+    be.timing_enable(True)
+    keys = be.search_keys(cb, cq, k, metric, stats=stats)
+    be.synchronize()
+    t = be.timing_read_full()
+    be.timing_enable(False)
+    assert t["kernel"] in ("lvs_rj_kernel", "lvs_rq_kernel", "lvs_tile_kernel"), t  # (the last timed launch may be the open queries' second round)
+    assert t["launches"] >= 2, t                                                    # ... but the first pass ran in chunks
+    plain = be.search_keys(cb, cq, k, metric, one_pass=False)
+    sexp = be.score_exp_of(cb, cq)
+    Dc, Ic = be.keys_to_result(keys, metric, score_exp=sexp)
+    Dp, Ip = be.keys_to_result(plain, metric, score_exp=sexp)
+    same = (Ic == Ip).float().mean().item()
+    assert same >= 0.9995, same  # (exact scores from two summation orders: only near-ties may swap)
+    assert stats["queries"] == nq and stats["uncertified"] <= 0.02 * nq, stats
+    rows = np.unique(np.concatenate([np.arange(0, nq, 97), [4, nq - 1]]))
+    Dr, Ir = oracle.flat_search(xb, xq[rows], k, metric)
+    dev = be.to_device(rows.astype(np.int64))
+    err, hard, recall = synth.compare_topk(Dr, Ir, Dc[dev].cpu().numpy(), Ic[dev].cpu().numpy(), atol=1e-5)
+    assert err <= 1e-5 and hard == 0 and recall >= 0.9999
