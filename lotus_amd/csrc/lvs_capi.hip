@@ -1914,6 +1914,114 @@ extern "C" int32_t lvs_range_join(const void* xb, int32_t xb_pack, int64_t nb, c
     LVS_REQUIRE(xb && xq && (capacity == 0 || (out_q && out_j && out_s)), "NULL buffer");
     LVS_REQUIRE(metric != LVS_METRIC_L2 || (xb_norms_sq && xq_norms_sq), "L2 needs both norm vectors");
     LVS_DEVICE_GUARD(stream);
+    // (r6) fp16 rows, inner product, one rank's tiles: the register-resident-queries kernel in RANGE mode (lvs_rj.hip) - chunks of
+    // <= 32 768 queries, each against the rows that can still pair with it (a self-join skips the rows below the chunk's first
+    // query: j > i), whole 32-row blocks; the corpus' last nb % 32 rows and chunks left with a short corpus go through the list
+    // kernel below.  Same pairs (keys are scores of the same MFMA sequence), one shared counter.
+    const bool rj_range = lvs_tune("LVS_RJ", LVS_RJ_DEFAULT) != 0 && lvs_tune("LVS_RJ_RANGE", 1) != 0 && xb_pack == LVS_PACK_F16 &&
+                          xq_pack == LVS_PACK_F16 && metric == LVS_METRIC_IP && qt_stride == 1 && nq >= 2048 &&
+                          lvs_rq_shape_ok(p.dpad, 1);
+    // one launch of the list kernel over queries [c0, c0 + cn) x rows [r0, r0 + rn)
+    auto tile_launch = [&](int64_t c0, int64_t cn, int64_t r0, int64_t rn, bool continuation) -> int32_t {
+        Plan pl;
+        LVS_REQUIRE(make_plan(cn, rn, d, xb_pack, xq_pack, 1, pl, true) == LVS_OK, "bad shape");
+        LvsTileArgs a;
+        memset(&a, 0, sizeof(a));
+        a.xb = (const char*)xb + r0 * pl.ldb * 2;
+        a.xq = (const char*)xq + c0 * pl.ldq * 2;
+        a.bn = xb_norms_sq ? xb_norms_sq + r0 : nullptr;
+        a.qn = xq_norms_sq ? xq_norms_sq + c0 : nullptr;
+        a.nb = rn;
+        a.nq = cn;
+        a.ldb = pl.ldb;
+        a.ldq = pl.ldq;
+        a.nseg = pl.nseg;
+        for (int i = 0; i < 3; ++i) {
+            a.seg_q[i] = pl.seg_q[i];
+            a.seg_c[i] = pl.seg_c[i];
+        }
+        a.id_offset = id_offset + r0;
+        a.nkd = pl.nkd;
+        a.nk = pl.nk;
+        a.metric = metric;
+        a.k = 1;
+        a.ntiles = pl.ntiles;
+        a.tiles_per_slab = pl.tiles_per_slab;
+        a.nslab = pl.nslab;
+        a.nqt = pl.nqt;
+        a.bq = pl.v2 ? LVS2_BQ : LVS3_BQ;
+        a.gq = pl.gq;
+        a.lead_slabs = pl.lead_slabs;
+        a.pair_q = (long long*)out_q;
+        a.pair_j = (long long*)out_j;
+        a.pair_s = out_s;
+        a.pair_count = (unsigned long long*)out_count;
+        a.pair_capacity = capacity;
+        a.q_row0 = q_row0 >= 0 ? q_row0 + c0 : -1;
+        a.q_base = c0;
+        a.threshold = threshold * ldexpf(1.0f, score_exp);
+        a.out_scale = ldexpf(1.0f, -score_exp);
+        a.qt_stride = 1;
+        a.qt_phase = 0;
+        ScopedKernelTimer timer((hipStream_t)stream, LVS_KERNEL_TILE, continuation);
+        LVS_HIP_CHECK(lvs_tile_launch(LVS_MODE_RANGE, a, (hipStream_t)stream));
+        return LVS_OK;
+    };
+    if (rj_range) {
+        const int64_t chunk = 32768;
+        bool first = true;
+        for (int64_t c0 = 0, cn = 0; c0 < nq; c0 += cn) {
+            const int64_t left = nq - c0;
+            cn = left >= chunk ? chunk : (left >= 8192 ? 8192 : (left > LVS_RQ_MAXQ ? LVS_RQ_MAXQ : left));
+            // rows that can pair with this chunk's queries: all of them, or (self-join) those above the chunk's first query row
+            int64_t r0 = 0;
+            if (q_row0 >= 0) {
+                r0 = (q_row0 + c0 - id_offset) / 32 * 32;
+                if (r0 < 0) r0 = 0;
+                if (r0 > nb) r0 = nb;
+            }
+            const int64_t r_full = nb / 32 * 32;  // the register-resident kernel sees whole blocks
+            const int64_t rn = r_full - r0;
+            const int64_t groups = (cn + LVS_RQ_GROUPQ - 1) / LVS_RQ_GROUPQ;
+            const bool take = rn >= LVS_RQ_JOIN_MINROWS && cn > 128 && (groups <= 32 || groups % 32 == 0);
+            if (take) {
+                LvsRqArgs ra;
+                memset(&ra, 0, sizeof(ra));
+                ra.xb = (const char*)xb + r0 * p.ldb * 2;
+                ra.xq = (const _Float16*)xq + c0 * p.ldq;
+                ra.nb = rn;
+                ra.ldb = p.ldb;
+                ra.ldq = p.ldq;
+                ra.id_offset = id_offset + r0;
+                ra.nq = (int)cn;
+                ra.k = 1;
+                ra.metric = metric;
+                ra.pair_q = (long long*)out_q;
+                ra.pair_j = (long long*)out_j;
+                ra.pair_s = out_s;
+                ra.pair_count = (unsigned long long*)out_count;
+                ra.pair_capacity = capacity;
+                ra.q_row0 = q_row0 >= 0 ? q_row0 + c0 : -1;
+                ra.q_base = c0;
+                ra.threshold = threshold * ldexpf(1.0f, score_exp);
+                ra.out_scale = ldexpf(1.0f, -score_exp);
+                {
+                    ScopedKernelTimer timer((hipStream_t)stream, LVS_KERNEL_RJ, !first);
+                    LVS_HIP_CHECK(lvs_rj_range_launch(ra, p.dpad, (hipStream_t)stream));
+                }
+                first = false;
+                if (r_full < nb) {  // the corpus' last nb % 32 rows
+                    const int32_t rc = tile_launch(c0, cn, r_full, nb - r_full, true);
+                    if (rc != LVS_OK) return rc;
+                }
+            } else if (nb - r0 > 0) {
+                const int32_t rc = tile_launch(c0, cn, r0, nb - r0, !first);
+                if (rc != LVS_OK) return rc;
+                first = false;
+            }
+        }
+        return LVS_OK;
+    }
     LvsTileArgs a;
     memset(&a, 0, sizeof(a));
     a.xb = xb;

@@ -133,8 +133,11 @@ struct RjGeom {
 };
 
 // NJ = K / 16; KCAP = list slots per query (k <= KCAP); L2: squared-L2 scores (the rows' |y|^2 ride in with the block)
-template <int NJ, int KCAP, bool L2, int DBG = 0>
+// RANGE: the threshold join of sem_dedup (lvs_range_join) on the same frame - no lists, no thresholds to exchange: a score above
+// the (one, constant) threshold goes straight to the global pair list
+template <int NJ, int KCAP, bool L2, int DBG = 0, bool RANGE = false>
 __global__ __launch_bounds__(256, 1) void lvs_rj_kernel(const LvsRqArgs a) {
+    static_assert(!RANGE || !L2, "the RANGE epilogue is built for inner-product scores");
     using G = RjGeom<NJ>;
     constexpr int UK = G::UK, U = G::U, LPW = G::LPW, AD = RJ_AD, RING = G::ring(KCAP), NB_RING = G::nb_ring(RING);
     static_assert(RING >= 4, "LDS budget: the ring must hold the unit being read, the certified one and two in flight");
@@ -180,12 +183,13 @@ __global__ __launch_bounds__(256, 1) void lvs_rj_kernel(const LvsRqArgs a) {
                 else bv[NJ + j - G::NB_AGPR < 0 ? 0 : NJ + j - G::NB_AGPR] = *(const half8*)(qp + j * 16);
             }
         });
-        pub[qb] = valid ? a.gtau[qi] : 0u;
-        tauf[qb] = valid ? rj_tau_float(pub[qb]) : INFINITY;  // lanes without a query never hold a candidate
+        pub[qb] = (valid && !RANGE) ? a.gtau[qi] : 0u;
+        tauf[qb] = valid ? (RANGE ? a.threshold : rj_tau_float(pub[qb])) : INFINITY;  // lanes without a query never hold a candidate
         qnv[qb] = L2 ? a.qn[qrow] : 0.f;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory", RJ_CLOBBER_AGPRS);  // (the loads into named registers are asm: nobody else waits for them)
-    for (int i = lane; i < 64 * KCAP; i += 64) mylists[i] = 0;
+    if constexpr (!RANGE)
+        for (int i = lane; i < 64 * KCAP; i += 64) mylists[i] = 0;
 
     // ---- corpus range of this workgroup, in WHOLE 32-row blocks (the caller searches the last nb % 32 rows elsewhere)
     const long long nblocks = a.nb / 32;
@@ -193,7 +197,8 @@ __global__ __launch_bounds__(256, 1) void lvs_rj_kernel(const LvsRqArgs a) {
     const long long b1 = b0 + a.blocks_per_wg < nblocks ? b0 + a.blocks_per_wg : nblocks;
     if (b0 >= b1) {  // an empty range still owns its slice of the output
         const int q1 = a.nq < qbase + 256 ? a.nq : qbase + 256;
-        for (int i = qbase * k + tid; i < q1 * k; i += 256) a.out[(long long)range * a.nq * k + i] = 0;
+        if constexpr (!RANGE)
+            for (int i = qbase * k + tid; i < q1 * k; i += 256) a.out[(long long)range * a.nq * k + i] = 0;
         return;
     }
     const int nblk = (int)(b1 - b0);
@@ -223,7 +228,7 @@ __global__ __launch_bounds__(256, 1) void lvs_rj_kernel(const LvsRqArgs a) {
             rj_glds16(is_src, soff[i], dst + (unsigned)((wave * LPW + i) * 1024));
         } else {
             if ((is_n & 3) == wave) rj_glds16(is_src, soff[LPW], dst + (unsigned)(UK * 1024));
-            if (is_kh == 0 && is_n < total_units) {
+            if (!RANGE && is_kh == 0 && is_n < total_units) {
                 // the block's side words, one 4-byte DMA per query block: lanes 0 .. 31 -> |y|^2 of its rows (any valid word under
                 // inner product), lanes 32 .. 63 -> the shared thresholds of this wave's queries as the other workgroups left them
                 const long long row0 = (b0 + is_blk) * 32;
@@ -417,7 +422,34 @@ __global__ __launch_bounds__(256, 1) void lvs_rj_kernel(const LvsRqArgs a) {
                         acc[qb][m * 4 + e] = -fmaxf((qnv[qb] + bn4[e]) - 2.0f * acc[qb][m * 4 + e], 0.f);
             }
         }
-        if constexpr (!(DBG & 4)) {
+        if constexpr (RANGE) {
+            // strict ">" as the reference compares (sem_dedup.py:46); a self-join keeps the pairs with row id > query row
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb) {
+                if (!__any(rj_max16(acc[qb]) > tauf[qb])) continue;
+                const long long qg = qidx_of(qb);
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    u64 m[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) m[e] = __ballot(acc[qb][g4 * 4 + e] > tauf[qb]);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (m[e] == 0) continue;
+                        const int r = g4 * 4 + e;
+                        const long long jg = row0 + 4 * (lane >> 5) + (r & 3) + 8 * (r >> 2) + a.id_offset;
+                        if (((m[e] >> lane) & 1) && !(a.q_row0 >= 0 && jg <= a.q_row0 + qg)) {
+                            const unsigned long long pos = atomicAdd(a.pair_count, 1ull);  // (keeps counting past the capacity)
+                            if ((long long)pos < a.pair_capacity) {
+                                a.pair_q[pos] = qg + a.q_base;
+                                a.pair_j[pos] = jg;
+                                a.pair_s[pos] = acc[qb][r] * a.out_scale;
+                            }
+                        }
+                    }
+                }
+            }
+        } else if constexpr (!(DBG & 4)) {
             bool wrote = false;
             const unsigned long long t_v0 = (DBG & 32) ? __builtin_amdgcn_s_memtime() : 0;
 #pragma unroll
@@ -439,7 +471,7 @@ __global__ __launch_bounds__(256, 1) void lvs_rj_kernel(const LvsRqArgs a) {
         } else {
             if (__any(rj_max16(acc[0]) >= 3.0e38f) || __any(rj_max16(acc[1]) >= 3.0e38f)) count = 1;
         }
-        block_end(blk);
+        if constexpr (!RANGE) block_end(blk);
         if (DBG & 32) d_epi += __builtin_amdgcn_s_memtime() - t_e0;
     };
 
@@ -448,7 +480,7 @@ __global__ __launch_bounds__(256, 1) void lvs_rj_kernel(const LvsRqArgs a) {
     // thresholds in.
     auto unit = [&](auto khc, int blk) {
         constexpr int kh = decltype(khc)::value;
-        constexpr bool F = kh == U - 1 && !(DBG & 2) && !(DBG & 256);
+        constexpr bool F = kh == U - 1 && !(DBG & 2) && !(DBG & 256) && !RANGE;
         constexpr int JS = UK - 7;  // the step that reads the side words
         const unsigned o_next = o_base + (slot + 1 == RING ? (unsigned)(-(RING - 1) * G::UB) : (unsigned)G::UB);
         static_for<UK>([&](auto jc) {
@@ -505,6 +537,7 @@ __global__ __launch_bounds__(256, 1) void lvs_rj_kernel(const LvsRqArgs a) {
         if constexpr (!(DBG & 2)) epilogue(blk);
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // the clamped tail loads still target the ring; the last fragment reads
+    if constexpr (RANGE) return;
     drain();
 #ifdef LVS_TUNING
     if ((DBG & 32) && lane == 0) {
@@ -534,7 +567,7 @@ __global__ __launch_bounds__(256, 1) void lvs_rj_kernel(const LvsRqArgs a) {
     }
 }
 
-template <int NJ, int KCAP, bool L2, int DBG = 0>
+template <int NJ, int KCAP, bool L2, int DBG = 0, bool RANGE = false>
 hipError_t rj_launch_k(const LvsRqArgs& a, int grid, hipStream_t stream) {
     using G = RjGeom<NJ>;
     const size_t lds = (size_t)G::lds_bytes(G::ring(KCAP), KCAP);
@@ -543,11 +576,11 @@ hipError_t rj_launch_k(const LvsRqArgs& a, int grid, hipStream_t stream) {
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
     if (!attr.done(dev, lds)) {
-        e = hipFuncSetAttribute((const void*)lvs_rj_kernel<NJ, KCAP, L2, DBG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        e = hipFuncSetAttribute((const void*)lvs_rj_kernel<NJ, KCAP, L2, DBG, RANGE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         attr.set(dev, lds);
     }
-    hipLaunchKernelGGL((lvs_rj_kernel<NJ, KCAP, L2, DBG>), dim3(grid), dim3(256), lds, stream, a);
+    hipLaunchKernelGGL((lvs_rj_kernel<NJ, KCAP, L2, DBG, RANGE>), dim3(grid), dim3(256), lds, stream, a);
     return hipGetLastError();
 }
 template <int NJ>
@@ -598,9 +631,13 @@ bool lvs_rj_fits(int64_t nq, int64_t nb, int dpad, int k, bool has_row_ids) {
     return nq <= LVS_RQ_CHUNK_MAX && groups % 32 == 0 && nb >= LVS_RQ_JOIN_MINROWS;
 }
 
+static hipError_t rj_launch_any(LvsRqArgs& a, int dpad, hipStream_t stream, bool range_mode);
 // a.nb rows are searched in whole 32-row blocks: the caller runs the last a.nb % 32 rows through lvs_rq_launch (one more list per
 // query).  On return a.nparts = candidate lists per query in a.out ([nparts][nq][k]).
-hipError_t lvs_rj_launch(LvsRqArgs& a, int dpad, hipStream_t stream) {
+hipError_t lvs_rj_launch(LvsRqArgs& a, int dpad, hipStream_t stream) { return rj_launch_any(a, dpad, stream, false); }
+// The threshold join on the same launch geometry (whole 32-row blocks; inner product; a.pair_* / a.threshold / a.q_row0 set)
+hipError_t lvs_rj_range_launch(LvsRqArgs& a, int dpad, hipStream_t stream) { return rj_launch_any(a, dpad, stream, true); }
+static hipError_t rj_launch_any(LvsRqArgs& a, int dpad, hipStream_t stream, bool range_mode) {
     const int64_t nblocks = a.nb / 32;
     a.groups = (a.nq + LVS_RQ_GROUPQ - 1) / LVS_RQ_GROUPQ;
     if (a.groups < 1) a.groups = 1;
@@ -615,6 +652,16 @@ hipError_t lvs_rj_launch(LvsRqArgs& a, int dpad, hipStream_t stream) {
     ranges = (nblocks + a.blocks_per_wg - 1) / a.blocks_per_wg;
     a.nparts = (int)ranges;
     const int grid = lvs_rq_grid(a.groups, (int)ranges);
+    if (range_mode) {
+        if (a.metric != LVS_METRIC_IP) return hipErrorInvalidValue;
+        switch (dpad / 16) {
+            case 48: return rj_launch_k<48, 10, false, 0, true>(a, grid, stream);
+            case 32: return rj_launch_k<32, 10, false, 0, true>(a, grid, stream);
+            case 24: return rj_launch_k<24, 10, false, 0, true>(a, grid, stream);
+            case 16: return rj_launch_k<16, 10, false, 0, true>(a, grid, stream);
+            default: return hipErrorInvalidValue;
+        }
+    }
     switch (dpad / 16) {
         case 48: return rj_launch_nj<48>(a, grid, stream);
         case 32: return rj_launch_nj<32>(a, grid, stream);

@@ -39,6 +39,7 @@ struct LvsTileArgs {
     unsigned long long* pair_count;
     long long pair_capacity;
     long long q_row0;         // >= 0: self-join, query r is corpus row q_row0 + r and only pairs j > i are kept
+    long long q_base;         // RANGE: added to the query numbers written to pair_q (a launch over a slice of the call's queries)
     float threshold;
     float out_scale;          // SCORES / RANGE: factor applied to a score on its way out (2^-e of operands packed with a scale)
     int qt_stride, qt_phase;  // only query tiles with qt % qt_stride == qt_phase are processed (multi-GPU deal)
@@ -239,6 +240,14 @@ struct LvsRqArgs {
     int debug;          // -DLVS_TUNING builds only (env LVS_RQ_DEBUG), timing ablations with WRONG results: bit 0 no staging loads in
                         // the loop, bit 1 no block epilogue, bit 2 no MFMAs, bit 3 no fragment reads, bit 4 no unit barrier
     int drain_every;    // lvs_rj_kernel: every wave empties its candidate buffer every that many blocks (a power of two)
+    // lvs_rj_kernel in RANGE mode (threshold join, lvs_range_join): every (query, row) with score > threshold (strict, as
+    // sem_dedup.py:46) is appended to the pair list; q_row0 >= 0: self-join, pairs with row id > query row only
+    long long* pair_q;
+    long long* pair_j;
+    float* pair_s;
+    unsigned long long* pair_count;
+    long long pair_capacity, q_row0, q_base;  // q_base: added to the query numbers written to pair_q (the launch's slice of the call)
+    float threshold, out_scale;
 };
 // blockIdx -> (corpus range, query group) of a grouped launch (lvs_rq_kernel, lvs_rj_kernel).  Workgroup b lands on XCD b % 8
 // (observed; used for speed only): the siblings of a range take slots of ONE XCD, so the range comes from HBM once per XCD and
@@ -277,6 +286,9 @@ hipError_t lvs_rq_launch(LvsRqArgs& a, int dpad, hipStream_t stream);
 #define LVS_RJ_DEFAULT 1    // launches lvs_rj_fits accepts go through lvs_rj_kernel (1) or lvs_rq_kernel (0)
 bool lvs_rj_fits(int64_t nq, int64_t nb, int dpad, int k, bool has_row_ids);
 hipError_t lvs_rj_launch(LvsRqArgs& a, int dpad, hipStream_t stream);  // whole 32-row blocks only: the caller adds the tail
+hipError_t lvs_rj_range_launch(LvsRqArgs& a, int dpad, hipStream_t stream);  // the same geometry, RANGE epilogue (inner product)
+#undef LVS_RQ_JOIN_MINROWS
+#define LVS_RQ_JOIN_MINROWS 32768  // shortest corpus (shard) a chunked call takes (r6: 50 k x 50 k 5.3 -> 4.4 ms; at 20 000 rows the list kernel wins)
 
 int lvs_stream_ranges(int64_t nb, int groups);
 size_t lvs_stream_lds_bytes(int nbfrag, int nqb, int kcap);

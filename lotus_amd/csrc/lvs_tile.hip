@@ -376,7 +376,7 @@ __global__ __launch_bounds__(512, 2) void lvs_tile_kernel(const LvsTileArgs a) {
                             if (a.q_row0 >= 0 && jg <= a.q_row0 + qg) continue;
                             const unsigned long long pos = atomicAdd(a.pair_count, 1ull);
                             if ((long long)pos < a.pair_capacity) {
-                                a.pair_q[pos] = qg;
+                                a.pair_q[pos] = qg + a.q_base;
                                 a.pair_j[pos] = jg;
                                 a.pair_s[pos] = s * a.out_scale;
                             }

@@ -160,3 +160,47 @@ def test_fp32_embeddings_take_the_same_kernel_for_their_one_certified_pass(hip_b
     dev = be.to_device(rows.astype(np.int64))
     err, hard, recall = synth.compare_topk(Dr, Ir, Dc[dev].cpu().numpy(), Ic[dev].cpu().numpy(), atol=1e-5)
     assert err <= 1e-5 and hard == 0 and recall >= 0.9999
+
+
+def test_threshold_self_join_on_the_same_kernel_equals_brute_force(hip_backend, monkeypatch):
+    """sem_dedup's arithmetic (`sem_dedup.py:45-46`: all pairs with score > threshold, strict) at a size where `lvs_range_join` runs
+    on lvs_rj_kernel's RANGE epilogue: chunks of 32 768 query rows, each against the rows above its first query (j > i), the
+    corpus' ragged last rows and the short last chunks through the list kernel - one pair list, the planted pairs exactly."""
+    be = hip_backend
+    n, d = 150_011, 256
+    rng = np.random.default_rng(5)
+    x = synth.corpus(n, d, seed=41)
+    src = rng.choice(n, 3000, replace=False)
+    dst = rng.choice(np.setdiff1d(np.arange(n), src), 3000, replace=False)
+    x[dst] = x[src] + 0.05 * synth.corpus(3000, d, seed=42)            # near-duplicates (cos ~ 0.998), spread over every chunk
+    hard = rng.choice(np.setdiff1d(np.arange(n), np.concatenate([src, dst])), 2000, replace=False)
+    x[hard] = x[(hard + 7) % n] + 0.5 * synth.corpus(2000, d, seed=43)  # hard negatives (cos ~ 0.89)
+    x[n - 1] = x[n - 40_000]                                             # an exact duplicate in the ragged tail
+    x /= np.linalg.norm(x, axis=1, keepdims=True)
+    x16 = x.astype(np.float16)
+    p = be.pack(x16, F16)
+    be.timing_enable(True)
+    q, j, sc = be.range_join(p, p, 0.95, IP, q_row0=0)
+    be.synchronize()
+    t = be.timing_read_full()
+    be.timing_enable(False)
+    assert t["launches"] >= 5, t  # chunks of the register-resident kernel + the list kernel's tails
+    got = set(zip(q.cpu().numpy().tolist(), j.cpu().numpy().tolist()))
+    assert len(got) == int(q.numel())  # no pair twice
+    # brute force over the candidate rows only (every planted row against everything) - float32 on the stored fp16 values
+    s = x16.astype(np.float32)
+    cand = np.unique(np.concatenate([src, dst, hard, (hard + 7) % n, [n - 1, n - 40_000]]))
+    sims = s[cand] @ s.T
+    want, near = set(), set()
+    for a_i, row in zip(cand.tolist(), sims):
+        for b_i in np.nonzero(row > 0.95 - 2e-5)[0].tolist():
+            if b_i == a_i:
+                continue
+            pair = (min(a_i, b_i), max(a_i, b_i))
+            (want if row[b_i] > 0.95 + 2e-5 else near).add(pair)
+    assert want <= got, sorted(want - got)[:5]
+    assert got <= (want | near), sorted(got - want - near)[:5]
+    assert len(want) >= 3000
+    qi, ji = q.cpu().numpy(), j.cpu().numpy()
+    assert np.allclose(sc.cpu().numpy(), np.einsum("ij,ij->i", s[qi], s[ji]), atol=1e-5)
+    assert (ji > qi).all()

@@ -30,6 +30,8 @@ VARIANTS = {  # name -> environment of the tuning build
     "rjk16k": {"LVS_RQ_JOIN": "1", "LVS_RJ": "1", "LVS_RQ_CHUNK": "16384"},
     "rjk32k": {"LVS_RQ_JOIN": "1", "LVS_RJ": "1", "LVS_RQ_CHUNK": "32768"},
     "rjk64k": {"LVS_RQ_JOIN": "1", "LVS_RJ": "1", "LVS_RQ_CHUNK": "65536"},
+    "min16k": {"LVS_RQ_JOIN_MINROWS": "16384"},                # shortest corpus the chunked path takes
+    "min8k": {"LVS_RQ_JOIN_MINROWS": "8192"},
     "d_s4k": {"LVS_RQ_SAMPLE": "4096"},                         # sample rows of the seed pass
     "d_s16k": {"LVS_RQ_SAMPLE": "16384"},
     "d_s32k": {"LVS_RQ_SAMPLE": "32768"},
