@@ -77,3 +77,65 @@ def test_every_range_and_group_has_exactly_one_workgroup_and_siblings_share_an_x
             assert slots == list(range(slots[0], slots[0] + groups))
     # the last group may be ragged; its queries are the call's last ones
     assert (groups - 1) * GROUPQ < nq <= groups * GROUPQ
+
+
+# ---- round 6: chunked calls (lvs_rq_item / lvs_rq_ranges_for / lvs_rq_grid in lvs_tile.h; the chunk policy of lvs_capi.hip) -----
+def ranges_for(groups):
+    return 256 if groups <= 1 else (8 * (32 // groups) if groups <= 32 else 256 // groups)
+
+
+def item(b, groups, nparts):
+    """lvs_rq_item: workgroup b -> (range, group) or None."""
+    if groups <= 1:
+        return b, 0
+    if groups <= 32:
+        s = b >> 3
+        rng = (s // groups) * 8 + (b & 7)
+        return (rng, s % groups) if rng < nparts else None
+    it = (b & 7) * 32 + (b >> 3)
+    rng, grp = divmod(it, groups)
+    return (rng, grp) if rng < nparts else None
+
+
+def chunks(nq, chunk=32768):
+    """The chunk policy: `chunk` queries while that many are left, then 8 192s, one 4 096, the rest."""
+    out, left = [], nq
+    while left > 0:
+        cn = chunk if left >= chunk else (8192 if left >= 8192 else (4096 if left > 4096 else left))
+        out.append(cn)
+        left -= cn
+    return out
+
+
+@pytest.mark.parametrize("groups", [32, 64, 128, 256])
+def test_beyond_32_groups_an_xcd_runs_32_items_of_one_range(groups):
+    ranges = ranges_for(groups)
+    assert groups * ranges == CUS  # one workgroup per CU, every CU busy
+    seen = {}
+    for b in range(CUS if groups > 32 else 8 * groups * -(-ranges // 8)):
+        m = item(b, groups, ranges)
+        assert m is not None and m not in seen
+        seen[m] = b
+    assert set(seen) == set(itertools.product(range(ranges), range(groups)))
+    for x in range(XCDS):
+        mine = [m for m, b in seen.items() if b % XCDS == x]
+        assert len(mine) == 32
+        if groups >= 32:
+            assert len({rng for rng, _ in mine}) == 1  # the XCD's 32 workgroups stream ONE range through its L2
+    # the earlier rule is unchanged up to 32 groups
+    for g in range(2, 33):
+        for b in range(8 * g * -(-ranges_for(g) // 8)):
+            assert item(b, g, ranges_for(g)) == block_map(b, g, ranges_for(g))
+
+
+@pytest.mark.parametrize("nq", [4097, 5000, 9000, 10_000, 20_000, 33_000, 40_000, 65_536, 100_000, 1_000_000])
+def test_chunk_policy_covers_the_queries_with_launchable_group_counts(nq):
+    cs = chunks(nq)
+    assert sum(cs) == nq and all(c > 0 for c in cs)
+    for c in cs[:-1]:
+        assert c in (32768, 8192, 4096)
+    for c in cs:
+        groups = -(-c // GROUPQ)
+        assert groups <= 32 or groups % 32 == 0  # what lvs_rq_launch / lvs_rj_launch accept
+    assert cs == sorted(cs, reverse=True)
+    assert chunks(100_000) == [32768, 32768, 32768, 1696]
