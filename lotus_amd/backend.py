@@ -197,6 +197,7 @@ class HipBackend:
         return tuple(h.numpy() for h in outs)
 
     CALL_PIPELINE_MIN_QUERIES = 32768
+    CALL_CHUNK = 32768  # queries per launch of a chunked search (LVS_RQ_CHUNK_DEFAULT, lotus_amd/csrc/lvs_tile.h)
     CALL_PIPELINE = (0.1, 0.9)  # shares of the queries per stage: a short first stage (its H2D is the exposed one; measured at
     # 100 k x 1 M, tools/tcall_probe.py: one stage 144.0 ms, (0.1, 0.9) 139.2, (0.2, 0.8) 141.5, (0.5, 0.5) 145.1, three or four
     # stages 141.8-150.1 against 135.9 ms device-resident - shorter launches run further below the long-stream rate)
@@ -210,8 +211,15 @@ class HipBackend:
         torch = self.torch
         nq, d = int(q.shape[0]), int(q.shape[1])
         cuts = [0]
-        for share in self.CALL_PIPELINE[:-1]:
-            cuts.append(min(nq, (int(nq * share) + cuts[-1] + 255) // 256 * 256))
+        if nq > 2 * self.CALL_CHUNK:
+            # (r6) stages cut where the search cuts its chunks (lvs_flat_search_keys: launches of 32 768 queries, the remainder
+            # last): a stage of the remainder (copy: a few MB), one chunk, then everything else - no stage splits a chunk into
+            # the smaller, slower launches, and every copy but the first tiny one runs under a search
+            r = nq % self.CALL_CHUNK
+            cuts += [r, r + self.CALL_CHUNK] if r >= 256 else [self.CALL_CHUNK]
+        else:
+            for share in self.CALL_PIPELINE[:-1]:
+                cuts.append(min(nq, (int(nq * share) + cuts[-1] + 255) // 256 * 256))
         cuts.append(nq)
         stages = [(a, b) for a, b in zip(cuts[:-1], cuts[1:]) if b > a]
         tdt = torch.float16 if q.dtype == np.float16 else torch.float32
