@@ -964,13 +964,27 @@ class HipBackend:
         capacity) - a 5 M-row self-join repeats at most 1/77 of its work, not all of it."""
         torch = self.torch
         step = max(256 * stride, self.RANGE_CHUNK_ROWS // (256 * stride) * (256 * stride))
+        # (r6) several ranks and a join the register-resident kernel's RANGE mode takes (fp16 rows, inner product, a long corpus):
+        # whole CHUNKS of query rows are dealt to the ranks instead of 256-query tiles inside every launch - each chunk then runs
+        # on that kernel as on one GPU.  Snake order (0 .. w-1, w-1 .. 0, ...): a self-join's early chunks see more rows than its
+        # late ones, and plain round-robin would hand rank 0 the heavier chunk of every round.  Every rank applies the same rule,
+        # so the ranks' pair lists partition the result.
+        deal_chunks = (stride > 1 and metric == _capi.METRIC_IP and corpus.mode == queries.mode == _capi.PACK_F16
+                       and corpus.n >= 2 * self.RANGE_CHUNK_ROWS and queries.n >= 2 * self.RANGE_CHUNK_ROWS
+                       and int(corpus.rows.shape[1]) in (256, 384, 512, 768))
+        if deal_chunks:
+            step = self.RANGE_CHUNK_ROWS
         outs = []
         cnt = torch.zeros((1,), dtype=torch.int64, device=self.device)
         oq = oj = os_ = None
-        for c0 in range(0, max(queries.n, 1), step):
+        for ci, c0 in enumerate(range(0, max(queries.n, 1), step)):
             c1 = min(queries.n, c0 + step)
             if c1 <= c0:
                 break
+            if deal_chunks:
+                rnd, pos = divmod(ci, stride)
+                if (pos if rnd % 2 == 0 else stride - 1 - pos) != phase:
+                    continue
             qs = self.slice_rows(queries, c0, c1)
             cap = capacity
             while True:
@@ -981,8 +995,8 @@ class HipBackend:
                 cnt.zero_()
                 self._c("lvs_range_join", _ptr(corpus.rows), corpus.mode, corpus.n, _ptr(qs.rows), qs.mode, qs.n,
                         corpus.d, metric, _ptr(corpus.norms), _ptr(qs.norms), float(threshold),
-                        self.score_exp_of(corpus, qs), int(q_row0 + c0) if q_row0 >= 0 else -1, int(id_offset), int(stride),
-                        int(phase), int(cap),
+                        self.score_exp_of(corpus, qs), int(q_row0 + c0) if q_row0 >= 0 else -1, int(id_offset),
+                        1 if deal_chunks else int(stride), 0 if deal_chunks else int(phase), int(cap),
                         _ptr(oq), _ptr(oj), _ptr(os_), _ptr(cnt), self._stream())
                 n = int(cnt.item())
                 if n <= cap:

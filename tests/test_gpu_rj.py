@@ -204,3 +204,8 @@ def test_threshold_self_join_on_the_same_kernel_equals_brute_force(hip_backend, 
     qi, ji = q.cpu().numpy(), j.cpu().numpy()
     assert np.allclose(sc.cpu().numpy(), np.einsum("ij,ij->i", s[qi], s[ji]), atol=1e-5)
     assert (ji > qi).all()
+    # several ranks: whole chunks of query rows are dealt to them (snake order) - three "ranks" partition the result
+    parts = [be.range_join(p, p, 0.95, IP, q_row0=0, stride=3, phase=r) for r in range(3)]
+    sets = [set(zip(a.cpu().numpy().tolist(), b.cpu().numpy().tolist())) for a, b, _ in parts]
+    assert all(sets) and not (sets[0] & sets[1]) and not (sets[0] & sets[2]) and not (sets[1] & sets[2])
+    assert (sets[0] | sets[1] | sets[2]) == got
